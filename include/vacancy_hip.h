@@ -1,0 +1,198 @@
+/*
+ * vacancy_hip.h -- C-ABI of the MI355X-native voxel-carving hot path.
+ *
+ * This is the drop-in boundary.  The reference (unclearness/vacancy) has no FFI
+ * layer of its own: its hot path is reached through the C++ class
+ * vacancy::VoxelCarver (include/vacancy/voxel_carver.h:95-118).  Every entry
+ * point below names the reference member/function it replaces; the C++ facade in
+ * include/vacancy/ (this repo) keeps the reference's class API and forwards to
+ * these symbols (see INTEGRATION.md for the exact binding).
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the boundary;
+ *   - every function returns VCY_OK (0) or a negative vcy_status; the text of the
+ *     last error on the calling thread is vcy_last_error();
+ *   - inputs are caller-owned and never retained past the call unless the
+ *     function name says "_device" (then the pointer is a HIP device pointer that
+ *     must stay valid until vcy_sync());
+ *   - outputs that the library allocates are released with the matching *_free;
+ *   - one context = one GPU = one caller thread.  A context owns a z-slab
+ *     [z_begin, z_end) of the global grid (the whole grid when world size is 1).
+ *   - there is NO CPU fallback: if no HIP device is usable, vcy_create fails.
+ */
+#ifndef VACANCY_HIP_H_
+#define VACANCY_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vcy_status {
+  VCY_OK = 0,
+  VCY_ERR_INVALID_ARG = -1,   /* reference: `return false` + LOGE in Init()/Carve() */
+  VCY_ERR_NOT_INITIALIZED = -2,
+  VCY_ERR_TOO_MANY_VOXELS = -3,
+  VCY_ERR_HIP = -4,           /* a HIP runtime call failed */
+  VCY_ERR_NO_DEVICE = -5,
+  VCY_ERR_UNSUPPORTED = -6
+} vcy_status;
+
+/* vacancy::VoxelUpdate / SdfInterpolation / UpdateOutsideImage
+ * (include/vacancy/voxel_carver.h:20-38) */
+enum { VCY_UPDATE_MAX = 0, VCY_UPDATE_WEIGHTED_AVERAGE = 1 };
+enum { VCY_INTERP_NN = 0, VCY_INTERP_BILINEAR = 1 };
+enum { VCY_OUTSIDE_NONE = 0, VCY_OUTSIDE_MAX = 1 };
+
+/* vacancy::VoxelUpdateOption (voxel_carver.h:43-52), same defaults. */
+typedef struct vcy_update_option {
+  int32_t voxel_update;          /* VCY_UPDATE_*           default kMax      */
+  int32_t sdf_interp;            /* VCY_INTERP_*           default kBilinear */
+  int32_t update_outside;        /* VCY_OUTSIDE_*          default kNone     */
+  int32_t voxel_max_update_num;  /*                        default 255       */
+  float   voxel_update_weight;   /*                        default 1.0f      */
+  int32_t use_truncation;        /* bool                   default false     */
+  float   truncation_band;       /*                        default 0.1f      */
+} vcy_update_option;
+
+/* vacancy::VoxelCarverOption (voxel_carver.h:54-60). */
+typedef struct vcy_carver_option {
+  float bb_max[3];
+  float bb_min[3];
+  float resolution;              /* default 0.1f */
+  int32_t sdf_minmax_normalize;  /* bool, default true */
+  vcy_update_option update_option;
+} vcy_carver_option;
+
+/* Everything Carve() reads from `const Camera&` plus the ROI:
+ *   w2c      = camera.w2c().cast<float>() (voxel_carver.cc:438), row-major 3x4
+ *   fx,fy,cx,cy = PinholeCamera focal_length / principal_point (camera.cc:131-137)
+ *   is_ortho = OrthoCamera::Project (camera.cc:201-205)
+ *   roi_min/roi_max = the Vector2i arguments of Carve (voxel_carver.cc:415-416)
+ *   width,height = sdf.width()/height() (image.h:65-74 layout: data[w*y+x]) */
+typedef struct vcy_view {
+  float   w2c[12];
+  float   fx, fy, cx, cy;
+  int32_t is_ortho;
+  int32_t roi_min[2];
+  int32_t roi_max[2];
+  int32_t width, height;
+} vcy_view;
+
+/* Output of marching cubes: what MarchingCubes() hands to
+ * Mesh::set_vertices / set_vertex_indices (marching_cubes.cc:223-224), plus the
+ * dedup key of every vertex (the sorted voxel-id pair, marching_cubes.cc:78). */
+typedef struct vcy_mesh {
+  int64_t  n_vertices;
+  int64_t  n_faces;
+  float*   vertices;   /* 3 * n_vertices, xyz                         */
+  int32_t* faces;      /* 3 * n_faces, indices into vertices          */
+  int64_t* edge_keys;  /* 2 * n_vertices, (lower id, higher id), GLOBAL voxel ids */
+} vcy_mesh;
+
+typedef struct vcy_ctx vcy_ctx;
+
+/* ---- lifetime ----------------------------------------------------------- */
+
+/* Replaces VoxelCarver::set_option + VoxelCarver::Init (voxel_carver.cc:373-392)
+ * and VoxelGrid::Init (voxel_carver.cc:276-345): validates the options with the
+ * reference's rules, sizes the grid n[i] = (int)((bb_max-bb_min)[i]/resolution),
+ * allocates the slab z in [z_begin, z_end) on `device_id` (pass z_begin=0,
+ * z_end=-1 for the whole grid) and sets sdf = lowest(), update_num = 0. */
+int vcy_create(const vcy_carver_option* option, int device_id, int z_begin,
+               int z_end, vcy_ctx** out);
+void vcy_destroy(vcy_ctx* ctx);
+
+/* VoxelGrid::voxel_num() (voxel_carver.cc:347): global dims (nx,ny,nz). */
+int vcy_grid_dims(const vcy_ctx* ctx, int32_t dims[3]);
+/* The z-range this context owns. */
+int vcy_slab_range(const vcy_ctx* ctx, int32_t z_range[2]);
+/* Grid dims without creating a context (host arithmetic of VoxelGrid::Init). */
+int vcy_compute_dims(const float bb_min[3], const float bb_max[3],
+                     float resolution, int32_t dims[3]);
+
+/* ---- carving ------------------------------------------------------------ */
+
+/* Replaces bool VoxelCarver::Carve(const Camera&, const Vector2i& roi_min,
+ * const Vector2i& roi_max, const Image1f& sdf) (voxel_carver.cc:415-496).
+ * `sdf_host` is row-major float[height*width]. */
+int vcy_carve(vcy_ctx* ctx, const vcy_view* view, const float* sdf_host);
+/* Same, SDF image already resident in HBM on the context's device. */
+int vcy_carve_device(vcy_ctx* ctx, const vcy_view* view, const float* sdf_device);
+/* Replaces the loop of Carve(const std::vector<Camera>&, ...)
+ * (voxel_carver.cc:516-528) for pre-built SDFs: fuses `n_views` views in
+ * sequence order with the voxel state held in registers across views.  The
+ * result is bit-identical to n_views calls of vcy_carve_device. */
+int vcy_carve_batch_device(vcy_ctx* ctx, int n_views, const vcy_view* views,
+                           const float* const* sdf_device);
+/* Replaces bool VoxelCarver::Carve(const Camera&, const Image1b& silhouette,
+ * const Vector2i& roi_min, const Vector2i& roi_max, Image1f* sdf)
+ * (voxel_carver.cc:394-413): MakeSignedDistanceField then the carve.
+ * `sdf_out_host` (may be NULL) receives the SDF image like the Image1f* does. */
+int vcy_carve_silhouette(vcy_ctx* ctx, const vcy_view* view,
+                         const uint8_t* mask_host, float* sdf_out_host);
+
+/* Replaces void DistanceTransformL1(...) (voxel_carver.cc:102-167). */
+int vcy_distance_transform_l1(const uint8_t* mask, int width, int height,
+                              const int32_t roi_min[2], const int32_t roi_max[2],
+                              float* dist_out);
+/* Replaces void MakeSignedDistanceField(...) (voxel_carver.cc:169-237). */
+int vcy_make_sdf(const uint8_t* mask, int width, int height,
+                 const int32_t roi_min[2], const int32_t roi_max[2],
+                 int minmax_normalize, int use_truncation, float truncation_band,
+                 float* sdf_out);
+
+/* ---- surface extraction ------------------------------------------------- */
+
+/* Replaces void VoxelCarver::ExtractIsoSurface(Mesh*, double iso_level,
+ * bool linear_interp) (voxel_carver.cc:540-543) = MarchingCubes()
+ * (marching_cubes.cc:63-228).  Vertex order and face order equal the
+ * reference's serial scan (first reference in z,y,x order). */
+int vcy_extract_iso(vcy_ctx* ctx, double iso_level, int linear_interp,
+                    vcy_mesh* out);
+void vcy_mesh_free(vcy_mesh* mesh);
+
+/* ---- state access (tests, ExtractVoxel on the host, checkpoint) ---------- */
+
+/* Copies the slab's voxel state to the host: sdf[nx*ny*nz_local] and
+ * update_num[nx*ny*nz_local] in the reference's linear order
+ * id = z*nx*ny + y*nx + x (voxel_carver.cc:333,349-355).  Either may be NULL. */
+int vcy_download(vcy_ctx* ctx, float* sdf, int32_t* update_num);
+int vcy_upload(vcy_ctx* ctx, const float* sdf, const int32_t* update_num);
+/* Voxel centres of the slab, 3 floats per voxel (Voxel::pos, voxel_carver.cc:315-337). */
+int vcy_download_positions(vcy_ctx* ctx, float* pos);
+
+/* ---- multi-GPU halo (one process per GPU; the exchange itself is one RCCL
+ * all-gather issued by the caller on the buffers below) ------------------- */
+
+/* Bytes one rank contributes: its first two and last two xy-slices of
+ * (sdf, update_num). */
+int64_t vcy_halo_bytes(const vcy_ctx* ctx);
+/* Packs this slab's boundary slices into `send_device` (vcy_halo_bytes bytes). */
+int vcy_halo_pack(vcy_ctx* ctx, void* send_device);
+/* Installs the neighbours' slices from the all-gathered buffer
+ * (world * vcy_halo_bytes bytes, rank-major). */
+int vcy_halo_unpack(vcy_ctx* ctx, const void* gathered_device, int rank, int world);
+
+/* ---- device memory / stream / timing helpers ----------------------------- */
+
+int vcy_device_count(int* count);
+int vcy_sdf_upload(vcy_ctx* ctx, const float* sdf_host, int width, int height,
+                   float** sdf_device_out);
+int vcy_device_free(vcy_ctx* ctx, void* device_ptr);
+/* Use an existing hipStream_t (e.g. torch's current stream) for all launches. */
+int vcy_set_stream(vcy_ctx* ctx, void* hip_stream);
+int vcy_sync(vcy_ctx* ctx);
+/* hipEvent pair recorded on the context's stream around whatever is launched
+ * between begin and end; vcy_timer_end synchronises and returns milliseconds. */
+int vcy_timer_begin(vcy_ctx* ctx);
+int vcy_timer_end(vcy_ctx* ctx, float* elapsed_ms);
+
+const char* vcy_last_error(void);
+const char* vcy_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VACANCY_HIP_H_ */
