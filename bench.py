@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Benchmark of the voxel-carving hot path on MI355X.
+
+A step = one pass of the hot path over one batch of synthetic input: reset the grid, then
+carve V silhouette SDFs (already resident in HBM) into the N^3 grid.  The headline workload is
+BASELINE.json configs[2]/[3]: 1024^3 voxels x 32 views at 1280x720, default update mode (kMax,
+bilinear); with --gpus G the grid is sharded by z-slab across G ranks (one process per GPU,
+no collective in the carve path, so total work is fixed: strong scaling).
+
+Prints ONE JSON line (rank 0).  value = whole-job Mvoxel*views/s.  The marching-cubes rate
+(Mcells/s) is measured after the timed region and reported in the same line under "mc".
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=1024)
+    ap.add_argument("--views", type=int, default=32)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--mode", default="default", choices=["default", "tsdf"])
+    ap.add_argument("--batch", type=int, default=1, help="1: fused multi-view carve; 0: one launch per view")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mc", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, views, sdfs, budget_s):
+    """Times the CPU oracle (faithful restatement of the reference's OpenMP loop, AoS 40-byte
+    voxels) on a bounded sample of the same workload: a (grid/4)^3... sub-sampled grid with the
+    same bounding box, cameras and SDF images, as many views as fit the time budget."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from vacancy_amd import synth
+    from vacancy_amd.capi import UpdateOption
+
+    lib = O.load()
+    n_cpu = min(args.grid, 320)
+    uo = UpdateOption(voxel_update=1, use_truncation=True, truncation_band=0.1) if args.mode == "tsdf" \
+        else UpdateOption()
+    # same scene, coarser voxels: bb = +-grid/2, resolution = grid / n_cpu
+    opt = synth.sphere_option(args.grid, uo)
+    opt.resolution = float(args.grid) / n_cpu
+    g = O.OracleGrid(opt)
+    t_total, n_done = 0.0, 0
+    for i in range(len(views)):
+        ms = g.carve(views[i], sdfs[i])
+        t_total += ms / 1e3
+        n_done += 1
+        if t_total > budget_s:
+            break
+    t0 = time.time()
+    mesh = g.marching_cubes(0.0, True)
+    mc_s = mesh["ms"] / 1e3
+    cells = (g.dims[0] - 1) * (g.dims[1] - 1) * (g.dims[2] - 1)
+    threads = lib.orc_omp_max_threads()
+    return {
+        "value": round(g.n * n_done / t_total / 1e6, 2),
+        "unit": "Mvoxel*views/s",
+        "cores": int(threads),
+        "kind": "port",
+        "sample": "oracle (OpenMP over z, %d threads), %d^3 grid over the same scene, %d of %d views at %dx%d; "
+                  "times the Carve main loop only (reference voxel_carver.cc:435,492)"
+                  % (threads, n_cpu, n_done, len(views), args.width, args.height),
+        "mc_mcells_per_s": round(cells / mc_s / 1e6, 2),
+        "mc_sample": "oracle MarchingCubes (serial std::map, like the reference) on the carved %d^3 grid" % n_cpu,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    dist = None
+    torch = None
+    if world > 1:
+        import torch  # device plumbing + RCCL only
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from vacancy_amd import carver as vc
+    from vacancy_amd import dist as vdist
+    from vacancy_amd import synth
+    from vacancy_amd.capi import UpdateOption
+
+    n, nv = args.grid, args.views
+    uo = UpdateOption(voxel_update=1, use_truncation=True, truncation_band=0.1) if args.mode == "tsdf" \
+        else UpdateOption()
+    opt = synth.sphere_option(n, uo)
+    views, masks = synth.sphere_views(n, nv, args.width, args.height)
+    sdf0 = vc.make_sdf(masks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
+    sdfs = [sdf0] * nv  # every view sees the same centred disc; the cameras differ
+
+    z0, z1 = vdist.slab_range(n, rank, world)
+    dev = vc.VoxelCarver(opt, device_id=local_rank, z_range=(z0, z1))
+    if not dev.Init():
+        raise SystemExit("vcy_create failed: " + vc.last_error())
+    d_sdf = [dev.upload_sdf(s) for s in sdfs]  # inputs resident in HBM before the timed region
+
+    def barrier():
+        dev.sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    kernel_ms = []
+
+    def step(record):
+        dev.reset()
+        dev.timer_begin()
+        if args.batch:
+            ok = dev.CarveBatchDevice(views, d_sdf)
+        else:
+            ok = all(dev.CarveDevice(views[i], d_sdf[i]) for i in range(nv))
+        ms = dev.timer_end()
+        if not ok:
+            raise SystemExit("carve failed: " + vc.last_error())
+        if record:
+            kernel_ms.append(ms)
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_vv = float(n) ** 3 * nv * args.steps
+    value = total_vv / elapsed / 1e6
+
+    # roofline of the dominant kernel (carve), this rank's slab: algorithmic bytes per launch /
+    # launch duration from HIP events on the launch stream.
+    bytes_per_vv = 4.0 if args.mode == "default" else 4.0 + (1 if uo.voxel_max_update_num <= 254 else 2)
+    slab_vox = dev.slab_voxels
+    launches_per_step = 1 if args.batch else nv
+    views_per_launch = nv if args.batch else 1
+    avg_launch_ms = sum(kernel_ms) / len(kernel_ms) / launches_per_step
+    achieved = slab_vox * views_per_launch * bytes_per_vv / (avg_launch_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = "%s_%d_%d_b%d" % (args.mode, n, nv, args.batch)
+            traffic = tj.get(key, {}).get("hbm_bytes_per_launch") if world == 1 else None
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "carve_batch" if args.batch else "carve_view",
+                "avg_launch_ms": round(avg_launch_ms, 4),
+                "algorithmic_bytes_per_launch": slab_vox * views_per_launch * bytes_per_vv}
+
+    # marching cubes (second half of the metric), outside the timed region
+    mc = None
+    if not args.no_mc:
+        vdist.exchange_halo(dev, rank, world)
+        mesh = dev.ExtractIsoSurface(0.0, True)
+        mesh = dev.ExtractIsoSurface(0.0, True)  # second run: scratch allocation warmed
+        cells_local = (n - 1) * (n - 1) * (z1 - max(z0, 1))
+        mc_ms = mesh["device_ms"]
+        nvert, nface = len(mesh["vertices"]) - mesh["n_foreign"], len(mesh["faces"])
+        if dist is not None:
+            t = torch.tensor([mc_ms, float(nvert), float(nface)], dtype=torch.float64, device="cuda")
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            mc_ms, nvert, nface = float(tmax[0].item()), int(t[1].item()), int(t[2].item())
+        cells = float(n - 1) ** 2 * (n - 1)
+        mc = {"mcells_per_s": round(cells / (mc_ms * 1e-3) / 1e6, 1), "device_ms": round(mc_ms, 3),
+              "vertices": int(nvert), "faces": int(nface),
+              "roofline_frac": round(cells * 4.0 / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del cells_local
+
+    out = {
+        "metric": "Mvoxel*views/s (Carve)", "value": round(value, 1), "unit": "Mvoxel*views/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%d^3 grid x %d views at %dx%d, %s mode, z-slab sharded over %d GPU(s)"
+                               % (n, nv, args.width, args.height, args.mode, world),
+                   "grid": n, "views": nv, "image": [args.width, args.height], "mode": args.mode,
+                   "fused_views_per_launch": views_per_launch},
+        "roofline": roofline, "mc": mc,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, views, sdfs, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    for p in d_sdf:
+        dev.free_device(p)
+    dev.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

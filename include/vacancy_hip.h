@@ -89,6 +89,10 @@ typedef struct vcy_mesh {
   float*   vertices;   /* 3 * n_vertices, xyz                         */
   int32_t* faces;      /* 3 * n_faces, indices into vertices          */
   int64_t* edge_keys;  /* 2 * n_vertices, (lower id, higher id), GLOBAL voxel ids */
+  /* Multi-GPU only (0 for a whole grid): the first n_foreign_vertices entries duplicate
+   * vertices that the previous z-slab owns (edges on the shared plane z_begin-1); a merge
+   * maps them onto that slab's numbering by edge key. */
+  int64_t  n_foreign_vertices;
 } vcy_mesh;
 
 typedef struct vcy_ctx vcy_ctx;
@@ -152,6 +156,10 @@ int vcy_make_sdf(const uint8_t* mask, int width, int height,
 int vcy_extract_iso(vcy_ctx* ctx, double iso_level, int linear_interp,
                     vcy_mesh* out);
 void vcy_mesh_free(vcy_mesh* mesh);
+/* Milliseconds the device kernels of the last vcy_extract_iso took (hipEvents on the
+ * context's stream: classify + owner + scan + emit; the mesh download is not included).
+ * This is the region the reference's MarchingCubes timer brackets, minus the copy into Mesh. */
+int vcy_last_extract_ms(const vcy_ctx* ctx, float* device_ms);
 
 /* ---- state access (tests, ExtractVoxel on the host, checkpoint) ---------- */
 
@@ -166,8 +174,8 @@ int vcy_download_positions(vcy_ctx* ctx, float* pos);
 /* ---- multi-GPU halo (one process per GPU; the exchange itself is one RCCL
  * all-gather issued by the caller on the buffers below) ------------------- */
 
-/* Bytes one rank contributes: its first two and last two xy-slices of
- * (sdf, update_num). */
+/* Bytes one rank contributes: the LAST two xy-slices of its slab, (sdf, update_num).
+ * Rank r consumes rank r-1's contribution as its slices z_begin-2, z_begin-1. */
 int64_t vcy_halo_bytes(const vcy_ctx* ctx);
 /* Packs this slab's boundary slices into `send_device` (vcy_halo_bytes bytes). */
 int vcy_halo_pack(vcy_ctx* ctx, void* send_device);
@@ -181,6 +189,12 @@ int vcy_device_count(int* count);
 int vcy_sdf_upload(vcy_ctx* ctx, const float* sdf_host, int width, int height,
                    float** sdf_device_out);
 int vcy_device_free(vcy_ctx* ctx, void* device_ptr);
+int vcy_device_alloc(vcy_ctx* ctx, int64_t bytes, void** device_ptr_out);
+int vcy_memcpy_h2d(vcy_ctx* ctx, void* dst_device, const void* src_host, int64_t bytes);
+int vcy_memcpy_d2h(vcy_ctx* ctx, void* dst_host, const void* src_device, int64_t bytes);
+/* Back to the state right after vcy_create (VoxelGrid::Init: sdf = lowest(), update_num = 0);
+ * asynchronous on the context's stream. */
+int vcy_reset(vcy_ctx* ctx);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all launches. */
 int vcy_set_stream(vcy_ctx* ctx, void* hip_stream);
 int vcy_sync(vcy_ctx* ctx);

@@ -1,0 +1,207 @@
+"""GPU parity tests: the HIP path (through the C-ABI, via the Python mirror of VoxelCarver)
+against the CPU oracle on the same inputs.  Bit-exact: sdf bits, update_num, marching-cubes
+vertex array, face array and edge keys (including their ORDER, which equals the reference's
+serial scan)."""
+import numpy as np
+import pytest
+
+import bunny_data as B
+import oracle_lib as O
+from vacancy_amd import carver as vc
+from vacancy_amd import synth
+from vacancy_amd.capi import UpdateOption
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_state_equal(dev, orc, ctx=""):
+    ds, du = dev.download()
+    os_, ou = orc.download()
+    assert np.array_equal(du, ou), "%s update_num differs at %d voxels" % (ctx, int((du != ou).sum()))
+    assert np.array_equal(ds.view(np.uint32), os_.view(np.uint32)), \
+        "%s sdf bits differ at %d voxels" % (ctx, int((ds.view(np.uint32) != os_.view(np.uint32)).sum()))
+
+
+def assert_mesh_equal(dm, om, ctx=""):
+    assert dm["vertices"].shape == om["vertices"].shape, (ctx, dm["vertices"].shape, om["vertices"].shape)
+    assert dm["faces"].shape == om["faces"].shape, (ctx, dm["faces"].shape, om["faces"].shape)
+    assert np.array_equal(dm["keys"], om["keys"]), ctx + " edge keys / vertex order differ"
+    assert np.array_equal(dm["faces"], om["faces"]), ctx + " faces differ"
+    assert np.array_equal(dm["vertices"].view(np.uint32), om["vertices"].view(np.uint32)), \
+        ctx + " vertex bits differ"
+
+
+@pytest.mark.parametrize("mode", list(B.MODES))
+def test_bunny_all_views(mode):
+    """configs[0]: data/ bunny, 6 masks + tumpose, resolution 10 (54x53x42)."""
+    uo = UpdateOption(**B.MODES[mode])
+    opt = B.bunny_option(10.0, uo)
+    views = B.bunny_views(lambda t, q: synth.affine_inverse(synth.pose_from_tum(t, q)))
+    masks = B.load_masks()
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init(), vc.last_error()
+    orc = O.OracleGrid(opt)
+    assert dev.dims == orc.dims
+    assert np.array_equal(dev.positions().view(np.uint32), orc.positions().view(np.uint32))
+    for i in range(6):
+        ok, sdf = dev.CarveSilhouette(views[i], masks[i], return_sdf=True)
+        assert ok, vc.last_error()
+        osdf = O.make_sdf(masks[i], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
+        assert np.array_equal(sdf.view(np.uint32), osdf.view(np.uint32))
+        orc.carve(views[i], osdf)
+        assert_state_equal(dev, orc, "%s view %d" % (mode, i))
+        for interp in (True, False):
+            assert_mesh_equal(dev.ExtractIsoSurface(0.0, interp), orc.marching_cubes(0.0, interp),
+                              "%s view %d interp=%s" % (mode, i, interp))
+    if mode == "default":
+        m = dev.ExtractIsoSurface(0.0, True)
+        assert (len(m["vertices"]), len(m["faces"])) == (8672, 17270)
+
+
+def test_bunny_fine_grid():
+    opt = B.bunny_option(2.5)
+    views = B.bunny_views(lambda t, q: synth.affine_inverse(synth.pose_from_tum(t, q)))
+    masks = B.load_masks()
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init(), vc.last_error()
+    orc = O.OracleGrid(opt)
+    for i in range(6):
+        sdf = O.make_sdf(masks[i])
+        assert dev.Carve(views[i], sdf)
+        orc.carve(views[i], sdf)
+    assert_state_equal(dev, orc, "res 2.5")
+    dm, om = dev.ExtractIsoSurface(), orc.marching_cubes()
+    assert (len(dm["vertices"]), len(dm["faces"])) == (144594, 288938)
+    assert_mesh_equal(dm, om, "res 2.5")
+
+
+SYN_MODES = {
+    "default": dict(),
+    "tsdf": dict(voxel_update=1, use_truncation=True, truncation_band=0.1),
+    "tsdf_weight": dict(voxel_update=1, voxel_update_weight=0.37),
+    "nn": dict(sdf_interp=0),
+    "outside_max": dict(update_outside=1),
+    "nn_outside_trunc": dict(sdf_interp=0, update_outside=1, use_truncation=True, truncation_band=0.3),
+    "max_update_2": dict(voxel_max_update_num=2),
+    "wa_max_update_300": dict(voxel_update=1, voxel_max_update_num=300),
+    "max_update_70000": dict(voxel_max_update_num=70000),
+}
+
+
+@pytest.mark.parametrize("mode", list(SYN_MODES))
+def test_synthetic_sphere_small(mode):
+    n, nv, w, h = 48, 7, 160, 120
+    uo = UpdateOption(**SYN_MODES[mode])
+    opt = synth.sphere_option(n, uo)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    # shrink the ROI of some views so that voxels fall outside it
+    views[2].roi_min[0], views[2].roi_min[1] = 40, 30
+    views[2].roi_max[0], views[2].roi_max[1] = 120, 90
+    views[5].roi_max[0] = 100
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init(), vc.last_error()
+    orc = O.OracleGrid(opt)
+    for i in range(nv):
+        rmin, rmax = tuple(views[i].roi_min), tuple(views[i].roi_max)
+        sdf = O.make_sdf(masks[i], rmin, rmax, use_truncation=bool(uo.use_truncation),
+                         band=uo.truncation_band)
+        assert dev.Carve(views[i], sdf), vc.last_error()
+        orc.carve(views[i], sdf)
+        assert_state_equal(dev, orc, "%s view %d" % (mode, i))
+    assert_mesh_equal(dev.ExtractIsoSurface(0.0, True), orc.marching_cubes(0.0, True), mode)
+    assert_mesh_equal(dev.ExtractIsoSurface(0.25, True), orc.marching_cubes(0.25, True), mode + " iso .25")
+
+
+def test_orthographic_camera():
+    n = 40
+    opt = synth.sphere_option(n)
+    views, masks = synth.sphere_views(n, 3, 96, 80)
+    for v in views:
+        v.is_ortho = 1
+        # camera-space x,y are used as pixel coordinates: shift them into the image
+        v.w2c[3] += 48.0
+        v.w2c[7] += 40.0
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init()
+    orc = O.OracleGrid(opt)
+    for i in range(3):
+        sdf = O.make_sdf(masks[i])
+        assert dev.Carve(views[i], sdf)
+        orc.carve(views[i], sdf)
+    assert_state_equal(dev, orc, "ortho")
+
+
+def test_camera_inside_grid_and_behind():
+    """voxels behind the camera (pc.z < 0), at pc.z == 0 and right at the camera."""
+    n = 32
+    opt = synth.sphere_option(n, UpdateOption(update_outside=1))
+    w2c = np.array([[1, 0, 0, 0.5], [0, 1, 0, 0.5], [0, 0, 1, 0.5]], np.float32)  # camera at a voxel centre
+    view = vc.make_view(w2c, np.float32(50), np.float32(50), np.float32(63.5), np.float32(47.5), 128, 96)
+    rng = np.random.RandomState(7)
+    sdf = rng.uniform(-1, 1, (96, 128)).astype(np.float32)
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init()
+    orc = O.OracleGrid(opt)
+    assert dev.Carve(view, sdf)
+    orc.carve(view, sdf)
+    assert_state_equal(dev, orc, "camera inside")
+
+
+def test_batch_equals_sequential():
+    n, nv, w, h = 40, 6, 128, 96
+    for kw in (dict(), dict(voxel_update=1, use_truncation=True)):
+        uo = UpdateOption(**kw)
+        opt = synth.sphere_option(n, uo)
+        views, masks = synth.sphere_views(n, nv, w, h)
+        sdfs = [vc.make_sdf(m, use_truncation=bool(uo.use_truncation), band=uo.truncation_band) for m in masks]
+        a = vc.VoxelCarver(opt)
+        b = vc.VoxelCarver(opt)
+        assert a.Init() and b.Init()
+        devs = [a.upload_sdf(s) for s in sdfs]
+        for i in range(nv):
+            assert b.Carve(views[i], sdfs[i])
+        assert a.CarveBatchDevice(views, devs), vc.last_error()
+        sa, ua = a.download()
+        sb, ub = b.download()
+        assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32)) and np.array_equal(ua, ub)
+        for d in devs:
+            a.free_device(d)
+
+
+def test_marching_cubes_random_state():
+    """MC alone on arbitrary state: random sdf, invalid holes, untouched voxels, values within
+    the 1e-5 snap band of the iso level, non-cubic dims."""
+    rng = np.random.RandomState(3)
+    opt = vc.CarverOption(bb_min=(0, 0, 0), bb_max=(37, 23, 29), resolution=1.0)
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init()
+    orc = O.OracleGrid(opt)
+    assert dev.dims == orc.dims == (37, 23, 29)
+    nvox = orc.n
+    sdf = rng.uniform(-1, 1, nvox).astype(np.float32)
+    sdf[rng.rand(nvox) < 0.05] = np.finfo(np.float32).min
+    snap = rng.rand(nvox) < 0.05
+    sdf[snap] = (rng.uniform(-2e-5, 2e-5, int(snap.sum()))).astype(np.float32)
+    cnt = rng.randint(0, 4, nvox).astype(np.int32)
+    dev.upload(sdf, cnt)
+    orc.upload(sdf, cnt)
+    for iso in (0.0, 0.3):
+        for interp in (True, False):
+            assert_mesh_equal(dev.ExtractIsoSurface(iso, interp), orc.marching_cubes(iso, interp),
+                              "random iso=%s interp=%s" % (iso, interp))
+
+
+def test_degenerate_grids_and_errors():
+    # 1-voxel-thick grids have no cells: empty mesh, like the reference's loops from 1
+    opt = vc.CarverOption(bb_min=(0, 0, 0), bb_max=(8, 8, 1), resolution=1.0)
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init()
+    m = dev.ExtractIsoSurface()
+    assert len(m["vertices"]) == 0 and len(m["faces"]) == 0
+    # invalid options -> Init() returns false (voxel_carver.cc:376-389, 278-287)
+    for kw in (dict(voxel_max_update_num=0), dict(voxel_update_weight=0.0), dict(truncation_band=0.0)):
+        assert not vc.VoxelCarver(B.bunny_option(10.0, UpdateOption(**kw))).Init()
+    assert not vc.VoxelCarver(B.bunny_option(0.0)).Init()
+    # Carve before Init (reference: UB; here: false)
+    c = vc.VoxelCarver(B.bunny_option())
+    assert not c.Carve(vc.make_view(np.eye(3, 4, dtype=np.float32), 1, 1, 0, 0, 4, 4), np.zeros((4, 4), np.float32))

@@ -72,6 +72,7 @@ class Mesh(C.Structure):
         ("vertices", C.POINTER(C.c_float)),
         ("faces", C.POINTER(C.c_int32)),
         ("edge_keys", C.POINTER(C.c_int64)),
+        ("n_foreign_vertices", C.c_int64),
     ]
 
 
@@ -120,6 +121,7 @@ def load():
                                    C.c_int, C.c_int, C.c_float, vp]),
         "vcy_extract_iso": (C.c_int, [vp, C.c_double, C.c_int, P(Mesh)]),
         "vcy_mesh_free": (None, [P(Mesh)]),
+        "vcy_last_extract_ms": (C.c_int, [vp, P(C.c_float)]),
         "vcy_download": (C.c_int, [vp, vp, vp]),
         "vcy_upload": (C.c_int, [vp, vp, vp]),
         "vcy_download_positions": (C.c_int, [vp, vp]),
@@ -129,6 +131,10 @@ def load():
         "vcy_device_count": (C.c_int, [P(C.c_int)]),
         "vcy_sdf_upload": (C.c_int, [vp, vp, C.c_int, C.c_int, P(vp)]),
         "vcy_device_free": (C.c_int, [vp, vp]),
+        "vcy_device_alloc": (C.c_int, [vp, C.c_int64, P(vp)]),
+        "vcy_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_int64]),
+        "vcy_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_int64]),
+        "vcy_reset": (C.c_int, [vp]),
         "vcy_set_stream": (C.c_int, [vp, vp]),
         "vcy_sync": (C.c_int, [vp]),
         "vcy_timer_begin": (C.c_int, [vp]),

@@ -1,0 +1,217 @@
+"""Python host-side mirror of vacancy::VoxelCarver over the C-ABI (include/vacancy_hip.h).
+
+Method names and argument meaning follow the reference class
+(include/vacancy/voxel_carver.h:95-118 in unclearness/vacancy); errors that the reference
+reports as `return false` + LOGE surface here as `False` returns with the message in
+`last_error()`.  Every call goes to libvacancy_hip.so; there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import CarverOption, Mesh, UpdateOption, View, make_view  # noqa: F401
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def last_error():
+    return capi.load().vcy_last_error().decode()
+
+
+class VoxelCarver:
+    def __init__(self, option=None, device_id=0, z_range=None):
+        self._lib = capi.load()
+        self._ctx = C.c_void_p()
+        self._device = device_id
+        self._z_range = z_range
+        self.option = option
+        self.dims = None
+
+    # -- VoxelCarver::set_option / Init (voxel_carver.cc:373-392)
+    def set_option(self, option):
+        self.option = option
+
+    def Init(self):
+        self.close()
+        z0, z1 = self._z_range if self._z_range else (0, -1)
+        rc = self._lib.vcy_create(C.byref(self.option), self._device, z0, z1, C.byref(self._ctx))
+        if rc != 0:
+            self._ctx = C.c_void_p()
+            return False
+        d = (C.c_int32 * 3)()
+        self._lib.vcy_grid_dims(self._ctx, d)
+        self.dims = tuple(d)
+        zr = (C.c_int32 * 2)()
+        self._lib.vcy_slab_range(self._ctx, zr)
+        self.z_range = tuple(zr)
+        return True
+
+    def close(self):
+        if self._ctx:
+            self._lib.vcy_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def ctx(self):
+        return self._ctx
+
+    @property
+    def slab_voxels(self):
+        return self.dims[0] * self.dims[1] * (self.z_range[1] - self.z_range[0])
+
+    # -- Carve(camera, roi_min, roi_max, sdf)  (voxel_carver.cc:415-496)
+    def Carve(self, view, sdf):
+        if not self._ctx:
+            return False
+        sdf = np.ascontiguousarray(sdf, dtype=np.float32)
+        assert sdf.shape == (view.height, view.width)
+        return self._lib.vcy_carve(self._ctx, C.byref(view), _p(sdf)) == 0
+
+    # -- Carve(camera, silhouette, roi_min, roi_max, &sdf)  (voxel_carver.cc:394-413)
+    def CarveSilhouette(self, view, silhouette, return_sdf=False):
+        if not self._ctx:
+            return False
+        mask = np.ascontiguousarray(silhouette, dtype=np.uint8)
+        sdf = np.empty(mask.shape, np.float32) if return_sdf else None
+        rc = self._lib.vcy_carve_silhouette(self._ctx, C.byref(view), _p(mask),
+                                            _p(sdf) if return_sdf else None)
+        return (rc == 0, sdf) if return_sdf else rc == 0
+
+    # -- device-resident SDF images (bench / streaming)
+    def upload_sdf(self, sdf):
+        sdf = np.ascontiguousarray(sdf, dtype=np.float32)
+        out = C.c_void_p()
+        rc = self._lib.vcy_sdf_upload(self._ctx, _p(sdf), sdf.shape[1], sdf.shape[0], C.byref(out))
+        if rc != 0:
+            raise RuntimeError(last_error())
+        return out
+
+    def free_device(self, ptr):
+        self._lib.vcy_device_free(self._ctx, ptr)
+
+    def CarveDevice(self, view, sdf_dev):
+        return self._lib.vcy_carve_device(self._ctx, C.byref(view), sdf_dev) == 0
+
+    # -- Carve(vector<Camera>, vector<...>) loop (voxel_carver.cc:516-528), fused on device
+    def CarveBatchDevice(self, views, sdf_devs):
+        n = len(views)
+        arr = (View * n)(*views)
+        ptrs = (C.c_void_p * n)(*[p.value if isinstance(p, C.c_void_p) else p for p in sdf_devs])
+        return self._lib.vcy_carve_batch_device(self._ctx, n, arr, ptrs) == 0
+
+    # -- ExtractIsoSurface(mesh, iso_level, linear_interp)  (voxel_carver.cc:540-543)
+    def ExtractIsoSurface(self, iso_level=0.0, linear_interp=True):
+        m = Mesh()
+        rc = self._lib.vcy_extract_iso(self._ctx, iso_level, int(linear_interp), C.byref(m))
+        if rc != 0:
+            self._lib.vcy_mesh_free(C.byref(m))
+            raise RuntimeError(last_error())
+        nv, nf = m.n_vertices, m.n_faces
+        out = {
+            "vertices": np.ctypeslib.as_array(m.vertices, shape=(max(nv, 1) * 3,))[: nv * 3].reshape(nv, 3).copy(),
+            "faces": np.ctypeslib.as_array(m.faces, shape=(max(nf, 1) * 3,))[: nf * 3].reshape(nf, 3).copy(),
+            "keys": np.ctypeslib.as_array(m.edge_keys, shape=(max(nv, 1) * 2,))[: nv * 2].reshape(nv, 2).copy(),
+            "n_foreign": int(m.n_foreign_vertices),
+        }
+        self._lib.vcy_mesh_free(C.byref(m))
+        ms = C.c_float()
+        self._lib.vcy_last_extract_ms(self._ctx, C.byref(ms))
+        out["device_ms"] = ms.value
+        return out
+
+    # -- state access
+    def download(self):
+        n = self.slab_voxels
+        s = np.empty(n, np.float32)
+        u = np.empty(n, np.int32)
+        rc = self._lib.vcy_download(self._ctx, _p(s), _p(u))
+        if rc != 0:
+            raise RuntimeError(last_error())
+        return s, u
+
+    def upload(self, sdf, update_num):
+        s = np.ascontiguousarray(sdf, np.float32)
+        u = np.ascontiguousarray(update_num, np.int32)
+        rc = self._lib.vcy_upload(self._ctx, _p(s), _p(u))
+        if rc != 0:
+            raise RuntimeError(last_error())
+
+    def positions(self):
+        p = np.empty((self.slab_voxels, 3), np.float32)
+        rc = self._lib.vcy_download_positions(self._ctx, _p(p))
+        if rc != 0:
+            raise RuntimeError(last_error())
+        return p
+
+    # -- halo staging through the host (gloo path of vacancy_amd.dist)
+    def halo_pack_host(self):
+        import ctypes as C_
+        nbytes = int(self._lib.vcy_halo_bytes(self._ctx))
+        dev = C_.c_void_p()
+        host = np.empty(nbytes, np.uint8)
+        rc = self._lib.vcy_device_alloc(self._ctx, nbytes, C_.byref(dev))
+        assert rc == 0, last_error()
+        assert self._lib.vcy_halo_pack(self._ctx, dev) == 0, last_error()
+        assert self._lib.vcy_memcpy_d2h(self._ctx, _p(host), dev, nbytes) == 0, last_error()
+        self._lib.vcy_device_free(self._ctx, dev)
+        return host
+
+    def halo_unpack_host(self, gathered, rank, world):
+        import ctypes as C_
+        gathered = np.ascontiguousarray(gathered, np.uint8)
+        dev = C_.c_void_p()
+        assert self._lib.vcy_device_alloc(self._ctx, gathered.nbytes, C_.byref(dev)) == 0, last_error()
+        assert self._lib.vcy_memcpy_h2d(self._ctx, dev, _p(gathered), gathered.nbytes) == 0, last_error()
+        assert self._lib.vcy_halo_unpack(self._ctx, dev, rank, world) == 0, last_error()
+        self._lib.vcy_device_free(self._ctx, dev)
+
+    def reset(self):
+        """Back to the state right after Init(): sdf = lowest(), update_num = 0."""
+        assert self._lib.vcy_reset(self._ctx) == 0, last_error()
+
+    def sync(self):
+        self._lib.vcy_sync(self._ctx)
+
+    def timer_begin(self):
+        self._lib.vcy_timer_begin(self._ctx)
+
+    def timer_end(self):
+        ms = C.c_float()
+        self._lib.vcy_timer_end(self._ctx, C.byref(ms))
+        return ms.value
+
+
+def make_sdf(mask, roi_min=None, roi_max=None, normalize=True, use_truncation=False, band=0.1):
+    """MakeSignedDistanceField (voxel_carver.cc:169-237) through the C-ABI."""
+    lib = capi.load()
+    mask = np.ascontiguousarray(mask, np.uint8)
+    h, w = mask.shape
+    rmin = (C.c_int32 * 2)(*(roi_min or (0, 0)))
+    rmax = (C.c_int32 * 2)(*(roi_max or (w - 1, h - 1)))
+    out = np.empty((h, w), np.float32)
+    rc = lib.vcy_make_sdf(_p(mask), w, h, rmin, rmax, int(normalize), int(use_truncation), band, _p(out))
+    if rc != 0:
+        raise RuntimeError(last_error())
+    return out
+
+
+def distance_transform_l1(mask, roi_min=None, roi_max=None):
+    lib = capi.load()
+    mask = np.ascontiguousarray(mask, np.uint8)
+    h, w = mask.shape
+    rmin = (C.c_int32 * 2)(*(roi_min or (0, 0)))
+    rmax = (C.c_int32 * 2)(*(roi_max or (w - 1, h - 1)))
+    out = np.empty((h, w), np.float32)
+    rc = lib.vcy_distance_transform_l1(_p(mask), w, h, rmin, rmax, _p(out))
+    if rc != 0:
+        raise RuntimeError(last_error())
+    return out

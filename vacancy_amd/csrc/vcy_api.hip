@@ -1,0 +1,561 @@
+// C-ABI entry points of libvacancy_hip.so: lifetime, state access, halo, helpers.
+// The carving and extraction kernels live in carve_kernels.hip / mc_kernels.hip.
+#include <cstdarg>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "vcy_internal.h"
+
+namespace vcy {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+// sdf = lowest(), update_num = 0 over slab + halo (reference voxel_carver.cc:339, Voxel ctor)
+__global__ void fill_f32_kernel(float* __restrict__ p, float v, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+int fill_state(vcy_ctx* c) {
+  const int64_t n = c->slice * (int64_t)(c->halo_lo + c->nz_local());
+  const int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(grid), dim3(256), 0, c->stream, c->d_sdf, kInvalidSdf, n);
+  VCY_HIP_CHECK(hipGetLastError());
+  VCY_HIP_CHECK(hipMemsetAsync(c->d_cnt, 0, (size_t)n * c->cnt_bytes, c->stream));
+  c->views_carved = 0;
+  c->halo_valid = false;
+  return VCY_OK;
+}
+
+static int dims_from_option(const float bb_min[3], const float bb_max[3], float res, int32_t n[3]) {
+  // VoxelGrid::Init, reference voxel_carver.cc:278-301
+  if (res < std::numeric_limits<float>::min()) {
+    set_error("resolution must be positive %f", res);
+    return VCY_ERR_INVALID_ARG;
+  }
+  if (bb_max[0] <= bb_min[0] || bb_max[1] <= bb_min[1] || bb_max[2] <= bb_min[2]) {
+    set_error("input bounding box is invalid");
+    return VCY_ERR_INVALID_ARG;
+  }
+  for (int i = 0; i < 3; ++i) {
+    const float diff = bb_max[i] - bb_min[i];
+    n[i] = static_cast<int>(diff / res);
+  }
+  if (n[0] <= 0 || n[1] <= 0 || n[2] <= 0) {
+    set_error("grid has an empty axis (%d,%d,%d)", n[0], n[1], n[2]);
+    return VCY_ERR_INVALID_ARG;
+  }
+  // The reference refuses more than INT_MAX voxels (32-bit ids, voxel_carver.cc:298-301).
+  // Device indices are 64-bit; a single xy slice must still fit 31 bits.
+  if ((int64_t)n[0] * n[1] > std::numeric_limits<int>::max()) {
+    set_error("too many voxels in one xy slice");
+    return VCY_ERR_TOO_MANY_VOXELS;
+  }
+  return VCY_OK;
+}
+
+}  // namespace vcy
+
+using namespace vcy;
+
+extern "C" {
+
+const char* vcy_last_error(void) { return g_last_error.c_str(); }
+const char* vcy_version(void) { return "vacancy_amd 0.1 (gfx950)"; }
+
+int vcy_device_count(int* count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+    return VCY_ERR_NO_DEVICE;
+  }
+  *count = n;
+  return VCY_OK;
+}
+
+int vcy_compute_dims(const float bb_min[3], const float bb_max[3], float resolution,
+                     int32_t dims[3]) {
+  return dims_from_option(bb_min, bb_max, resolution, dims);
+}
+
+int vcy_create(const vcy_carver_option* o, int device_id, int z_begin, int z_end, vcy_ctx** out) {
+  if (!o || !out) {
+    set_error("null argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  *out = nullptr;
+  // VoxelCarver::Init, reference voxel_carver.cc:376-389
+  if (o->update_option.voxel_max_update_num < 1) {
+    set_error("voxel_max_update_num must be positive");
+    return VCY_ERR_INVALID_ARG;
+  }
+  if (o->update_option.voxel_update_weight < std::numeric_limits<float>::min()) {
+    set_error("voxel_update_weight must be positive");
+    return VCY_ERR_INVALID_ARG;
+  }
+  if (o->update_option.truncation_band < std::numeric_limits<float>::min()) {
+    set_error("truncation_band must be positive");
+    return VCY_ERR_INVALID_ARG;
+  }
+  const vcy_update_option& u = o->update_option;
+  if (u.voxel_update < 0 || u.voxel_update > 1 || u.sdf_interp < 0 || u.sdf_interp > 1 ||
+      u.update_outside < 0 || u.update_outside > 1) {
+    set_error("unknown enum value in update_option");
+    return VCY_ERR_INVALID_ARG;
+  }
+  int32_t n[3];
+  int rc = dims_from_option(o->bb_min, o->bb_max, o->resolution, n);
+  if (rc != VCY_OK) return rc;
+  if (z_end < 0) z_end = n[2];
+  if (z_begin < 0 || z_begin >= z_end || z_end > n[2]) {
+    set_error("invalid z-slab [%d,%d) for nz=%d", z_begin, z_end, n[2]);
+    return VCY_ERR_INVALID_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("no HIP device available (there is no CPU fallback)");
+    return VCY_ERR_NO_DEVICE;
+  }
+  if (device_id < 0 || device_id >= ndev) {
+    set_error("device %d out of range (%d devices)", device_id, ndev);
+    return VCY_ERR_NO_DEVICE;
+  }
+  VCY_HIP_CHECK(hipSetDevice(device_id));
+
+  vcy_ctx* c = new vcy_ctx;
+  c->device = device_id;
+  c->opt = *o;
+  c->nx = n[0];
+  c->ny = n[1];
+  c->nz = n[2];
+  c->z0 = z_begin;
+  c->z1 = z_end;
+  c->slice = (int64_t)n[0] * n[1];
+  c->halo_lo = (z_begin > 0) ? 2 : 0;
+  if (c->halo_lo && z_begin < 2) {
+    delete c;
+    set_error("a non-first slab must start at z >= 2");
+    return VCY_ERR_INVALID_ARG;
+  }
+  // update_num never exceeds voxel_max_update_num + 1 (voxel_carver.cc:447-450)
+  const int64_t max_cnt = (int64_t)u.voxel_max_update_num + 1;
+  c->cnt_bytes = max_cnt <= 255 ? 1 : (max_cnt <= 65535 ? 2 : 4);
+
+  auto fail = [&](int code) {
+    vcy_destroy(c);
+    return code;
+  };
+#define VCY_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      set_error("%s failed: %s", #expr, hipGetErrorString(_e));                               \
+      return fail(VCY_ERR_HIP);                                                               \
+    }                                                                                         \
+  } while (0)
+  VCY_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->own_stream = true;
+  VCY_TRY(hipEventCreate(&c->ev_begin));
+  VCY_TRY(hipEventCreate(&c->ev_end));
+  const int64_t nvox = c->slice * (int64_t)(c->halo_lo + c->nz_local());
+  VCY_TRY(hipMalloc(&c->d_sdf, (size_t)nvox * sizeof(float)));
+  VCY_TRY(hipMalloc(&c->d_cnt, (size_t)nvox * c->cnt_bytes));
+  VCY_TRY(hipMalloc(&c->d_px, sizeof(float) * n[0]));
+  VCY_TRY(hipMalloc(&c->d_py, sizeof(float) * n[1]));
+  VCY_TRY(hipMalloc(&c->d_pz, sizeof(float) * n[2]));
+
+  // Voxel::pos per axis, reference voxel_carver.cc:308-326:
+  //   pos = diff * ((float)i / (float)n) + bb_min + resolution*0.5f   (left to right)
+  // Host IEEE arithmetic, this TU is built with -ffp-contract=off.
+  const float offset = o->resolution * 0.5f;
+  float* d_axis[3] = {c->d_px, c->d_py, c->d_pz};
+  for (int a = 0; a < 3; ++a) {
+    const float diff = o->bb_max[a] - o->bb_min[a];
+    std::vector<float> p(n[a]);
+    for (int i = 0; i < n[a]; ++i)
+      p[i] = diff * (static_cast<float>(i) / static_cast<float>(n[a])) + o->bb_min[a] + offset;
+    VCY_TRY(hipMemcpy(d_axis[a], p.data(), sizeof(float) * n[a], hipMemcpyHostToDevice));
+  }
+  rc = fill_state(c);
+  if (rc != VCY_OK) return fail(rc);
+  VCY_TRY(hipStreamSynchronize(c->stream));
+#undef VCY_TRY
+  *out = c;
+  return VCY_OK;
+}
+
+void vcy_destroy(vcy_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(c->d_sdf);
+  (void)hipFree(c->d_cnt);
+  (void)hipFree(c->d_px);
+  (void)hipFree(c->d_py);
+  (void)hipFree(c->d_pz);
+  (void)hipFree(c->d_mc_tables);
+  if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+  if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int vcy_grid_dims(const vcy_ctx* c, int32_t dims[3]) {
+  if (!c) return VCY_ERR_NOT_INITIALIZED;
+  dims[0] = c->nx;
+  dims[1] = c->ny;
+  dims[2] = c->nz;
+  return VCY_OK;
+}
+
+int vcy_slab_range(const vcy_ctx* c, int32_t zr[2]) {
+  if (!c) return VCY_ERR_NOT_INITIALIZED;
+  zr[0] = c->z0;
+  zr[1] = c->z1;
+  return VCY_OK;
+}
+
+int vcy_set_stream(vcy_ctx* c, void* s) {
+  if (!c) return VCY_ERR_NOT_INITIALIZED;
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  if (c->stream) VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (c->own_stream && c->stream) VCY_HIP_CHECK(hipStreamDestroy(c->stream));
+  c->stream = (hipStream_t)s;
+  c->own_stream = false;
+  return VCY_OK;
+}
+
+int vcy_sync(vcy_ctx* c) {
+  if (!c) return VCY_ERR_NOT_INITIALIZED;
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return VCY_OK;
+}
+
+int vcy_timer_begin(vcy_ctx* c) {
+  if (!c) return VCY_ERR_NOT_INITIALIZED;
+  VCY_HIP_CHECK(hipEventRecord(c->ev_begin, c->stream));
+  return VCY_OK;
+}
+
+int vcy_timer_end(vcy_ctx* c, float* ms) {
+  if (!c) return VCY_ERR_NOT_INITIALIZED;
+  VCY_HIP_CHECK(hipEventRecord(c->ev_end, c->stream));
+  VCY_HIP_CHECK(hipEventSynchronize(c->ev_end));
+  VCY_HIP_CHECK(hipEventElapsedTime(ms, c->ev_begin, c->ev_end));
+  return VCY_OK;
+}
+
+int vcy_sdf_upload(vcy_ctx* c, const float* host, int w, int h, float** dev_out) {
+  if (!c || !host || !dev_out || w <= 0 || h <= 0) {
+    set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  float* d = nullptr;
+  VCY_HIP_CHECK(hipMalloc(&d, sizeof(float) * (size_t)w * h));
+  hipError_t e = hipMemcpy(d, host, sizeof(float) * (size_t)w * h, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    set_error("hipMemcpy H2D failed: %s", hipGetErrorString(e));
+    return VCY_ERR_HIP;
+  }
+  *dev_out = d;
+  return VCY_OK;
+}
+
+int vcy_device_alloc(vcy_ctx* c, int64_t bytes, void** out) {
+  if (!c || !out || bytes <= 0) return VCY_ERR_INVALID_ARG;
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  VCY_HIP_CHECK(hipMalloc(out, (size_t)bytes));
+  return VCY_OK;
+}
+
+int vcy_memcpy_h2d(vcy_ctx* c, void* dst, const void* src, int64_t bytes) {
+  if (!c || !dst || !src || bytes < 0) return VCY_ERR_INVALID_ARG;
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+  VCY_HIP_CHECK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+  return VCY_OK;
+}
+
+int vcy_memcpy_d2h(vcy_ctx* c, void* dst, const void* src, int64_t bytes) {
+  if (!c || !dst || !src || bytes < 0) return VCY_ERR_INVALID_ARG;
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+  VCY_HIP_CHECK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+  return VCY_OK;
+}
+
+int vcy_reset(vcy_ctx* c) {
+  if (!c) return VCY_ERR_NOT_INITIALIZED;
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  return fill_state(c);
+}
+
+int vcy_device_free(vcy_ctx* c, void* p) {
+  if (!c) return VCY_ERR_NOT_INITIALIZED;
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+  VCY_HIP_CHECK(hipFree(p));
+  return VCY_OK;
+}
+
+/* ---- state access ------------------------------------------------------- */
+
+int vcy_download(vcy_ctx* c, float* sdf, int32_t* update_num) {
+  if (!c) return VCY_ERR_NOT_INITIALIZED;
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+  const int64_t n = c->slab_voxels();
+  if (sdf)
+    VCY_HIP_CHECK(hipMemcpy(sdf, c->owned_slab_sdf(), sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+  if (update_num) {
+    std::vector<uint8_t> raw((size_t)n * c->cnt_bytes);
+    VCY_HIP_CHECK(hipMemcpy(raw.data(), c->owned_slab_cnt(), raw.size(), hipMemcpyDeviceToHost));
+    if (c->cnt_bytes == 1) {
+      for (int64_t i = 0; i < n; ++i) update_num[i] = raw[i];
+    } else if (c->cnt_bytes == 2) {
+      const uint16_t* r = (const uint16_t*)raw.data();
+      for (int64_t i = 0; i < n; ++i) update_num[i] = r[i];
+    } else {
+      std::memcpy(update_num, raw.data(), raw.size());
+    }
+  }
+  return VCY_OK;
+}
+
+int vcy_upload(vcy_ctx* c, const float* sdf, const int32_t* update_num) {
+  if (!c) return VCY_ERR_NOT_INITIALIZED;
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+  const int64_t n = c->slab_voxels();
+  if (sdf)
+    VCY_HIP_CHECK(hipMemcpy(c->owned_slab_sdf(), sdf, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+  if (update_num) {
+    const int64_t cap = (int64_t)c->opt.update_option.voxel_max_update_num + 1;
+    int64_t mx = 0;
+    std::vector<uint8_t> raw((size_t)n * c->cnt_bytes);
+    for (int64_t i = 0; i < n; ++i) {
+      const int32_t v = update_num[i];
+      if (v < 0 || v > cap) {
+        set_error("update_num[%lld]=%d outside [0, voxel_max_update_num+1]", (long long)i, v);
+        return VCY_ERR_INVALID_ARG;
+      }
+      mx = v > mx ? v : mx;
+      if (c->cnt_bytes == 1) raw[i] = (uint8_t)v;
+      else if (c->cnt_bytes == 2) ((uint16_t*)raw.data())[i] = (uint16_t)v;
+      else ((int32_t*)raw.data())[i] = v;
+    }
+    VCY_HIP_CHECK(hipMemcpy(c->owned_slab_cnt(), raw.data(), raw.size(), hipMemcpyHostToDevice));
+    c->views_carved = std::max<int64_t>(c->views_carved, mx);
+  }
+  c->halo_valid = false;
+  return VCY_OK;
+}
+
+int vcy_download_positions(vcy_ctx* c, float* pos) {
+  if (!c || !pos) return VCY_ERR_INVALID_ARG;
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  std::vector<float> px(c->nx), py(c->ny), pz(c->nz);
+  VCY_HIP_CHECK(hipMemcpy(px.data(), c->d_px, sizeof(float) * c->nx, hipMemcpyDeviceToHost));
+  VCY_HIP_CHECK(hipMemcpy(py.data(), c->d_py, sizeof(float) * c->ny, hipMemcpyDeviceToHost));
+  VCY_HIP_CHECK(hipMemcpy(pz.data(), c->d_pz, sizeof(float) * c->nz, hipMemcpyDeviceToHost));
+  int64_t i = 0;
+  for (int z = c->z0; z < c->z1; ++z)
+    for (int y = 0; y < c->ny; ++y)
+      for (int x = 0; x < c->nx; ++x, ++i) {
+        pos[3 * i + 0] = px[x];
+        pos[3 * i + 1] = py[y];
+        pos[3 * i + 2] = pz[z];
+      }
+  return VCY_OK;
+}
+
+/* ---- halo --------------------------------------------------------------- */
+// Each rank contributes the LAST two xy-slices of its slab: [sdf slice z1-2][sdf slice
+// z1-1][cnt slice z1-2][cnt slice z1-1].  Rank r installs rank r-1's contribution as its
+// two halo slices z0-2, z0-1 (cells of layer z0 need slice z0-1; deciding which rank owns
+// the marching-cubes vertices on plane z0-1 needs the validity of layer z0-1, i.e. slice
+// z0-2 as well).
+
+int64_t vcy_halo_bytes(const vcy_ctx* c) {
+  if (!c) return 0;
+  return 2 * c->slice * (int64_t)(sizeof(float) + c->cnt_bytes);
+}
+
+int vcy_halo_pack(vcy_ctx* c, void* send) {
+  if (!c || !send) return VCY_ERR_INVALID_ARG;
+  if (c->nz_local() < 2) {
+    set_error("a slab needs at least 2 slices to exchange halos");
+    return VCY_ERR_INVALID_ARG;
+  }
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  const int64_t s = c->slice;
+  const float* sdf_src = c->owned_slab_sdf() + (int64_t)(c->nz_local() - 2) * s;
+  const char* cnt_src = (const char*)c->owned_slab_cnt() + (int64_t)(c->nz_local() - 2) * s * c->cnt_bytes;
+  VCY_HIP_CHECK(hipMemcpyAsync(send, sdf_src, 2 * s * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  VCY_HIP_CHECK(hipMemcpyAsync((char*)send + 2 * s * sizeof(float), cnt_src, 2 * s * c->cnt_bytes,
+                               hipMemcpyDeviceToDevice, c->stream));
+  return VCY_OK;
+}
+
+int vcy_halo_unpack(vcy_ctx* c, const void* gathered, int rank, int world) {
+  if (!c || !gathered || rank < 0 || rank >= world) return VCY_ERR_INVALID_ARG;
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  if (c->halo_lo == 0) {
+    c->halo_valid = true;
+    return VCY_OK;
+  }
+  if (rank == 0) {
+    set_error("rank 0 must own z_begin == 0");
+    return VCY_ERR_INVALID_ARG;
+  }
+  const int64_t s = c->slice;
+  const char* src = (const char*)gathered + (int64_t)(rank - 1) * vcy_halo_bytes(c);
+  VCY_HIP_CHECK(hipMemcpyAsync(c->d_sdf, src, 2 * s * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  VCY_HIP_CHECK(hipMemcpyAsync(c->d_cnt, src + 2 * s * sizeof(float), 2 * s * c->cnt_bytes,
+                               hipMemcpyDeviceToDevice, c->stream));
+  c->halo_valid = true;
+  return VCY_OK;
+}
+
+/* ---- carving entry points ------------------------------------------------ */
+
+static int check_view(const vcy_ctx* c, const vcy_view* v) {
+  if (!c) {
+    set_error("VoxelCarver::Carve voxel grid has not been initialized");
+    return VCY_ERR_NOT_INITIALIZED;
+  }
+  if (!v || v->width <= 0 || v->height <= 0) {
+    set_error("invalid view");
+    return VCY_ERR_INVALID_ARG;
+  }
+  // The reference indexes sdf.at() unchecked (assert only); a ROI outside the image is
+  // undefined there and rejected here.
+  if (v->roi_min[0] < 0 || v->roi_min[1] < 0 || v->roi_max[0] >= v->width ||
+      v->roi_max[1] >= v->height || v->roi_min[0] > v->roi_max[0] || v->roi_min[1] > v->roi_max[1]) {
+    set_error("ROI [%d,%d]-[%d,%d] outside the %dx%d SDF image", v->roi_min[0], v->roi_min[1],
+              v->roi_max[0], v->roi_max[1], v->width, v->height);
+    return VCY_ERR_INVALID_ARG;
+  }
+  return VCY_OK;
+}
+
+int vcy_carve_batch_device(vcy_ctx* c, int n_views, const vcy_view* views,
+                           const float* const* sdf_device) {
+  if (n_views <= 0 || !views || !sdf_device) {
+    set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  for (int i = 0; i < n_views; ++i) {
+    int rc = check_view(c, &views[i]);
+    if (rc != VCY_OK) return rc;
+    if (!sdf_device[i]) {
+      set_error("null SDF pointer");
+      return VCY_ERR_INVALID_ARG;
+    }
+  }
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  return launch_carve(c, n_views, views, sdf_device);
+}
+
+int vcy_carve_device(vcy_ctx* c, const vcy_view* view, const float* sdf_device) {
+  return vcy_carve_batch_device(c, 1, view, &sdf_device);
+}
+
+int vcy_carve(vcy_ctx* c, const vcy_view* view, const float* sdf_host) {
+  int rc = check_view(c, view);
+  if (rc != VCY_OK) return rc;
+  if (!sdf_host) {
+    set_error("null SDF pointer");
+    return VCY_ERR_INVALID_ARG;
+  }
+  float* d = nullptr;
+  rc = vcy_sdf_upload(c, sdf_host, view->width, view->height, &d);
+  if (rc != VCY_OK) return rc;
+  rc = vcy_carve_device(c, view, d);
+  int rc2 = vcy_device_free(c, d);  // synchronises the stream first
+  return rc != VCY_OK ? rc : rc2;
+}
+
+int vcy_carve_silhouette(vcy_ctx* c, const vcy_view* view, const uint8_t* mask, float* sdf_out) {
+  int rc = check_view(c, view);
+  if (rc != VCY_OK) return rc;
+  if (!mask) {
+    set_error("null silhouette");
+    return VCY_ERR_INVALID_ARG;
+  }
+  std::vector<float> tmp;
+  float* sdf = sdf_out;
+  if (!sdf) {
+    tmp.resize((size_t)view->width * view->height);
+    sdf = tmp.data();
+  }
+  const vcy_update_option& u = c->opt.update_option;
+  // MakeSignedDistanceField(silhouette, roi_min, roi_max, sdf, option_.sdf_minmax_normalize,
+  //   use_truncation, truncation_band), reference voxel_carver.cc:405-408
+  host_make_sdf(mask, view->width, view->height, view->roi_min, view->roi_max,
+                c->opt.sdf_minmax_normalize != 0, u.use_truncation != 0, u.truncation_band, sdf);
+  return vcy_carve(c, view, sdf);
+}
+
+int vcy_distance_transform_l1(const uint8_t* mask, int w, int h, const int32_t rmin[2],
+                              const int32_t rmax[2], float* out) {
+  if (!mask || !out || w <= 0 || h <= 0 || rmin[0] < 0 || rmin[1] < 0 || rmax[0] >= w || rmax[1] >= h) {
+    set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  host_distance_transform_l1(mask, w, h, rmin, rmax, out);
+  return VCY_OK;
+}
+
+int vcy_make_sdf(const uint8_t* mask, int w, int h, const int32_t rmin[2], const int32_t rmax[2],
+                 int normalize, int truncate, float band, float* out) {
+  if (!mask || !out || w <= 0 || h <= 0 || rmin[0] < 0 || rmin[1] < 0 || rmax[0] >= w || rmax[1] >= h) {
+    set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  host_make_sdf(mask, w, h, rmin, rmax, normalize != 0, truncate != 0, band, out);
+  return VCY_OK;
+}
+
+int vcy_extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
+  if (!c) {
+    set_error("voxel grid has not been initialized");
+    return VCY_ERR_NOT_INITIALIZED;
+  }
+  if (!out) return VCY_ERR_INVALID_ARG;
+  std::memset(out, 0, sizeof(*out));
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  return extract_iso(c, iso, linear_interp, out);
+}
+
+int vcy_last_extract_ms(const vcy_ctx* c, float* device_ms) {
+  if (!c || !device_ms) return VCY_ERR_INVALID_ARG;
+  *device_ms = c->last_extract_device_ms;
+  return VCY_OK;
+}
+
+void vcy_mesh_free(vcy_mesh* m) {
+  if (!m) return;
+  std::free(m->vertices);
+  std::free(m->faces);
+  std::free(m->edge_keys);
+  std::memset(m, 0, sizeof(*m));
+}
+
+}  // extern "C"

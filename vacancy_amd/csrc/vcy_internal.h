@@ -1,0 +1,88 @@
+// Internal declarations shared by the HIP translation units of libvacancy_hip.so.
+// gfx950 (MI355X) only; built with -ffp-contract=off (bit-exact parity with the
+// reference's non-FMA x86 arithmetic).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "vacancy_hip.h"
+
+namespace vcy {
+
+void set_error(const char* fmt, ...);
+
+#define VCY_HIP_CHECK(expr)                                                        \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      ::vcy::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                       __FILE__, __LINE__);                                        \
+      return VCY_ERR_HIP;                                                          \
+    }                                                                              \
+  } while (0)
+
+// std::numeric_limits<float>::lowest(), InvalidSdf::kVal (reference voxel_carver.cc:100)
+constexpr float kInvalidSdf = -3.402823466e+38f;
+
+}  // namespace vcy
+
+// The device-resident voxel grid of one z-slab.
+//
+// Layout (structure of arrays, the reference's 40-byte AoS Voxel is never materialised):
+//   sdf   float  [halo_lo + nz_local][ny][nx]   x fastest, one contiguous slab in HBM
+//   cnt   u8/u16/u32 same shape                 Voxel::update_num
+//   px/py/pz     float[nx]/[ny]/[nz]            Voxel::pos per axis (global index)
+// halo_lo = 2 slices below the slab when z_begin > 0 (filled by vcy_halo_unpack before
+// extraction), 0 otherwise.  Voxel::index/id are implicit, Voxel::outside is dead in the
+// reference, Voxel::on_surface belongs to ExtractVoxel (host).
+struct vcy_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+
+  vcy_carver_option opt{};
+  int nx = 0, ny = 0, nz = 0;  // global dims
+  int z0 = 0, z1 = 0;          // owned slab [z0, z1)
+  int halo_lo = 0;             // slices stored below z0
+  bool halo_valid = false;
+  int64_t slice = 0;           // nx*ny
+  int cnt_bytes = 1;
+
+  float* d_sdf = nullptr;      // includes halo slices
+  void* d_cnt = nullptr;
+  float* d_px = nullptr;
+  float* d_py = nullptr;
+  float* d_pz = nullptr;
+
+  void* d_mc_tables = nullptr;        // marching-cubes case tables (mc_kernels.hip)
+  float last_extract_device_ms = 0.0f;
+
+  // upper bound on any voxel's update_num (each carved view adds at most one)
+  int64_t views_carved = 0;
+
+  float* owned_slab_sdf() const { return d_sdf + (int64_t)halo_lo * slice; }
+  void* owned_slab_cnt() const { return (char*)d_cnt + (int64_t)halo_lo * slice * cnt_bytes; }
+  int nz_local() const { return z1 - z0; }
+  int64_t slab_voxels() const { return slice * (int64_t)(z1 - z0); }
+};
+
+namespace vcy {
+
+// carve_kernels.hip
+int launch_carve(vcy_ctx* ctx, int n_views, const vcy_view* views, const float* const* sdf_dev);
+// mc_kernels.hip
+int extract_iso(vcy_ctx* ctx, double iso, int linear_interp, vcy_mesh* out);
+// sdf2d.hip
+void host_distance_transform_l1(const uint8_t* mask, int w, int h, const int32_t* rmin,
+                                const int32_t* rmax, float* out);
+void host_make_sdf(const uint8_t* mask, int w, int h, const int32_t* rmin, const int32_t* rmax,
+                   bool normalize, bool truncate, float band, float* out);
+// utility kernels (vcy_api.hip)
+int fill_state(vcy_ctx* ctx);
+
+}  // namespace vcy
