@@ -115,6 +115,7 @@ def main():
     dev = vc.VoxelCarver(opt, device_id=local_rank, z_range=(z0, z1))
     if not dev.Init():
         raise SystemExit("vcy_create failed: " + vc.last_error())
+    dev.set_param("fused", args.batch)
     d_sdf = [dev.upload_sdf(s) for s in sdfs]  # inputs resident in HBM before the timed region
 
     def barrier():
@@ -128,10 +129,7 @@ def main():
     def step(record):
         dev.reset()
         dev.timer_begin()
-        if args.batch:
-            ok = dev.CarveBatchDevice(views, d_sdf)
-        else:
-            ok = all(dev.CarveDevice(views[i], d_sdf[i]) for i in range(nv))
+        ok = dev.CarveBatchDevice(views, d_sdf)
         ms = dev.timer_end()
         if not ok:
             raise SystemExit("carve failed: " + vc.last_error())

@@ -195,6 +195,9 @@ int vcy_memcpy_d2h(vcy_ctx* ctx, void* dst_host, const void* src_device, int64_t
 /* Back to the state right after vcy_create (VoxelGrid::Init: sdf = lowest(), update_num = 0);
  * asynchronous on the context's stream. */
 int vcy_reset(vcy_ctx* ctx);
+/* Tuning knobs that never change results.  "fused" (default 1): 0 forces one kernel launch
+ * per view (the generic kernel) instead of the fused multi-view kernel. */
+int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all launches. */
 int vcy_set_stream(vcy_ctx* ctx, void* hip_stream);
 int vcy_sync(vcy_ctx* ctx);

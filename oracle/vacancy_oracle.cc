@@ -282,13 +282,13 @@ double orc_carve(orc_grid* g, const vcy_view* view, const float* sdf) {
           u = view->fx / pc[2] * pc[0] + view->cx;
           v = view->fy / pc[2] * pc[1] + view->cy;
         }
-        // Defined behaviour where the reference has none: pc.z == 0 with pc.x or
-        // pc.y == 0 gives NaN image coordinates, which the reference would feed to
-        // floor()/int conversion (UB).  Oracle and device both skip such a voxel.
-        if (std::isnan(u) || std::isnan(v)) continue;
-
         float dist = kInvalidSdf;  // :462
-        if (u < roi_min[0] || v < roi_min[1] || roi_max[0] < u || roi_max[1] < v) {  // :464-465
+        // :464-465.  The reference tests `u < roi_min.x || v < roi_min.y || roi_max.x < u ||
+        // roi_max.y < v`; this is its complement, which differs only for NaN coordinates
+        // (pc.z == 0 with pc.x or pc.y == 0): there the reference feeds NaN to floor()/int
+        // conversion (undefined behaviour); oracle and device both treat them as outside.
+        const bool inside = u >= roi_min[0] && v >= roi_min[1] && u <= roi_max[0] && v <= roi_max[1];
+        if (!inside) {
           if (opt.update_outside == VCY_OUTSIDE_NONE) {
             continue;
           } else if (opt.update_outside == VCY_OUTSIDE_MAX) {

@@ -22,8 +22,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB):
-        build()
+    build()  # incremental make: never test against a stale oracle
     lib = C.CDLL(LIB)
     P, vp = C.POINTER, C.c_void_p
     lib.orc_grid_create.restype = vp

@@ -135,6 +135,7 @@ def load():
         "vcy_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_int64]),
         "vcy_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_int64]),
         "vcy_reset": (C.c_int, [vp]),
+        "vcy_set_param": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "vcy_set_stream": (C.c_int, [vp, vp]),
         "vcy_sync": (C.c_int, [vp]),
         "vcy_timer_begin": (C.c_int, [vp]),

@@ -174,6 +174,9 @@ class VoxelCarver:
         assert self._lib.vcy_halo_unpack(self._ctx, dev, rank, world) == 0, last_error()
         self._lib.vcy_device_free(self._ctx, dev)
 
+    def set_param(self, name, value):
+        assert self._lib.vcy_set_param(self._ctx, name.encode(), int(value)) == 0, last_error()
+
     def reset(self):
         """Back to the state right after Init(): sdf = lowest(), update_num = 0."""
         assert self._lib.vcy_reset(self._ctx) == 0, last_error()

@@ -1,0 +1,447 @@
+// K1 (fused): carve up to 32 views per launch with the voxel state held in registers.
+//
+// Replaces the loop `for each view: Carve(camera, roi, sdf)` (reference voxel_carver.cc:516-528
+// around :415-496).  Voxels are independent and every voxel sees its views in sequence order,
+// so fusing views changes nothing but where the state lives: each workgroup owns a brick of
+// 32x8x8 voxels (x fastest: a wave reads two 128-byte row segments per slice), loads
+// sdf/update_num ONCE, applies all views, writes back only what changed.
+//
+// Per view every WAVE stages the footprint of its own 8x8x8 sub-brick in LDS as *quads*
+//   tile[j][i] = { s(x,y), s(x1,y), s(x,y1), s(x1,y1) },  x1 = min(x+1, roi_max.x) ...
+// i.e. the four bilinear taps of pixel (x,y) with the reference's ROI clamps already applied
+// (voxel_carver.cc:51-66), so a sample is ONE ds_read_b128 and no clamp arithmetic.  Tiles
+// are wave-private and double buffered: no workgroup barrier at all, and the global loads of
+// view i+1's tile are in flight while view i is computed.  A voxel whose projection falls outside the
+// staged tile (brick near the camera plane, footprint larger than the LDS budget, outside the
+// ROI) takes the generic global-memory path of carve_common.h, so correctness never depends
+// on the footprint estimate.
+//
+// The arithmetic of a sample is the reference's, operation for operation (carve_common.h);
+// the two divides fx/z, fy/z (camera.cc:133-136) use the same Newton sequence the compiler
+// emits for IEEE division minus the exponent pre-scaling, which is a no-op for operands in
+// [2^-60, 2^60]; anything outside that range takes the generic path.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "carve_common.h"
+
+namespace vcy {
+
+namespace {
+
+constexpr int BX = 32, BY = 8, BZ = 8;  // voxels per workgroup: four 8x8x8 wave bricks along x
+constexpr int WX = 8;                    // wave brick is WX x BY x BZ, lane = (x & 7) | (y << 3)
+constexpr int kMaxFusedViews = 32;
+constexpr int kTileQuads = 128;          // per wave and buffer (2 KB); 2 quads per lane at most
+
+struct FusedView {
+  ViewParams v;
+};
+// c2_all[view][3][nz_local] = R[i][2] * pz[z]  (one fp32 multiply per entry, done on the host)
+
+struct TileInfo {
+  float lo_x, hi_x, lo_y, hi_y;  // closed range of (u,v) whose taps are in the tile
+  float pitchf;
+  int base;                      // -(ty0*tw + tx0)
+  int tx0, ty0, tw, nq;          // nq = tw*th quads; 0: no tile for this view
+  unsigned magic;                // ceil(2^16 / tw): q / tw == (q * magic) >> 16 for q < 128
+};
+
+// Correctly rounded n/d for normal operands away from the exponent limits: v_rcp_f32 plus the
+// refinement steps of the standard fp32 division expansion (without v_div_scale/v_div_fixup).
+__device__ __forceinline__ float div_fast(float n, float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r, 1.0f);
+  r = __builtin_fmaf(e, r, r);
+  float q = n * r;
+  const float e2 = __builtin_fmaf(-d, q, n);
+  q = __builtin_fmaf(e2, r, q);
+  const float e3 = __builtin_fmaf(-d, q, n);
+  return __builtin_fmaf(e3, r, q);
+}
+
+// 2^-60 <= z <= 2^60 (also false for negative z, NaN, inf, 0)
+__device__ __forceinline__ bool in_fast_div_range(float z) {
+  const unsigned lo = 0x21800000u;  // 2^-60
+  const unsigned hi = 0x5d800000u;  // 2^60
+  return (__float_as_uint(z) - lo) <= (hi - lo);
+}
+
+typedef const float __attribute__((address_space(1))) * gfloat_ptr;  // known-global loads
+typedef const float __attribute__((address_space(4))) * cfloat_ptr;  // read-only: scalar loads
+
+// Generic sample for a voxel the staged tile does not cover (rare): global-memory taps and the
+// full ROI / outside-image semantics of carve_common.h.  Kept out of line so that the hot loop
+// stays small.
+__device__ __attribute__((noinline)) bool sample_generic(const ViewParams* v, ModeParams m, float px,
+                                                         float py, float pz, float* dist) {
+  return view_distance<true, 0, 0, false, false>(*v, m, px, py, pz, dist);
+}
+
+// LDS traffic inside one wave needs ordering against the compiler only (DS ops of a wave are
+// executed in issue order).
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Branch-free voxel update (select form of fuse() in carve_common.h): first touch
+// (voxel_carver.cc:482-486), UpdateVoxelMax (:78-86) or UpdateVoxelWeightedAverage (:88-95).
+template <int UPDATE>
+__device__ __forceinline__ void apply_sample(bool ok, float dist, float wgt, float& s, int& n) {
+  if (UPDATE == VCY_UPDATE_MAX) {
+    const bool take = ok && (n < 1 || dist > s);
+    s = take ? dist : s;
+    n += take ? 1 : 0;
+  } else {
+    const float inv_denom = div_fast(1.0f, wgt * (float)(n + 1));
+    const float avg = (wgt * (float)n * s + wgt * dist) * inv_denom;
+    const float ns = (n < 1) ? dist : avg;
+    s = ok ? ns : s;
+    n += ok ? 1 : 0;
+  }
+}
+
+struct QuadRegs {
+  float4 q0, q1;
+};
+
+// Issues the global loads of this lane's (up to two) quads of view vi's tile.
+__device__ __forceinline__ void tile_prefetch(const ViewParams& v, const TileInfo& ti, int lane,
+                                              QuadRegs* r) {
+  const int nq = __builtin_amdgcn_readfirstlane(ti.nq);
+  r->q0 = r->q1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nq == 0) return;
+  const int tw = __builtin_amdgcn_readfirstlane(ti.tw);
+  const int tx0 = __builtin_amdgcn_readfirstlane(ti.tx0);
+  const int ty0 = __builtin_amdgcn_readfirstlane(ti.ty0);
+  const unsigned magic = __builtin_amdgcn_readfirstlane(ti.magic);
+  gfloat_ptr img = (gfloat_ptr)v.sdf;
+  if (lane < nq) {
+    const int j = (int)(((unsigned)lane * magic) >> 16), i = lane - j * tw;
+    const int xx = tx0 + i, yy = ty0 + j;
+    const int xx1 = min(xx + 1, v.roi_max_xi), yy1 = min(yy + 1, v.roi_max_yi);
+    gfloat_ptr r0 = img + (int64_t)v.width * yy;
+    gfloat_ptr r1 = img + (int64_t)v.width * yy1;
+    r->q0 = make_float4(r0[xx], r0[xx1], r1[xx], r1[xx1]);
+  }
+  if (nq > 64 && lane + 64 < nq) {
+    const int q = lane + 64;
+    const int j = (int)(((unsigned)q * magic) >> 16), i = q - j * tw;
+    const int xx = tx0 + i, yy = ty0 + j;
+    const int xx1 = min(xx + 1, v.roi_max_xi), yy1 = min(yy + 1, v.roi_max_yi);
+    gfloat_ptr r0 = img + (int64_t)v.width * yy;
+    gfloat_ptr r1 = img + (int64_t)v.width * yy1;
+    r->q1 = make_float4(r0[xx], r0[xx1], r1[xx], r1[xx1]);
+  }
+}
+
+template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX>
+__global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
+                                                          const FusedView* __restrict__ views,
+                                                          const float* __restrict__ c2_all,
+                                                          int nviews, ModeParams mode, int nbx,
+                                                          int nby) {
+  __shared__ float4 tile_all[4][2][kTileQuads];
+  __shared__ TileInfo tinfo_all[4][kMaxFusedViews];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  float4(*tile)[kTileQuads] = tile_all[wave];
+  TileInfo* tinfo = tinfo_all[wave];
+  const int lx = lane & (WX - 1), ly = lane >> 3;
+  int b = blockIdx.x;
+  const int bx = b % nbx;
+  b /= nbx;
+  const int by = b % nby;
+  const int bz = b / nby;
+  const int x_first = bx * BX + wave * WX;  // wave brick origin
+  const int x_raw = x_first + lx, y_raw = by * BY + ly;
+  const bool col_valid = x_raw < g.nx && y_raw < g.ny;
+  const int x = min(x_raw, g.nx - 1), y = min(y_raw, g.ny - 1);  // clones for out-of-grid lanes
+  const int zl0 = bz * BZ;
+  const float px = g.px[x], py = g.py[y];
+
+  // ---- prologue: footprint rectangle of the wave brick in every view ---------------------
+  for (int vbase = 0; vbase < nviews; vbase += 8) {
+    const int vi = vbase + (lane >> 3), corner = lane & 7;
+    if (vi < nviews) {
+      const ViewParams& v = views[vi].v;
+      const int x_lo = min(x_first, g.nx - 1), x_hi = min(x_first + WX - 1, g.nx - 1);
+      const int y_hi = min(by * BY + BY - 1, g.ny - 1);
+      const int z_hi = min(zl0 + BZ - 1, g.nz_local - 1);
+      const float cpx = g.px[(corner & 1) ? x_hi : x_lo];
+      const float cpy = g.py[(corner & 2) ? y_hi : by * BY];
+      const float cpz = g.pz[g.z0 + ((corner & 4) ? z_hi : zl0)];
+      float pc[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        pc[i] = v.t[i] + (v.r[i][0] * cpx + (v.r[i][1] * cpy + v.r[i][2] * cpz));
+      const float u = v.fx / pc[2] * pc[0] + v.cx;
+      const float w = v.fy / pc[2] * pc[1] + v.cy;
+      // the whole (convex) brick is in front of the camera iff all 8 corners are
+      int bad = !(pc[2] > 0.0f) || !(fabsf(u) < 1.0e8f) || !(fabsf(w) < 1.0e8f);
+      float umin = u, umax = u, wmin = w, wmax = w;
+#pragma unroll
+      for (int d = 1; d < 8; d <<= 1) {
+        umin = fminf(umin, __shfl_xor(umin, d, 64));
+        umax = fmaxf(umax, __shfl_xor(umax, d, 64));
+        wmin = fminf(wmin, __shfl_xor(wmin, d, 64));
+        wmax = fmaxf(wmax, __shfl_xor(wmax, d, 64));
+        bad |= __shfl_xor(bad, d, 64);
+      }
+      if (corner == 0) {
+        TileInfo ti;
+        ti.lo_x = ti.lo_y = INFINITY;  // nothing passes the tile test
+        ti.hi_x = ti.hi_y = -INFINITY;
+        ti.pitchf = 0.0f;
+        ti.base = 0;
+        ti.tx0 = ti.ty0 = ti.tw = ti.nq = 0;
+        ti.magic = 0;
+        if (!bad) {
+          // one pixel of slack on each side covers the rounding of the corner projections
+          const int tx0 = max((int)floorf(umin) - 1, v.roi_min_xi);
+          const int ty0 = max((int)floorf(wmin) - 1, v.roi_min_yi);
+          const int tx1 = min((int)floorf(umax) + 1, v.roi_max_xi);
+          const int ty1 = min((int)floorf(wmax) + 1, v.roi_max_yi);
+          const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
+          if (tw > 0 && th > 0 && tw <= kTileQuads && th <= kTileQuads && tw * th <= kTileQuads) {
+            ti.tx0 = tx0;
+            ti.ty0 = ty0;
+            ti.tw = tw;
+            ti.nq = tw * th;
+            ti.magic = (65536u + (unsigned)tw - 1u) / (unsigned)tw;
+            ti.pitchf = (float)tw;
+            ti.base = -(ty0 * tw + tx0);
+            ti.lo_x = (float)tx0;
+            ti.lo_y = (float)ty0;
+            // taps exist for floor(u) in [tx0, tx1]; at the ROI edge u == roi_max is still inside
+            ti.hi_x = (tx1 == v.roi_max_xi) ? v.roi_max_x
+                                            : __uint_as_float(__float_as_uint((float)(tx1 + 1)) - 1u);
+            ti.hi_y = (ty1 == v.roi_max_yi) ? v.roi_max_y
+                                            : __uint_as_float(__float_as_uint((float)(ty1 + 1)) - 1u);
+          }
+        }
+        tinfo[vi] = ti;
+      }
+    }
+  }
+  wave_lds_fence();
+
+  // ---- load the wave brick's state ----------------------------------------------------------
+  CountT* __restrict__ cnt = (CountT*)g.cnt;
+  float s[BZ];
+  int n[BZ];
+  const int64_t slice = (int64_t)g.nx * g.ny;
+  const int64_t col = (int64_t)y * g.nx + x;
+#pragma unroll
+  for (int k = 0; k < BZ; ++k) {
+    const int zl = min(zl0 + k, g.nz_local - 1);
+    s[k] = g.sdf[(int64_t)zl * slice + col];
+    n[k] = (int)cnt[(int64_t)zl * slice + col];
+  }
+
+  // tile of view 0
+  QuadRegs pre;
+  tile_prefetch(views[0].v, tinfo[0], lane, &pre);
+  tile[0][lane] = pre.q0;
+  tile[0][lane + 64] = pre.q1;
+  wave_lds_fence();
+
+  // ---- views ------------------------------------------------------------------------------
+  for (int vi = 0; vi < nviews; ++vi) {
+    const ViewParams& v = views[vi].v;
+    cfloat_ptr c2 = (cfloat_ptr)(c2_all + (size_t)vi * 3 * g.nz_local);
+    const int buf = vi & 1;
+    // loads of the next view's tile fly while this view is computed
+    if (vi + 1 < nviews) tile_prefetch(views[vi + 1].v, tinfo[vi + 1], lane, &pre);
+
+    const float lo_x = tinfo[vi].lo_x, hi_x = tinfo[vi].hi_x;
+    const float lo_y = tinfo[vi].lo_y, hi_y = tinfo[vi].hi_y;
+    const float pitchf = tinfo[vi].pitchf;
+    const int base = tinfo[vi].base;
+    const float c0x = v.r[0][0] * px, c0y = v.r[1][0] * px, c0z = v.r[2][0] * px;
+    const float c1x = v.r[0][1] * py, c1y = v.r[1][1] * py, c1z = v.r[2][1] * py;
+
+    // Straight-line fast path for the 8 voxels of this thread (no divergent control flow, so
+    // the eight LDS reads and the arithmetic interleave); voxels the tile does not cover are
+    // only recorded here and handled below.
+    unsigned slow = 0;
+#pragma unroll
+    for (int k = 0; k < BZ; ++k) {
+      const int zl = min(zl0 + k, g.nz_local - 1);
+      const float pcx = v.t[0] + (c0x + (c1x + c2[zl]));
+      const float pcy = v.t[1] + (c0y + (c1y + c2[g.nz_local + zl]));
+      const float pcz = v.t[2] + (c0z + (c1z + c2[2 * g.nz_local + zl]));
+      const bool zfast = in_fast_div_range(pcz);
+      const float qx = div_fast(v.fx, pcz);
+      const float qy = SAMEF ? qx : div_fast(v.fy, pcz);
+      const float u = qx * pcx + v.cx;
+      const float w = qy * pcy + v.cy;
+      const bool in_tile = zfast && u >= lo_x && u <= hi_x && w >= lo_y && w <= hi_y;
+      slow |= (in_tile ? 0u : 1u) << k;
+      const float fu = floorf(u), fw = floorf(w);
+      const float lu = u - fu, lv = w - fw;
+      // any index is harmless when !in_tile (the sample is discarded); keep it inside the tile
+      const unsigned idx = min((unsigned)((int)__builtin_fmaf(fw, pitchf, fu) + base),
+                               (unsigned)(kTileQuads - 1));
+      const float4 q = tile[buf][idx];
+      const float a = (1.0f - lu) * (1.0f - lv) * q.x;
+      const float bb = lu * (1.0f - lv) * q.y;
+      const float cc = (1.0f - lu) * lv * q.z;
+      const float dd = lu * lv * q.w;
+      const float dist = ((a + bb) + cc) + dd;
+      bool ok = in_tile;
+      if (TRUNC) ok = ok && !(dist < -1.0f);
+      if (CHECKMAX) ok = ok && !(n[k] > g.max_update_num);
+      apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]);
+    }
+    if (slow) {
+#pragma unroll
+      for (int k = 0; k < BZ; ++k) {
+        if ((slow >> k) & 1u) {
+          const int zl = min(zl0 + k, g.nz_local - 1);
+          float dist = 0.0f;
+          bool ok = sample_generic(&v, mode, px, py, g.pz[g.z0 + zl], &dist);
+          if (CHECKMAX) ok = ok && !(n[k] > g.max_update_num);
+          apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]);
+        }
+      }
+    }
+    // the next view's tile goes into the other buffer (its last readers finished a view ago)
+    if (vi + 1 < nviews) {
+      wave_lds_fence();
+      tile[buf ^ 1][lane] = pre.q0;
+      tile[buf ^ 1][lane + 64] = pre.q1;
+      wave_lds_fence();
+    }
+  }
+
+  // ---- write back what changed (update_num grows with every change) ----------------------------
+  if (col_valid) {
+#pragma unroll
+    for (int k = 0; k < BZ; ++k) {
+      if (zl0 + k < g.nz_local) {
+        const int64_t idx = (int64_t)(zl0 + k) * slice + col;
+        if (n[k] != (int)cnt[idx]) {
+          g.sdf[idx] = s[k];
+          cnt[idx] = (CountT)n[k];
+        }
+      }
+    }
+  }
+}
+
+template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF>
+void launch_fused_4(bool checkmax, dim3 grid, hipStream_t s, const GridParams& g, const FusedView* dv,
+                    const float* c2, int nv, const ModeParams& m, int nbx, int nby) {
+  if (checkmax)
+    hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, true>), grid, dim3(256), 0, s, g,
+                       dv, c2, nv, m, nbx, nby);
+  else
+    hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, false>), grid, dim3(256), 0, s, g,
+                       dv, c2, nv, m, nbx, nby);
+}
+
+template <typename CountT, int UPDATE>
+void launch_fused_2(bool trunc, bool samef, bool checkmax, dim3 grid, hipStream_t s, const GridParams& g,
+                    const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby) {
+  if (trunc) {
+    if (samef) launch_fused_4<CountT, UPDATE, true, true>(checkmax, grid, s, g, dv, c2, nv, m, nbx, nby);
+    else launch_fused_4<CountT, UPDATE, true, false>(checkmax, grid, s, g, dv, c2, nv, m, nbx, nby);
+  } else {
+    if (samef) launch_fused_4<CountT, UPDATE, false, true>(checkmax, grid, s, g, dv, c2, nv, m, nbx, nby);
+    else launch_fused_4<CountT, UPDATE, false, false>(checkmax, grid, s, g, dv, c2, nv, m, nbx, nby);
+  }
+}
+
+template <typename CountT>
+void launch_fused_1(int update, bool trunc, bool samef, bool checkmax, dim3 grid, hipStream_t s,
+                    const GridParams& g, const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby) {
+  if (update == VCY_UPDATE_MAX)
+    launch_fused_2<CountT, VCY_UPDATE_MAX>(trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby);
+  else
+    launch_fused_2<CountT, VCY_UPDATE_WEIGHTED_AVERAGE>(trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby);
+}
+
+bool sane(float f) { return f >= 0x1p-40f && f <= 0x1p40f; }
+
+}  // namespace
+
+// True when the fused kernel can take these views (otherwise the per-view kernel does).
+bool fused_eligible(const vcy_ctx* c, int n_views, const vcy_view* views) {
+  const vcy_update_option& u = c->opt.update_option;
+  if (u.sdf_interp != VCY_INTERP_BILINEAR) return false;
+  if (c->cnt_bytes > 2) return false;
+  if (u.voxel_update == VCY_UPDATE_WEIGHTED_AVERAGE && !sane(u.voxel_update_weight)) return false;
+  for (int i = 0; i < n_views; ++i) {
+    const vcy_view& v = views[i];
+    if (v.is_ortho) return false;
+    if (!sane(v.fx) || !sane(v.fy)) return false;
+    if (v.width > 8192 || v.height > 8192) return false;
+  }
+  return true;
+}
+
+// Carves views[0..n_views) (n_views <= 32, max_sdf already resolved) in one launch.
+int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewParams* vp) {
+  const vcy_update_option& u = c->opt.update_option;
+  const int nzl = c->nz_local();
+  // per-view tables c2[i][zl] = R[i][2] * pz[z0+zl]
+  std::vector<float> c2((size_t)n_views * 3 * nzl);
+  for (int vi = 0; vi < n_views; ++vi)
+    for (int i = 0; i < 3; ++i)
+      for (int zl = 0; zl < nzl; ++zl)
+        c2[((size_t)vi * 3 + i) * nzl + zl] = vp[vi].r[i][2] * c->h_pz[c->z0 + zl];
+  const size_t c2_bytes = c2.size() * sizeof(float);
+  const size_t fv_bytes = sizeof(FusedView) * (size_t)n_views;
+  // staging buffer owned by the context, grown on demand
+  if (c->fused_scratch_bytes < c2_bytes + fv_bytes) {
+    VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->d_fused_scratch) VCY_HIP_CHECK(hipFree(c->d_fused_scratch));
+    c->d_fused_scratch = nullptr;
+    c->fused_scratch_bytes = 0;
+    VCY_HIP_CHECK(hipMalloc(&c->d_fused_scratch, c2_bytes + fv_bytes));
+    c->fused_scratch_bytes = c2_bytes + fv_bytes;
+  }
+  float* d_c2 = (float*)c->d_fused_scratch;
+  FusedView* d_views = (FusedView*)((char*)c->d_fused_scratch + c2_bytes);
+  std::vector<FusedView> fv((size_t)n_views);
+  bool samef = true;
+  for (int vi = 0; vi < n_views; ++vi) {
+    fv[vi].v = vp[vi];
+    samef = samef && (vp[vi].fx == vp[vi].fy);
+  }
+  // the scratch may still be read by the previous launch on this stream
+  VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+  VCY_HIP_CHECK(hipMemcpyAsync(d_c2, c2.data(), c2_bytes, hipMemcpyHostToDevice, c->stream));
+  VCY_HIP_CHECK(hipMemcpyAsync(d_views, fv.data(), fv_bytes, hipMemcpyHostToDevice, c->stream));
+  VCY_HIP_CHECK(hipStreamSynchronize(c->stream));  // host vectors die at return
+
+  const int nbx = (c->nx + BX - 1) / BX, nby = (c->ny + BY - 1) / BY, nbz = (nzl + BZ - 1) / BZ;
+  const int64_t nblocks = (int64_t)nbx * nby * nbz;
+  if (nblocks > 0x7fffffffLL) {
+    set_error("slab too large for one launch");
+    return VCY_ERR_TOO_MANY_VOXELS;
+  }
+  ModeParams m{u.voxel_update, u.sdf_interp, u.update_outside, u.use_truncation ? 1 : 0, 0};
+  // update_num can only exceed voxel_max_update_num after more than that many views
+  const bool checkmax = c->views_carved + n_views > (int64_t)u.voxel_max_update_num;
+  const dim3 grid((unsigned)nblocks);
+  if (c->cnt_bytes == 1)
+    launch_fused_1<uint8_t>(u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, g, d_views,
+                            d_c2, n_views, m, nbx, nby);
+  else
+    launch_fused_1<uint16_t>(u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, g, d_views,
+                             d_c2, n_views, m, nbx, nby);
+  VCY_HIP_CHECK(hipGetLastError());
+  return VCY_OK;
+}
+
+int fused_max_views() { return kMaxFusedViews; }
+
+}  // namespace vcy

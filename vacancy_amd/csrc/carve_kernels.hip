@@ -16,135 +16,9 @@
 #include <algorithm>
 #include <vector>
 
-#include "vcy_internal.h"
+#include "carve_common.h"
 
 namespace vcy {
-
-struct ViewParams {
-  float r[3][3];   // w2c rotation, row-major
-  float t[3];
-  float fx, fy, cx, cy;
-  float roi_min_x, roi_min_y, roi_max_x, roi_max_y;  // (float)int, as the reference's int->float compare
-  int roi_min_xi, roi_min_yi, roi_max_xi, roi_max_yi;
-  int width;
-  float max_sdf;
-  const float* sdf;
-};
-
-struct GridParams {
-  float* sdf;
-  void* cnt;
-  const float* px;
-  const float* py;
-  const float* pz;
-  int nx, ny;
-  int z0;        // global z of local slice 0
-  int nz_local;
-  int max_update_num;
-  float weight;
-};
-
-struct ModeParams {
-  int update, interp, outside, trunc, ortho;
-};
-
-// ---- sampling, shared by every carve kernel --------------------------------------------
-
-__device__ __forceinline__ float tap(const float* __restrict__ s, int width, int x, int y) {
-  return s[(int64_t)width * y + x];
-}
-
-// Returns false when the voxel must be skipped for this view.
-template <bool RT, int INTERP, int OUTSIDE, bool TRUNC, bool ORTHO>
-__device__ __forceinline__ bool view_distance(const ViewParams& v, const ModeParams& m, float px,
-                                              float py, float pz, float* dist_out) {
-  const int interp = RT ? m.interp : INTERP;
-  const int outside = RT ? m.outside : OUTSIDE;
-  const bool trunc = RT ? (m.trunc != 0) : TRUNC;
-  const bool ortho = RT ? (m.ortho != 0) : ORTHO;
-
-  float pc[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const float c0 = v.r[i][0] * px;
-    const float c1 = v.r[i][1] * py;
-    const float c2 = v.r[i][2] * pz;
-    pc[i] = v.t[i] + (c0 + (c1 + c2));
-  }
-  if (pc[2] < 0.0f) return false;
-  float u, w;
-  if (ortho) {
-    u = pc[0];
-    w = pc[1];
-  } else {
-    u = v.fx / pc[2] * pc[0] + v.cx;
-    w = v.fy / pc[2] * pc[1] + v.cy;
-  }
-  // NaN image coordinates (pc.z == 0 and pc.x|y == 0) are undefined in the reference;
-  // skipped here and in the oracle.
-  if (u != u || w != w) return false;
-
-  float dist;
-  if (u < v.roi_min_x || w < v.roi_min_y || v.roi_max_x < u || v.roi_max_y < w) {
-    if (outside == VCY_OUTSIDE_NONE) return false;
-    dist = v.max_sdf;
-  } else if (interp == VCY_INTERP_NN) {
-    int xi = (int)roundf(u);
-    int yi = (int)roundf(w);
-    xi = max(xi, v.roi_min_xi);
-    yi = max(yi, v.roi_min_yi);
-    xi = min(xi, v.roi_max_xi);
-    yi = min(yi, v.roi_max_yi);
-    dist = tap(v.sdf, v.width, xi, yi);
-  } else {
-    const float fu = floorf(u), fw = floorf(w);
-    int x0 = (int)fu, y0 = (int)fw;
-    int x1 = x0 + 1, y1 = y0 + 1;
-    x0 = max(x0, v.roi_min_xi);
-    y0 = max(y0, v.roi_min_yi);
-    x1 = min(x1, v.roi_max_xi);
-    y1 = min(y1, v.roi_max_yi);
-    const float lu = u - (float)x0;
-    const float lv = w - (float)y0;
-    const float s00 = tap(v.sdf, v.width, x0, y0);
-    const float s10 = tap(v.sdf, v.width, x1, y0);
-    const float s01 = tap(v.sdf, v.width, x0, y1);
-    const float s11 = tap(v.sdf, v.width, x1, y1);
-    const float a = (1.0f - lu) * (1.0f - lv) * s00;
-    const float b = lu * (1.0f - lv) * s10;
-    const float c = (1.0f - lu) * lv * s01;
-    const float d = lu * lv * s11;
-    dist = ((a + b) + c) + d;
-  }
-  if (trunc && dist < -1.0f) return false;
-  *dist_out = dist;
-  return true;
-}
-
-// Applies one sample to the voxel state held in registers.  Returns true if it changed.
-template <bool RT, int UPDATE>
-__device__ __forceinline__ bool fuse(const ModeParams& m, float weight, float dist, float& sdf,
-                                     int& n) {
-  const int update = RT ? m.update : UPDATE;
-  if (n < 1) {  // first touch, voxel_carver.cc:482-486
-    sdf = dist;
-    n = 1;
-    return true;
-  }
-  if (update == VCY_UPDATE_MAX) {  // UpdateVoxelMax, :78-86
-    if (dist > sdf) {
-      sdf = dist;
-      n = n + 1;
-      return true;
-    }
-    return false;
-  }
-  // UpdateVoxelWeightedAverage, :88-95
-  const float inv_denom = 1.0f / (weight * (float)(n + 1));
-  sdf = (weight * (float)n * sdf + weight * dist) * inv_denom;
-  n = n + 1;
-  return true;
-}
 
 // ---- kernel A: one thread per voxel, one view per launch (generic, every mode) ---------
 //
@@ -253,32 +127,47 @@ int launch_carve(vcy_ctx* c, int n_views, const vcy_view* views, const float* co
     return VCY_ERR_TOO_MANY_VOXELS;
   }
 
-  float* d_max = nullptr;
-  if (u.update_outside == VCY_OUTSIDE_MAX) VCY_HIP_CHECK(hipMalloc(&d_max, sizeof(float)));
-
-  for (int i = 0; i < n_views; ++i) {
-    ModeParams m{u.voxel_update, u.sdf_interp, u.update_outside, u.use_truncation ? 1 : 0,
-                 views[i].is_ortho ? 1 : 0};
-    float max_sdf = 0.0f;
-    if (d_max) {
+  // max over the whole SDF buffer (voxel_carver.cc:436); only update_outside = kMax reads it
+  std::vector<float> max_sdf((size_t)n_views, 0.0f);
+  if (u.update_outside == VCY_OUTSIDE_MAX) {
+    float* d_max = nullptr;
+    VCY_HIP_CHECK(hipMalloc(&d_max, sizeof(float) * (size_t)n_views));
+    for (int i = 0; i < n_views; ++i) {
       const int64_t npx = (int64_t)views[i].width * views[i].height;
-      hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, c->stream, sdf_dev[i], npx, d_max);
-      VCY_HIP_CHECK(hipMemcpyAsync(&max_sdf, d_max, sizeof(float), hipMemcpyDeviceToHost, c->stream));
-      VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+      hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, c->stream, sdf_dev[i], npx, d_max + i);
     }
-    ViewParams v;
-    fill_view(views[i], sdf_dev[i], max_sdf, &v);
-    if (c->cnt_bytes == 1) launch_view<uint8_t>(c, g, v, m);
-    else if (c->cnt_bytes == 2) launch_view<uint16_t>(c, g, v, m);
-    else launch_view<uint32_t>(c, g, v, m);
-    VCY_HIP_CHECK(hipGetLastError());
-    c->views_carved += 1;
+    hipError_t e = hipMemcpyAsync(max_sdf.data(), d_max, sizeof(float) * (size_t)n_views,
+                                  hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_max);
+    if (e != hipSuccess) {
+      set_error("max reduce failed: %s", hipGetErrorString(e));
+      return VCY_ERR_HIP;
+    }
+  }
+  std::vector<ViewParams> vp((size_t)n_views);
+  for (int i = 0; i < n_views; ++i) fill_view(views[i], sdf_dev[i], max_sdf[i], &vp[i]);
+
+  if (c->use_fused && fused_eligible(c, n_views, views)) {
+    const int chunk = fused_max_views();
+    for (int i = 0; i < n_views; i += chunk) {
+      const int m = std::min(chunk, n_views - i);
+      int rc = launch_carve_fused(c, g, m, &vp[i]);
+      if (rc != VCY_OK) return rc;
+      c->views_carved += m;
+    }
+  } else {
+    for (int i = 0; i < n_views; ++i) {
+      ModeParams m{u.voxel_update, u.sdf_interp, u.update_outside, u.use_truncation ? 1 : 0,
+                   views[i].is_ortho ? 1 : 0};
+      if (c->cnt_bytes == 1) launch_view<uint8_t>(c, g, vp[i], m);
+      else if (c->cnt_bytes == 2) launch_view<uint16_t>(c, g, vp[i], m);
+      else launch_view<uint32_t>(c, g, vp[i], m);
+      VCY_HIP_CHECK(hipGetLastError());
+      c->views_carved += 1;
+    }
   }
   c->halo_valid = false;
-  if (d_max) {
-    VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
-    VCY_HIP_CHECK(hipFree(d_max));
-  }
   return VCY_OK;
 }
 

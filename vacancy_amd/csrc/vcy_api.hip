@@ -188,6 +188,10 @@ int vcy_create(const vcy_carver_option* o, int device_id, int z_begin, int z_end
     for (int i = 0; i < n[a]; ++i)
       p[i] = diff * (static_cast<float>(i) / static_cast<float>(n[a])) + o->bb_min[a] + offset;
     VCY_TRY(hipMemcpy(d_axis[a], p.data(), sizeof(float) * n[a], hipMemcpyHostToDevice));
+    if (a == 2) {
+      c->h_pz = new float[n[2]];
+      std::memcpy(c->h_pz, p.data(), sizeof(float) * n[2]);
+    }
   }
   rc = fill_state(c);
   if (rc != VCY_OK) return fail(rc);
@@ -207,6 +211,8 @@ void vcy_destroy(vcy_ctx* c) {
   (void)hipFree(c->d_py);
   (void)hipFree(c->d_pz);
   (void)hipFree(c->d_mc_tables);
+  (void)hipFree(c->d_fused_scratch);
+  delete[] c->h_pz;
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -236,6 +242,16 @@ int vcy_set_stream(vcy_ctx* c, void* s) {
   c->stream = (hipStream_t)s;
   c->own_stream = false;
   return VCY_OK;
+}
+
+int vcy_set_param(vcy_ctx* c, const char* name, int value) {
+  if (!c || !name) return VCY_ERR_INVALID_ARG;
+  if (std::strcmp(name, "fused") == 0) {
+    c->use_fused = value != 0;
+    return VCY_OK;
+  }
+  set_error("unknown parameter %s", name);
+  return VCY_ERR_INVALID_ARG;
 }
 
 int vcy_sync(vcy_ctx* c) {

@@ -59,6 +59,10 @@ struct vcy_ctx {
   float* d_py = nullptr;
   float* d_pz = nullptr;
 
+  bool use_fused = true;              // vcy_set_option("fused", 0) forces the per-view kernel
+  float* h_pz = nullptr;              // host copy of d_pz (per-view z tables of the fused carve)
+  void* d_fused_scratch = nullptr;    // view blocks + z tables of the fused carve kernel
+  size_t fused_scratch_bytes = 0;
   void* d_mc_tables = nullptr;        // marching-cubes case tables (mc_kernels.hip)
   float last_extract_device_ms = 0.0f;
 
@@ -75,6 +79,12 @@ namespace vcy {
 
 // carve_kernels.hip
 int launch_carve(vcy_ctx* ctx, int n_views, const vcy_view* views, const float* const* sdf_dev);
+// carve_fused.hip
+struct GridParams;
+struct ViewParams;
+bool fused_eligible(const vcy_ctx* ctx, int n_views, const vcy_view* views);
+int launch_carve_fused(vcy_ctx* ctx, const GridParams& g, int n_views, const ViewParams* vp);
+int fused_max_views();
 // mc_kernels.hip
 int extract_iso(vcy_ctx* ctx, double iso, int linear_interp, vcy_mesh* out);
 // sdf2d.hip
