@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--mode", default="default", choices=["default", "tsdf"])
     ap.add_argument("--batch", type=int, default=1, help="1: fused multi-view carve; 0: one launch per view")
+    ap.add_argument("--cull", type=int, default=1,
+                    help="1: drop (brick, view) pairs that provably cannot change the brick (results identical)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -116,6 +118,7 @@ def main():
     if not dev.Init():
         raise SystemExit("vcy_create failed: " + vc.last_error())
     dev.set_param("fused", args.batch)
+    dev.set_param("cull", args.cull)
     d_sdf = [dev.upload_sdf(s) for s in sdfs]  # inputs resident in HBM before the timed region
 
     def barrier():
@@ -204,7 +207,7 @@ def main():
         "config": {"workload": "%d^3 grid x %d views at %dx%d, %s mode, z-slab sharded over %d GPU(s)"
                                % (n, nv, args.width, args.height, args.mode, world),
                    "grid": n, "views": nv, "image": [args.width, args.height], "mode": args.mode,
-                   "fused_views_per_launch": views_per_launch},
+                   "fused_views_per_launch": views_per_launch, "view_dropping": bool(args.cull)},
         "roofline": roofline, "mc": mc,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

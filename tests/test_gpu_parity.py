@@ -168,6 +168,60 @@ def test_batch_equals_sequential():
             a.free_device(d)
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(use_truncation=True, truncation_band=0.2),
+                                dict(update_outside=1), dict(voxel_update=1, use_truncation=True)])
+def test_view_dropping_is_exact(kw):
+    """The fused kernel drops (wave brick, view) pairs that provably cannot change the brick.
+    20 views in one fused call with dropping on == off == per-view kernel == oracle, on smooth
+    silhouette SDFs and on adversarial ones (white noise, plateaus equal to the running max,
+    NaN / inf / lowest() pixels)."""
+    n, nv, w, h = 56, 20, 200, 150
+    uo = UpdateOption(**kw)
+    opt = synth.sphere_option(n, uo)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    rng = np.random.RandomState(11)
+    sdfs = []
+    for i in range(nv):
+        base = vc.make_sdf(masks[i], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
+        kind = i % 5
+        if kind == 1:
+            base = rng.uniform(-1.5, 1.0, base.shape).astype(np.float32)
+        elif kind == 2:
+            base = np.round(base * 4) / 4  # plateaus: many exact ties with the running max
+            base = base.astype(np.float32)
+        elif kind == 3:
+            base = base.copy()
+            base[rng.rand(*base.shape) < 0.01] = np.nan
+            base[rng.rand(*base.shape) < 0.01] = np.inf
+            base[rng.rand(*base.shape) < 0.01] = np.finfo(np.float32).min
+            base[rng.rand(*base.shape) < 0.01] = -np.inf
+        sdfs.append(np.ascontiguousarray(base))
+    views[4].roi_min[0], views[4].roi_max[1] = 30, 120
+    orc = O.OracleGrid(opt)
+    for i in range(nv):
+        orc.carve(views[i], sdfs[i])
+    os_, ou = orc.download()
+    for fused, cull in ((1, 1), (1, 0), (0, 0)):
+        dev = vc.VoxelCarver(opt)
+        assert dev.Init()
+        dev.set_param("fused", fused)
+        dev.set_param("cull", cull)
+        devs = [dev.upload_sdf(s) for s in sdfs]
+        assert dev.CarveBatchDevice(views, devs), vc.last_error()
+        ds, du = dev.download()
+        for d in devs:
+            dev.free_device(d)
+        assert np.array_equal(du, ou), (kw, fused, cull, int((du != ou).sum()))
+        # NaN voxels (only the NaN/inf-poisoned SDFs produce them) must be NaN on both sides;
+        # their sign/payload is not defined by IEEE-754 and differs between x86 and gfx950
+        # for generated NaNs (inf - inf).  Everything else is compared bit for bit.
+        nan_d, nan_o = np.isnan(ds), np.isnan(os_)
+        assert np.array_equal(nan_d, nan_o), (kw, fused, cull)
+        bits_d = np.where(nan_d, 0, ds.view(np.uint32))
+        bits_o = np.where(nan_o, 0, os_.view(np.uint32))
+        assert np.array_equal(bits_d, bits_o), (kw, fused, cull, int((bits_d != bits_o).sum()))
+
+
 def test_marching_cubes_random_state():
     """MC alone on arbitrary state: random sdf, invalid holes, untouched voxels, values within
     the 1e-5 snap band of the iso level, non-cubic dims."""

@@ -48,6 +48,7 @@ struct TileInfo {
   int base;                      // -(ty0*tw + tx0)
   int tx0, ty0, tw, nq;          // nq = tw*th quads; 0: no tile for this view
   unsigned magic;                // ceil(2^16 / tw): q / tw == (q * magic) >> 16 for q < 128
+  float ub;                      // upper bound of any sample taken from this tile (+inf: unknown)
 };
 
 // Correctly rounded n/d for normal operands away from the exponent limits: v_rcp_f32 plus the
@@ -140,18 +141,33 @@ __device__ __forceinline__ void tile_prefetch(const ViewParams& v, const TileInf
   }
 }
 
+// min over the wave (NaN operands are ignored, like the `dist > s` test ignores them)
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) v = fminf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX>
 __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
                                                           const FusedView* __restrict__ views,
                                                           const float* __restrict__ c2_all,
                                                           int nviews, ModeParams mode, int nbx,
-                                                          int nby) {
-  __shared__ float4 tile_all[4][2][kTileQuads];
+                                                          int nby, int cull_enabled) {
+  __shared__ float4 tile_all[4][kTileQuads];
   __shared__ TileInfo tinfo_all[4][kMaxFusedViews];
+  // A view can be dropped for a whole wave brick when no voxel of the brick can change:
+  //   - use_truncation and every sample is provably < -1 (voxel_carver.cc:478), or
+  //   - kMax, every voxel already touched, and every sample is provably <= min(sdf) of the
+  //     brick (UpdateVoxelMax only writes when dist > sdf, voxel_carver.cc:82).
+  // "Provably": a bilinear sample is a convex combination of taps of the staged footprint, so
+  // it is bounded by the footprint's maximum M times the rounding slack of the four products
+  // and three sums (|error| < 2^-20 |M|).  ub below is that bound.
+  constexpr bool kNeedBound = TRUNC || UPDATE == VCY_UPDATE_MAX;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  float4(*tile)[kTileQuads] = tile_all[wave];
+  float4* tile = tile_all[wave];
   TileInfo* tinfo = tinfo_all[wave];
   const int lx = lane & (WX - 1), ly = lane >> 3;
   int b = blockIdx.x;
@@ -165,8 +181,10 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
   const int x = min(x_raw, g.nx - 1), y = min(y_raw, g.ny - 1);  // clones for out-of-grid lanes
   const int zl0 = bz * BZ;
   const float px = g.px[x], py = g.py[y];
+  const bool want_bound = kNeedBound && cull_enabled;
 
-  // ---- prologue: footprint rectangle of the wave brick in every view ---------------------
+  // ---- prologue: per view, 8 lanes project the 8 corners of the wave brick -> footprint
+  // rectangle, then scan the rectangle for its maximum ---------------------------------------
   for (int vbase = 0; vbase < nviews; vbase += 8) {
     const int vi = vbase + (lane >> 3), corner = lane & 7;
     if (vi < nviews) {
@@ -194,43 +212,71 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
         wmax = fmaxf(wmax, __shfl_xor(wmax, d, 64));
         bad |= __shfl_xor(bad, d, 64);
       }
-      if (corner == 0) {
-        TileInfo ti;
-        ti.lo_x = ti.lo_y = INFINITY;  // nothing passes the tile test
-        ti.hi_x = ti.hi_y = -INFINITY;
-        ti.pitchf = 0.0f;
-        ti.base = 0;
-        ti.tx0 = ti.ty0 = ti.tw = ti.nq = 0;
-        ti.magic = 0;
-        if (!bad) {
-          // one pixel of slack on each side covers the rounding of the corner projections
-          const int tx0 = max((int)floorf(umin) - 1, v.roi_min_xi);
-          const int ty0 = max((int)floorf(wmin) - 1, v.roi_min_yi);
-          const int tx1 = min((int)floorf(umax) + 1, v.roi_max_xi);
-          const int ty1 = min((int)floorf(wmax) + 1, v.roi_max_yi);
-          const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
-          if (tw > 0 && th > 0 && tw <= kTileQuads && th <= kTileQuads && tw * th <= kTileQuads) {
-            ti.tx0 = tx0;
-            ti.ty0 = ty0;
-            ti.tw = tw;
-            ti.nq = tw * th;
-            ti.magic = (65536u + (unsigned)tw - 1u) / (unsigned)tw;
-            ti.pitchf = (float)tw;
-            ti.base = -(ty0 * tw + tx0);
-            ti.lo_x = (float)tx0;
-            ti.lo_y = (float)ty0;
-            // taps exist for floor(u) in [tx0, tx1]; at the ROI edge u == roi_max is still inside
-            ti.hi_x = (tx1 == v.roi_max_xi) ? v.roi_max_x
-                                            : __uint_as_float(__float_as_uint((float)(tx1 + 1)) - 1u);
-            ti.hi_y = (ty1 == v.roi_max_yi) ? v.roi_max_y
-                                            : __uint_as_float(__float_as_uint((float)(ty1 + 1)) - 1u);
+      TileInfo ti;
+      ti.lo_x = ti.lo_y = INFINITY;  // nothing passes the tile test
+      ti.hi_x = ti.hi_y = -INFINITY;
+      ti.pitchf = 0.0f;
+      ti.base = 0;
+      ti.tx0 = ti.ty0 = ti.tw = ti.nq = 0;
+      ti.magic = 0;
+      ti.ub = INFINITY;  // never dropped
+      if (!bad) {
+        // one pixel of slack on each side covers the rounding of the corner projections
+        const int tx0 = max((int)floorf(umin) - 1, v.roi_min_xi);
+        const int ty0 = max((int)floorf(wmin) - 1, v.roi_min_yi);
+        const int tx1 = min((int)floorf(umax) + 1, v.roi_max_xi);
+        const int ty1 = min((int)floorf(wmax) + 1, v.roi_max_yi);
+        const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
+        if (tw > 0 && th > 0 && tw <= kTileQuads && th <= kTileQuads && tw * th <= kTileQuads) {
+          ti.tx0 = tx0;
+          ti.ty0 = ty0;
+          ti.tw = tw;
+          ti.nq = tw * th;
+          ti.magic = (65536u + (unsigned)tw - 1u) / (unsigned)tw;
+          ti.pitchf = (float)tw;
+          ti.base = -(ty0 * tw + tx0);
+          ti.lo_x = (float)tx0;
+          ti.lo_y = (float)ty0;
+          // taps exist for floor(u) in [tx0, tx1]; at the ROI edge u == roi_max is still inside
+          ti.hi_x = (tx1 == v.roi_max_xi) ? v.roi_max_x
+                                          : __uint_as_float(__float_as_uint((float)(tx1 + 1)) - 1u);
+          ti.hi_y = (ty1 == v.roi_max_yi) ? v.roi_max_y
+                                          : __uint_as_float(__float_as_uint((float)(ty1 + 1)) - 1u);
+          if (want_bound) {
+            // maximum over every pixel a tap of this tile can read
+            const int pw = min(tx1 + 1, v.roi_max_xi) - tx0 + 1;
+            const int ph = min(ty1 + 1, v.roi_max_yi) - ty0 + 1;
+            const int npx = pw * ph;  // <= 258
+            const unsigned pmagic = (65536u + (unsigned)pw - 1u) / (unsigned)pw;
+            gfloat_ptr img = (gfloat_ptr)v.sdf;
+            float m = -INFINITY;
+            int has_nan = 0;
+            for (int p = corner; p < npx; p += 8) {
+              const int j = (int)(((unsigned)p * pmagic) >> 16), i = p - j * pw;
+              const float t = img[(int64_t)v.width * (ty0 + j) + (tx0 + i)];
+              has_nan |= (t != t);
+              m = fmaxf(m, t);
+            }
+#pragma unroll
+            for (int d = 1; d < 8; d <<= 1) {
+              m = fmaxf(m, __shfl_xor(m, d, 64));
+              has_nan |= __shfl_xor(has_nan, d, 64);
+            }
+            // voxels projecting outside the ROI sample max_sdf instead (voxel_carver.cc:469-471)
+            if (mode.outside == VCY_OUTSIDE_MAX) {
+              has_nan |= (v.max_sdf != v.max_sdf);
+              m = fmaxf(m, v.max_sdf);
+            }
+            ti.ub = has_nan ? INFINITY : (__builtin_fmaf(fabsf(m), 0x1p-20f, m) + 1.0e-30f);
           }
         }
-        tinfo[vi] = ti;
       }
+      if (corner == 0) tinfo[vi] = ti;
     }
   }
   wave_lds_fence();
+  const float ub_lane = (lane < nviews) ? tinfo[min(lane, kMaxFusedViews - 1)].ub : INFINITY;
+  const unsigned long long view_mask = (nviews >= 64) ? ~0ull : ((1ull << nviews) - 1ull);
 
   // ---- load the wave brick's state ----------------------------------------------------------
   CountT* __restrict__ cnt = (CountT*)g.cnt;
@@ -245,20 +291,48 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
     n[k] = (int)cnt[(int64_t)zl * slice + col];
   }
 
-  // tile of view 0
+  // views that may still change something, as a wave-uniform bit mask
+  auto live_views = [&]() -> unsigned long long {
+    bool drop = false;
+    if (want_bound) {
+      if (TRUNC) drop = ub_lane < -1.0f;
+      if (UPDATE == VCY_UPDATE_MAX) {
+        float m = s[0];
+        int nmin = n[0];
+#pragma unroll
+        for (int k = 1; k < BZ; ++k) {
+          m = fminf(m, s[k]);
+          nmin = min(nmin, n[k]);
+        }
+        const float smin = wave_min(m);
+        const bool touched = __all(nmin >= 1);
+        drop = drop || (touched && ub_lane <= smin);
+      }
+    }
+    return __ballot(!drop) & view_mask;
+  };
+  auto next_view = [&](unsigned long long live, int after) -> int {
+    const unsigned long long rest = (after >= 63) ? 0ull : (live & ~((2ull << after) - 1ull));
+    return rest ? (__ffsll((long long)rest) - 1) : nviews;
+  };
+
+  unsigned long long live = live_views();
+  int vi = live ? (__ffsll((long long)live) - 1) : nviews;
   QuadRegs pre;
-  tile_prefetch(views[0].v, tinfo[0], lane, &pre);
-  tile[0][lane] = pre.q0;
-  tile[0][lane + 64] = pre.q1;
-  wave_lds_fence();
+  if (vi < nviews) tile_prefetch(views[vi].v, tinfo[vi], lane, &pre);
 
   // ---- views ------------------------------------------------------------------------------
-  for (int vi = 0; vi < nviews; ++vi) {
+  while (vi < nviews) {
     const ViewParams& v = views[vi].v;
     cfloat_ptr c2 = (cfloat_ptr)(c2_all + (size_t)vi * 3 * g.nz_local);
-    const int buf = vi & 1;
-    // loads of the next view's tile fly while this view is computed
-    if (vi + 1 < nviews) tile_prefetch(views[vi + 1].v, tinfo[vi + 1], lane, &pre);
+    // stage this view's tile (wave-private: program order is enough)
+    wave_lds_fence();
+    tile[lane] = pre.q0;
+    tile[lane + 64] = pre.q1;
+    wave_lds_fence();
+    // the next live view's tile is fetched while this one is computed
+    int vnext = next_view(live, vi);
+    if (vnext < nviews) tile_prefetch(views[vnext].v, tinfo[vnext], lane, &pre);
 
     const float lo_x = tinfo[vi].lo_x, hi_x = tinfo[vi].hi_x;
     const float lo_y = tinfo[vi].lo_y, hi_y = tinfo[vi].hi_y;
@@ -270,7 +344,8 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
     // Straight-line fast path for the 8 voxels of this thread (no divergent control flow, so
     // the eight LDS reads and the arithmetic interleave); voxels the tile does not cover are
     // only recorded here and handled below.
-    unsigned slow = 0;
+    bool slow[BZ];
+    bool any_slow = false;
 #pragma unroll
     for (int k = 0; k < BZ; ++k) {
       const int zl = min(zl0 + k, g.nz_local - 1);
@@ -283,13 +358,14 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
       const float u = qx * pcx + v.cx;
       const float w = qy * pcy + v.cy;
       const bool in_tile = zfast && u >= lo_x && u <= hi_x && w >= lo_y && w <= hi_y;
-      slow |= (in_tile ? 0u : 1u) << k;
+      slow[k] = !in_tile;
+      any_slow = any_slow || !in_tile;
       const float fu = floorf(u), fw = floorf(w);
       const float lu = u - fu, lv = w - fw;
       // any index is harmless when !in_tile (the sample is discarded); keep it inside the tile
       const unsigned idx = min((unsigned)((int)__builtin_fmaf(fw, pitchf, fu) + base),
                                (unsigned)(kTileQuads - 1));
-      const float4 q = tile[buf][idx];
+      const float4 q = tile[idx];
       const float a = (1.0f - lu) * (1.0f - lv) * q.x;
       const float bb = lu * (1.0f - lv) * q.y;
       const float cc = (1.0f - lu) * lv * q.z;
@@ -300,10 +376,10 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
       if (CHECKMAX) ok = ok && !(n[k] > g.max_update_num);
       apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]);
     }
-    if (slow) {
+    if (any_slow) {
 #pragma unroll
       for (int k = 0; k < BZ; ++k) {
-        if ((slow >> k) & 1u) {
+        if (slow[k]) {
           const int zl = min(zl0 + k, g.nz_local - 1);
           float dist = 0.0f;
           bool ok = sample_generic(&v, mode, px, py, g.pz[g.z0 + zl], &dist);
@@ -312,13 +388,17 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
         }
       }
     }
-    // the next view's tile goes into the other buffer (its last readers finished a view ago)
-    if (vi + 1 < nviews) {
-      wave_lds_fence();
-      tile[buf ^ 1][lane] = pre.q0;
-      tile[buf ^ 1][lane + 64] = pre.q1;
-      wave_lds_fence();
+
+    // state moved: some of the remaining views may have become droppable (min(sdf) only grows)
+    if (want_bound && UPDATE == VCY_UPDATE_MAX) {
+      live = live_views();
+      const int v2 = next_view(live, vi);
+      if (v2 != vnext) {
+        vnext = v2;
+        if (vnext < nviews) tile_prefetch(views[vnext].v, tinfo[vnext], lane, &pre);
+      }
     }
+    vi = vnext;
   }
 
   // ---- write back what changed (update_num grows with every change) ----------------------------
@@ -338,34 +418,34 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
 
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF>
 void launch_fused_4(bool checkmax, dim3 grid, hipStream_t s, const GridParams& g, const FusedView* dv,
-                    const float* c2, int nv, const ModeParams& m, int nbx, int nby) {
+                    const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull) {
   if (checkmax)
     hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, true>), grid, dim3(256), 0, s, g,
-                       dv, c2, nv, m, nbx, nby);
+                       dv, c2, nv, m, nbx, nby, cull);
   else
     hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, false>), grid, dim3(256), 0, s, g,
-                       dv, c2, nv, m, nbx, nby);
+                       dv, c2, nv, m, nbx, nby, cull);
 }
 
 template <typename CountT, int UPDATE>
 void launch_fused_2(bool trunc, bool samef, bool checkmax, dim3 grid, hipStream_t s, const GridParams& g,
-                    const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby) {
+                    const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull) {
   if (trunc) {
-    if (samef) launch_fused_4<CountT, UPDATE, true, true>(checkmax, grid, s, g, dv, c2, nv, m, nbx, nby);
-    else launch_fused_4<CountT, UPDATE, true, false>(checkmax, grid, s, g, dv, c2, nv, m, nbx, nby);
+    if (samef) launch_fused_4<CountT, UPDATE, true, true>(checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
+    else launch_fused_4<CountT, UPDATE, true, false>(checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
   } else {
-    if (samef) launch_fused_4<CountT, UPDATE, false, true>(checkmax, grid, s, g, dv, c2, nv, m, nbx, nby);
-    else launch_fused_4<CountT, UPDATE, false, false>(checkmax, grid, s, g, dv, c2, nv, m, nbx, nby);
+    if (samef) launch_fused_4<CountT, UPDATE, false, true>(checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
+    else launch_fused_4<CountT, UPDATE, false, false>(checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
   }
 }
 
 template <typename CountT>
 void launch_fused_1(int update, bool trunc, bool samef, bool checkmax, dim3 grid, hipStream_t s,
-                    const GridParams& g, const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby) {
+                    const GridParams& g, const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull) {
   if (update == VCY_UPDATE_MAX)
-    launch_fused_2<CountT, VCY_UPDATE_MAX>(trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby);
+    launch_fused_2<CountT, VCY_UPDATE_MAX>(trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
   else
-    launch_fused_2<CountT, VCY_UPDATE_WEIGHTED_AVERAGE>(trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby);
+    launch_fused_2<CountT, VCY_UPDATE_WEIGHTED_AVERAGE>(trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
 }
 
 bool sane(float f) { return f >= 0x1p-40f && f <= 0x1p40f; }
@@ -434,10 +514,10 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   const dim3 grid((unsigned)nblocks);
   if (c->cnt_bytes == 1)
     launch_fused_1<uint8_t>(u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, g, d_views,
-                            d_c2, n_views, m, nbx, nby);
+                            d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0);
   else
     launch_fused_1<uint16_t>(u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, g, d_views,
-                             d_c2, n_views, m, nbx, nby);
+                             d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0);
   VCY_HIP_CHECK(hipGetLastError());
   return VCY_OK;
 }

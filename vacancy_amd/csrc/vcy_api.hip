@@ -250,6 +250,10 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
     c->use_fused = value != 0;
     return VCY_OK;
   }
+  if (std::strcmp(name, "cull") == 0) {
+    c->use_cull = value != 0;
+    return VCY_OK;
+  }
   set_error("unknown parameter %s", name);
   return VCY_ERR_INVALID_ARG;
 }

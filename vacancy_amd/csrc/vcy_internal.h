@@ -59,6 +59,7 @@ struct vcy_ctx {
   float* d_py = nullptr;
   float* d_pz = nullptr;
 
+  bool use_cull = true;               // vcy_set_param("cull", 0): never drop provably idle views
   bool use_fused = true;              // vcy_set_option("fused", 0) forces the per-view kernel
   float* h_pz = nullptr;              // host copy of d_pz (per-view z tables of the fused carve)
   void* d_fused_scratch = nullptr;    // view blocks + z tables of the fused carve kernel
