@@ -1,0 +1,88 @@
+// The reference's demo (examples.cc:75-152) on the MI355X path: 6 masks + TUM poses of data/
+// bunny, 10 mm voxels; per view carve -> marching cubes (interpolated and not), PLY out.
+// Usage: bunny <data_dir> <out_dir> [resolution]
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "vacancy/voxel_carver.h"
+
+// TUM trajectory line: id tx ty tz qx qy qz qw -> pose = Translation * Quaternion (examples.cc:36-50)
+static bool LoadTumPoses(const std::string& path, std::vector<Eigen::Affine3d>* poses) {
+  std::ifstream in(path);
+  std::string line;
+  while (std::getline(in, line)) {
+    std::istringstream ss(line);
+    std::vector<std::string> tok;
+    for (std::string t; std::getline(ss, t, ' ');) tok.push_back(t);
+    if (tok.size() != 8) {
+      vacancy::LOGE("wrong tum format\n");
+      return false;
+    }
+    Eigen::Translation3d t;
+    t.x() = std::atof(tok[1].c_str());
+    t.y() = std::atof(tok[2].c_str());
+    t.z() = std::atof(tok[3].c_str());
+    Eigen::Quaterniond q;
+    q.x() = std::atof(tok[4].c_str());
+    q.y() = std::atof(tok[5].c_str());
+    q.z() = std::atof(tok[6].c_str());
+    q.w() = std::atof(tok[7].c_str());
+    poses->push_back(t * q);
+  }
+  return !poses->empty();
+}
+
+int main(int argc, char* argv[]) {
+  const std::string data_dir = argc > 1 ? argv[1] : "../data/";
+  const std::string out_dir = argc > 2 ? argv[2] : data_dir;
+  const float resolution = argc > 3 ? (float)std::atof(argv[3]) : 10.0f;
+  std::vector<Eigen::Affine3d> poses;
+  if (!LoadTumPoses(data_dir + "/tumpose.txt", &poses)) return 1;
+
+  vacancy::VoxelCarverOption option;
+  option.bb_min = Eigen::Vector3f(-250.000000f, -344.586151f, -129.982697f);
+  option.bb_max = Eigen::Vector3f(250.000000f, 150.542343f, 257.329224f);
+  const float bb_offset = 20.0f;  // keep the boundary clean
+  for (int i = 0; i < 3; ++i) {
+    option.bb_min[i] -= bb_offset;
+    option.bb_max[i] += bb_offset;
+  }
+  option.resolution = resolution;
+  vacancy::VoxelCarver carver(option);
+  if (!carver.Init()) return 2;
+
+  const int width = 320, height = 240;
+  std::shared_ptr<vacancy::Camera> camera = std::make_shared<vacancy::PinholeCamera>(
+      width, height, Eigen::Affine3d::Identity(), Eigen::Vector2f(159.3f, 127.65f), Eigen::Vector2f(258.65f, 258.25f));
+
+  for (size_t i = 0; i < 6 && i < poses.size(); ++i) {
+    camera->set_c2w(poses[i]);
+    const std::string num = vacancy::zfill(i);
+    vacancy::Image1b silhouette;
+    if (!silhouette.Load(data_dir + "/mask_" + num + ".png")) return 3;
+    vacancy::Image1f sdf;
+    if (!carver.Carve(*camera, silhouette, &sdf)) return 4;
+    vacancy::Image3b vis;
+    vacancy::SignedDistance2Color(sdf, &vis, -1.0f, 1.0f);
+    vis.WritePng(out_dir + "/sdf_" + num + ".png");
+
+    vacancy::Mesh mesh;
+    carver.ExtractIsoSurface(&mesh, 0.0);
+    mesh.WritePly(out_dir + "/surface_" + num + ".ply");
+    const size_t nv = mesh.vertices().size(), nf = mesh.vertex_indices().size();
+    double sum[3] = {0, 0, 0};
+    for (const auto& v : mesh.vertices())
+      for (int k = 0; k < 3; ++k) sum[k] += v[k];
+    carver.ExtractIsoSurface(&mesh, 0.0, false);
+    mesh.WritePly(out_dir + "/surface_nointerp_" + num + ".ply");
+    std::printf("RESULT view %zu verts %zu faces %zu nointerp_verts %zu nointerp_faces %zu vsum %.6f %.6f %.6f\n", i,
+                nv, nf, mesh.vertices().size(), mesh.vertex_indices().size(), sum[0], sum[1], sum[2]);
+  }
+  return 0;
+}

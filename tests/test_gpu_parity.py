@@ -259,3 +259,28 @@ def test_degenerate_grids_and_errors():
     # Carve before Init (reference: UB; here: false)
     c = vc.VoxelCarver(B.bunny_option())
     assert not c.Carve(vc.make_view(np.eye(3, 4, dtype=np.float32), 1, 1, 0, 0, 4, 4), np.zeros((4, 4), np.float32))
+
+
+def test_cpp_bunny_example(tmp_path):
+    """configs[0] end to end through the C++ facade: examples/bunny.cc (the reference's
+    examples.cc sequence) must print the reference's mesh sizes."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "vacancy_amd", "host"), "-s"], check=True)
+    out = subprocess.run([os.path.join(root, "vacancy_amd", "host", "bunny"), B.BUNNY, str(tmp_path)],
+                         check=True, capture_output=True, text=True).stdout
+    gold = json.load(open(os.path.join(root, "tests", "golden", "appendix_c.json")))
+    rows = [l.split() for l in out.splitlines() if l.startswith("RESULT")]
+    assert len(rows) == 6
+    for i, r in enumerate(rows):
+        exp = gold["modes"]["default"][i]
+        assert (int(r[4]), int(r[6])) == (exp[5], exp[6]), (i, r)
+    assert (int(rows[5][8]), int(rows[5][10])) == tuple(gold["final_nointerp"])
+    vsum = [float(x) for x in rows[5][12:15]]
+    assert np.allclose(vsum, gold["final_vertex_sums"], rtol=0, atol=1e-4)
+    # ASCII PLY in the reference's format
+    ply = open(os.path.join(str(tmp_path), "surface_00005.ply")).read().splitlines()
+    assert ply[0] == "ply" and ply[2] == "element vertex 8672" and "element face 17270" in ply
+    assert ply[ply.index("end_header") + 1].endswith(" ") and ply[-1].startswith("3 ")

@@ -96,3 +96,30 @@ def test_mc_case_table_integrity():
         assert cut == used, c  # edge table == edges used by the case's triangles
         edge_sum += cut
     assert edge_sum == gold["edge_sum"]
+
+
+def _build_host():
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(ROOT, "vacancy_amd", "host"), "-s"], check=True)
+
+
+def test_cpp_facade_host_utilities():
+    """The C++ facade (include/vacancy/*.h + vacancy_amd/host) builds; its PNG decoder reads the
+    reference's masks exactly and its camera arithmetic reproduces the reference's w2c."""
+    import subprocess
+    _build_host()
+    out = subprocess.run([os.path.join(ROOT, "vacancy_amd", "host", "host_selftest"), B.BUNNY],
+                         check=True, capture_output=True, text=True).stdout.splitlines()
+    masks = B.load_masks()
+    rows = [l.split() for l in out if l.startswith("MASK")]
+    assert len(rows) == 6
+    for i, r in enumerate(rows):
+        assert (int(r[2]), int(r[3])) == (320, 240)
+        assert int(r[4]) == int(masks[i].astype(np.int64).sum())
+    w2c = np.array([float(x) for x in [l for l in out if l.startswith("W2C")][0].split()[1:]], np.float32)
+    ref = GOLD["w2c_f32"]["2"]
+    got = w2c.reshape(3, 4)
+    assert np.array_equal(got[:, :3].reshape(-1), np.array(ref["R"], np.float32))
+    assert np.array_equal(got[:, 3], np.array(ref["t"], np.float32))
+    focal = [np.float32(x) for x in [l for l in out if l.startswith("FOCAL")][0].split()[1:]]
+    assert focal[0] == synth.focal_from_fov_y(720, 60.0) and focal[1] == np.float32(639.5)

@@ -1,0 +1,238 @@
+// vacancy::VoxelCarver facade: the reference's class API (src/vacancy/voxel_carver.cc:367-543)
+// forwarding to the HIP path through the C-ABI of include/vacancy_hip.h.
+#include "vacancy/voxel_carver.h"
+
+#include <chrono>
+#include <cstring>
+#include <limits>
+
+#include "vacancy_hip.h"
+
+namespace vacancy {
+
+const float InvalidSdf::kVal = std::numeric_limits<float>::lowest();
+
+namespace {
+double NowMs() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+vcy_view ToView(const Camera& camera, const Eigen::Vector2i& roi_min, const Eigen::Vector2i& roi_max, int width,
+                int height) {
+  vcy_view v;
+  std::memset(&v, 0, sizeof(v));
+  const Eigen::Affine3f w2c = camera.w2c().cast<float>();  // reference voxel_carver.cc:438
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) v.w2c[4 * i + j] = w2c.linear()(i, j);
+    v.w2c[4 * i + 3] = w2c.translation()[i];
+  }
+  if (const PinholeCamera* p = dynamic_cast<const PinholeCamera*>(&camera)) {
+    v.fx = p->focal_length()[0];
+    v.fy = p->focal_length()[1];
+    v.cx = p->principal_point()[0];
+    v.cy = p->principal_point()[1];
+  }
+  v.is_ortho = camera.is_orthographic() ? 1 : 0;
+  v.roi_min[0] = roi_min[0];
+  v.roi_min[1] = roi_min[1];
+  v.roi_max[0] = roi_max[0];
+  v.roi_max[1] = roi_max[1];
+  v.width = width;
+  v.height = height;
+  return v;
+}
+}  // namespace
+
+struct VoxelCarver::Impl {
+  VoxelCarverOption option;
+  vcy_ctx* ctx = nullptr;
+  int device = 0;
+  ~Impl() { vcy_destroy(ctx); }
+};
+
+VoxelCarver::VoxelCarver() : impl_(new Impl) {}
+VoxelCarver::VoxelCarver(VoxelCarverOption option) : impl_(new Impl) { set_option(option); }
+VoxelCarver::~VoxelCarver() {}
+
+void VoxelCarver::set_option(VoxelCarverOption option) { impl_->option = option; }
+void VoxelCarver::set_device(int device_id) { impl_->device = device_id; }
+
+bool VoxelCarver::Init() {
+  vcy_destroy(impl_->ctx);
+  impl_->ctx = nullptr;
+  const VoxelCarverOption& o = impl_->option;
+  vcy_carver_option c;
+  std::memset(&c, 0, sizeof(c));
+  for (int i = 0; i < 3; ++i) {
+    c.bb_max[i] = o.bb_max[i];
+    c.bb_min[i] = o.bb_min[i];
+  }
+  c.resolution = o.resolution;
+  c.sdf_minmax_normalize = o.sdf_minmax_normalize ? 1 : 0;
+  c.update_option.voxel_update = static_cast<int>(o.update_option.voxel_update);
+  c.update_option.sdf_interp = static_cast<int>(o.update_option.sdf_interp);
+  c.update_option.update_outside = static_cast<int>(o.update_option.update_outside);
+  c.update_option.voxel_max_update_num = o.update_option.voxel_max_update_num;
+  c.update_option.voxel_update_weight = o.update_option.voxel_update_weight;
+  c.update_option.use_truncation = o.update_option.use_truncation ? 1 : 0;
+  c.update_option.truncation_band = o.update_option.truncation_band;
+  if (vcy_create(&c, impl_->device, 0, -1, &impl_->ctx) != VCY_OK) {
+    LOGE("%s\n", vcy_last_error());
+    return false;
+  }
+  return true;
+}
+
+bool VoxelCarver::Carve(const Camera& camera, const Image1b& silhouette, const Eigen::Vector2i& roi_min,
+                        const Eigen::Vector2i& roi_max, Image1f* sdf) {
+  if (!impl_->ctx) {
+    LOGE("VoxelCarver::Carve voxel grid has not been initialized\n");
+    return false;
+  }
+  sdf->Init(silhouette.width(), silhouette.height(), 0.0f);
+  const vcy_view v = ToView(camera, roi_min, roi_max, silhouette.width(), silhouette.height());
+  const double t0 = NowMs();
+  const int rc = vcy_carve_silhouette(impl_->ctx, &v, silhouette.data().data(), sdf->data_ptr()->data());
+  if (rc == VCY_OK) vcy_sync(impl_->ctx);
+  LOGI("VoxelCarver::Carve make SDF + main loop %02f\n", NowMs() - t0);
+  if (rc != VCY_OK) LOGE("%s\n", vcy_last_error());
+  return rc == VCY_OK;
+}
+
+bool VoxelCarver::Carve(const Camera& camera, const Eigen::Vector2i& roi_min, const Eigen::Vector2i& roi_max,
+                        const Image1f& sdf) {
+  if (!impl_->ctx) {
+    LOGE("VoxelCarver::Carve voxel grid has not been initialized\n");
+    return false;
+  }
+  const vcy_view v = ToView(camera, roi_min, roi_max, sdf.width(), sdf.height());
+  const double t0 = NowMs();
+  const int rc = vcy_carve(impl_->ctx, &v, sdf.data().data());
+  if (rc == VCY_OK) vcy_sync(impl_->ctx);
+  LOGI("VoxelCarver::Carve main loop %02f\n", NowMs() - t0);
+  if (rc != VCY_OK) LOGE("%s\n", vcy_last_error());
+  return rc == VCY_OK;
+}
+
+bool VoxelCarver::Carve(const Camera& camera, const Image1b& silhouette, Image1f* sdf) {
+  return Carve(camera, silhouette, Eigen::Vector2i(0, 0),
+               Eigen::Vector2i(silhouette.width() - 1, silhouette.height() - 1), sdf);
+}
+
+bool VoxelCarver::Carve(const Camera& camera, const Image1b& silhouette) {
+  Image1f sdf(camera.width(), camera.height());
+  return Carve(camera, silhouette, &sdf);
+}
+
+bool VoxelCarver::Carve(const Camera& camera, const Image1f& sdf) {
+  return Carve(camera, Eigen::Vector2i(0, 0), Eigen::Vector2i(sdf.width() - 1, sdf.height() - 1), sdf);
+}
+
+bool VoxelCarver::Carve(const std::vector<const Camera*>& cameras, const std::vector<Image1b>& silhouettes) {
+  if (!impl_->ctx || cameras.size() != silhouettes.size()) return false;
+  const VoxelCarverOption& o = impl_->option;
+  const int n = static_cast<int>(cameras.size());
+  std::vector<vcy_view> views(n);
+  std::vector<float*> dev(n, nullptr);
+  bool ok = true;
+  for (int i = 0; i < n && ok; ++i) {
+    const Image1b& s = silhouettes[i];
+    const int32_t rmin[2] = {0, 0}, rmax[2] = {s.width() - 1, s.height() - 1};
+    views[i] = ToView(*cameras[i], Eigen::Vector2i(0, 0), Eigen::Vector2i(rmax[0], rmax[1]), s.width(), s.height());
+    std::vector<float> sdf(static_cast<size_t>(s.width()) * s.height());
+    ok = vcy_make_sdf(s.data().data(), s.width(), s.height(), rmin, rmax, o.sdf_minmax_normalize,
+                      o.update_option.use_truncation, o.update_option.truncation_band, sdf.data()) == VCY_OK &&
+         vcy_sdf_upload(impl_->ctx, sdf.data(), s.width(), s.height(), &dev[i]) == VCY_OK;
+  }
+  if (ok) ok = vcy_carve_batch_device(impl_->ctx, n, views.data(), dev.data()) == VCY_OK;
+  if (!ok) LOGE("%s\n", vcy_last_error());
+  for (float* p : dev)
+    if (p) vcy_device_free(impl_->ctx, p);
+  return ok;
+}
+
+void VoxelCarver::ExtractIsoSurface(Mesh* mesh, double iso_level, bool linear_interp) {
+  mesh->Clear();
+  if (!impl_->ctx) return;
+  const double t0 = NowMs();
+  vcy_mesh m;
+  if (vcy_extract_iso(impl_->ctx, iso_level, linear_interp ? 1 : 0, &m) != VCY_OK) {
+    LOGE("%s\n", vcy_last_error());
+    vcy_mesh_free(&m);
+    return;
+  }
+  static_assert(sizeof(Eigen::Vector3f) == 3 * sizeof(float), "packed vector layout");
+  static_assert(sizeof(Eigen::Vector3i) == 3 * sizeof(int), "packed vector layout");
+  std::vector<Eigen::Vector3f>* v = mesh->mutable_vertices();
+  std::vector<Eigen::Vector3i>* f = mesh->mutable_vertex_indices();
+  v->resize(static_cast<size_t>(m.n_vertices));
+  f->resize(static_cast<size_t>(m.n_faces));
+  if (m.n_vertices) std::memcpy(static_cast<void*>(v->data()), m.vertices, sizeof(float) * 3 * m.n_vertices);
+  if (m.n_faces) std::memcpy(static_cast<void*>(f->data()), m.faces, sizeof(int) * 3 * m.n_faces);
+  vcy_mesh_free(&m);
+  LOGI("MarchingCubes %02f\n", NowMs() - t0);
+}
+
+void VoxelCarver::ExtractVoxel(Mesh* mesh, bool inside_empty) {
+  (void)inside_empty;
+  // The cube-per-voxel visualisation mesh (reference extract_voxel.cc) is a host-side consumer
+  // of the grid state and not part of the accelerated path yet.
+  mesh->Clear();
+  LOGW("VoxelCarver::ExtractVoxel is not available in this build; use Download() for the voxel state\n");
+}
+
+Eigen::Vector3i VoxelCarver::voxel_num() const {
+  int32_t d[3] = {0, 0, 0};
+  if (impl_->ctx) vcy_grid_dims(impl_->ctx, d);
+  return Eigen::Vector3i(d[0], d[1], d[2]);
+}
+
+bool VoxelCarver::Download(std::vector<float>* sdf, std::vector<int>* update_num) const {
+  if (!impl_->ctx) return false;
+  const Eigen::Vector3i n = voxel_num();
+  const size_t total = static_cast<size_t>(n[0]) * n[1] * n[2];
+  if (sdf) sdf->resize(total);
+  if (update_num) update_num->resize(total);
+  return vcy_download(impl_->ctx, sdf ? sdf->data() : nullptr, update_num ? update_num->data() : nullptr) == VCY_OK;
+}
+
+void DistanceTransformL1(const Image1b& mask, const Eigen::Vector2i& roi_min, const Eigen::Vector2i& roi_max,
+                         Image1f* dist) {
+  dist->Init(mask.width(), mask.height(), 0.0f);
+  const int32_t rmin[2] = {roi_min[0], roi_min[1]}, rmax[2] = {roi_max[0], roi_max[1]};
+  if (vcy_distance_transform_l1(mask.data().data(), mask.width(), mask.height(), rmin, rmax,
+                                dist->data_ptr()->data()) != VCY_OK)
+    LOGE("%s\n", vcy_last_error());
+}
+
+void MakeSignedDistanceField(const Image1b& mask, const Eigen::Vector2i& roi_min, const Eigen::Vector2i& roi_max,
+                             Image1f* dist, bool minmax_normalize, bool use_truncation, float truncation_band) {
+  dist->Init(mask.width(), mask.height(), 0.0f);
+  const int32_t rmin[2] = {roi_min[0], roi_min[1]}, rmax[2] = {roi_max[0], roi_max[1]};
+  if (vcy_make_sdf(mask.data().data(), mask.width(), mask.height(), rmin, rmax, minmax_normalize, use_truncation,
+                   truncation_band, dist->data_ptr()->data()) != VCY_OK)
+    LOGE("%s\n", vcy_last_error());
+}
+
+// blue inside, red outside, white at the silhouette (reference voxel_carver.cc:239-267)
+void SignedDistance2Color(const Image1f& sdf, Image3b* vis, float min_negative_d, float max_positive_d) {
+  vis->Init(sdf.width(), sdf.height());
+  for (int y = 0; y < sdf.height(); ++y)
+    for (int x = 0; x < sdf.width(); ++x) {
+      const float d = sdf.at(x, y, 0);
+      uint8_t* px = vis->at(x, y);
+      if (d > 0) {
+        float k = (max_positive_d - d) / max_positive_d;
+        k = std::min(std::max(k, 0.0f), 1.0f);
+        px[0] = 255;
+        px[1] = px[2] = static_cast<uint8_t>(255 * k);
+      } else {
+        float k = (d - min_negative_d) / (-min_negative_d);
+        k = std::min(std::max(k, 0.0f), 1.0f);
+        px[0] = px[1] = static_cast<uint8_t>(255 * k);
+        px[2] = 255;
+      }
+    }
+}
+
+}  // namespace vacancy
