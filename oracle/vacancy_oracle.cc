@@ -430,20 +430,29 @@ void vertex_interp(double iso, const Voxel& a, const Voxel& b, float* p, bool li
 
 }  // namespace
 
-double orc_marching_cubes(const orc_grid* g, double iso, int linear_interp, vcy_mesh* out) {
+// z_begin/z_end select the cell layers [max(z_begin,1), z_end) (a cell is named by its max
+// corner).  The whole grid is (0, nz): exactly the reference loop.  For a slab with z_begin > 0
+// the layer below it (z_begin-1) is walked first without emitting faces, which is what a rank
+// of the multi-GPU path knows from its two halo slices: the vertices it creates on the shared
+// plane (both key voxels in slice z_begin-1) are reported first as n_foreign_vertices.
+static double marching_cubes_range(const orc_grid* g, double iso, int linear_interp, int z_begin,
+                                   int z_end, vcy_mesh* out) {
   const double t0 = now_ms();
   const McTables& T = tables();
   std::vector<std::array<float, 3>> vertices;
   std::vector<std::array<int, 3>> faces;
   std::vector<std::pair<int, int>> keys;
   std::map<std::pair<int, int>, int> ids2vertex;  // :78
-  const int nx = g->n[0], ny = g->n[1], nz = g->n[2];
+  const int nx = g->n[0], ny = g->n[1];
   // corner pairs (interp order) and key order per edge, marching_cubes.cc:138-197
   static const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3};
   static const int eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
   static const int ka[12] = {0, 1, 3, 0, 4, 5, 7, 4, 0, 1, 2, 3};
   static const int kb[12] = {1, 2, 2, 3, 5, 6, 6, 7, 4, 5, 6, 7};
-  for (int z = 1; z < nz; z++) {
+  const int z_own = std::max(z_begin, 1);
+  const int z_first = (z_begin > 1) ? z_begin - 1 : z_own;  // ghost layer
+  for (int z = z_first; z < z_end; z++) {
+    const bool ghost = z < z_own;
     for (int y = 1; y < ny; y++) {
       for (int x = 1; x < nx; x++) {
         if (g->get(x, y, z).update_num < 1) continue;  // :88-90
@@ -485,24 +494,54 @@ double orc_marching_cubes(const orc_grid* g, double iso, int linear_interp, vcy_
               face[j] = it->second;
             }
           }
-          faces.push_back(face);
+          if (!ghost) faces.push_back(face);
         }
       }
     }
   }
-  out->n_vertices = (int64_t)vertices.size();
-  out->n_faces = (int64_t)faces.size();
-  out->vertices = (float*)std::malloc(sizeof(float) * 3 * std::max<size_t>(1, vertices.size()));
-  out->faces = (int32_t*)std::malloc(sizeof(int32_t) * 3 * std::max<size_t>(1, faces.size()));
-  out->edge_keys = (int64_t*)std::malloc(sizeof(int64_t) * 2 * std::max<size_t>(1, vertices.size()));
+  // drop the ghost-layer vertices that are not on the shared plane (they touch slice
+  // z_begin-2 and no cell of the slab refers to them) and renumber
+  std::vector<int> remap(vertices.size(), -1);
+  std::vector<size_t> keep;
+  const long long lo = (z_begin > 1) ? (long long)(z_begin - 1) * g->xy : 0;
   for (size_t i = 0; i < vertices.size(); ++i) {
-    for (int k = 0; k < 3; ++k) out->vertices[3 * i + k] = vertices[i][k];
-    out->edge_keys[2 * i] = keys[i].first;
-    out->edge_keys[2 * i + 1] = keys[i].second;
+    if (keys[i].first < lo) continue;
+    remap[i] = (int)keep.size();
+    keep.push_back(i);
+  }
+  out->n_vertices = (int64_t)keep.size();
+  out->n_faces = (int64_t)faces.size();
+  out->vertices = (float*)std::malloc(sizeof(float) * 3 * std::max<size_t>(1, keep.size()));
+  out->faces = (int32_t*)std::malloc(sizeof(int32_t) * 3 * std::max<size_t>(1, faces.size()));
+  out->edge_keys = (int64_t*)std::malloc(sizeof(int64_t) * 2 * std::max<size_t>(1, keep.size()));
+  for (size_t k = 0; k < keep.size(); ++k) {
+    const size_t i = keep[k];
+    for (int c = 0; c < 3; ++c) out->vertices[3 * k + c] = vertices[i][c];
+    out->edge_keys[2 * k] = keys[i].first;
+    out->edge_keys[2 * k + 1] = keys[i].second;
   }
   for (size_t i = 0; i < faces.size(); ++i)
-    for (int k = 0; k < 3; ++k) out->faces[3 * i + k] = faces[i][k];
+    for (int c = 0; c < 3; ++c) out->faces[3 * i + c] = remap[faces[i][c]];
+  out->n_foreign_vertices = 0;
   return now_ms() - t0;
+}
+
+double orc_marching_cubes(const orc_grid* g, double iso, int linear_interp, vcy_mesh* out) {
+  return marching_cubes_range(g, iso, linear_interp, 0, g->n[2], out);
+}
+
+double orc_marching_cubes_slab(const orc_grid* g, double iso, int linear_interp, int z_begin, int z_end,
+                               vcy_mesh* out) {
+  const double ms = marching_cubes_range(g, iso, linear_interp, z_begin, z_end, out);
+  // Foreign vertices = the plane vertices created while the ghost layer was walked; they are a
+  // prefix of the kept vertices.  Count them by walking the ghost layer alone.
+  if (z_begin > 1) {
+    vcy_mesh ghost_only;
+    marching_cubes_range(g, iso, linear_interp, z_begin, z_begin, &ghost_only);
+    out->n_foreign_vertices = ghost_only.n_vertices;
+    orc_mesh_free(&ghost_only);
+  }
+  return ms;
 }
 
 void orc_mesh_free(vcy_mesh* m) {

@@ -50,6 +50,10 @@ void orc_make_sdf(const uint8_t* mask, int width, int height,
  * milliseconds of the whole function. */
 double orc_marching_cubes(const orc_grid* g, double iso_level, int linear_interp,
                           vcy_mesh* out);
+/* The same loop restricted to the cell layers of a z-slab, with the layer below walked first as
+ * a ghost layer (what one rank of the multi-GPU path computes); see the .cc. */
+double orc_marching_cubes_slab(const orc_grid* g, double iso_level, int linear_interp,
+                               int z_begin, int z_end, vcy_mesh* out);
 void orc_mesh_free(vcy_mesh* m);
 
 /* Pose arithmetic of the harness (Eigen operations restated, see .cc). */

@@ -39,6 +39,8 @@ def load():
                                  C.c_float, vp]
     lib.orc_marching_cubes.restype = C.c_double
     lib.orc_marching_cubes.argtypes = [vp, C.c_double, C.c_int, P(Mesh)]
+    lib.orc_marching_cubes_slab.restype = C.c_double
+    lib.orc_marching_cubes_slab.argtypes = [vp, C.c_double, C.c_int, C.c_int, C.c_int, P(Mesh)]
     lib.orc_mesh_free.argtypes = [P(Mesh)]
     lib.orc_pose_from_tum.argtypes = [vp, vp, vp]
     lib.orc_affine_inverse.argtypes = [vp, vp]
@@ -100,6 +102,15 @@ class OracleGrid:
         self.lib.orc_mesh_free(C.byref(m))
         out["ms"] = ms
         return out
+
+
+def marching_cubes_slab(grid, z0, z1, iso=0.0, linear_interp=True):
+    m = Mesh()
+    grid.lib.orc_marching_cubes_slab(grid.h, iso, int(linear_interp), z0, z1, C.byref(m))
+    out = mesh_to_numpy(m)
+    out["n_foreign"] = int(m.n_foreign_vertices)
+    grid.lib.orc_mesh_free(C.byref(m))
+    return out
 
 
 def mesh_to_numpy(m):

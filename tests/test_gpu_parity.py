@@ -284,3 +284,47 @@ def test_cpp_bunny_example(tmp_path):
     ply = open(os.path.join(str(tmp_path), "surface_00005.ply")).read().splitlines()
     assert ply[0] == "ply" and ply[2] == "element vertex 8672" and "element face 17270" in ply
     assert ply[ply.index("end_header") + 1].endswith(" ") and ply[-1].startswith("3 ")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_z_slab_sharding_on_one_gpu(world):
+    """The multi-GPU path with every 'rank' as its own context on cuda:0: slab carve (no
+    exchange), halo pack -> (host all-gather stand-in) -> unpack, per-slab extraction with the
+    ghost layer, host merge == the single-context mesh == the oracle, array for array."""
+    from vacancy_amd import dist as vdist
+    n, nv, w, h = 44, 5, 128, 96
+    opt = synth.sphere_option(n)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    sdfs = [vc.make_sdf(m) for m in masks]
+    whole = vc.VoxelCarver(opt)
+    assert whole.Init()
+    orc = O.OracleGrid(opt)
+    for i in range(nv):
+        assert whole.Carve(views[i], sdfs[i])
+        orc.carve(views[i], sdfs[i])
+    ranks = []
+    for r in range(world):
+        c = vc.VoxelCarver(opt, z_range=vdist.slab_range(n, r, world))
+        assert c.Init(), vc.last_error()
+        for i in range(nv):
+            assert c.Carve(views[i], sdfs[i])
+        ranks.append(c)
+    # slab states tile the whole grid
+    ws, wu = whole.download()
+    assert np.array_equal(np.concatenate([c.download()[0] for c in ranks]).view(np.uint32), ws.view(np.uint32))
+    assert np.array_equal(np.concatenate([c.download()[1] for c in ranks]), wu)
+    # extraction before the halo is installed must fail loudly on non-first slabs
+    with pytest.raises(RuntimeError):
+        ranks[1].ExtractIsoSurface()
+    gathered = np.concatenate([c.halo_pack_host() for c in ranks])
+    for r, c in enumerate(ranks):
+        c.halo_unpack_host(gathered, r, world)
+    for iso, interp in ((0.0, True), (0.1, False)):
+        parts = [c.ExtractIsoSurface(iso, interp) for c in ranks]
+        for r, (p, c) in enumerate(zip(parts, ranks)):
+            ref = O.marching_cubes_slab(orc, c.z_range[0], c.z_range[1], iso, interp)
+            assert p["n_foreign"] == ref["n_foreign"]
+            assert_mesh_equal(p, ref, "slab %d/%d" % (r, world))
+        merged = vdist.merge_meshes(parts)
+        assert_mesh_equal(merged, whole.ExtractIsoSurface(iso, interp), "merged vs single context")
+        assert_mesh_equal(merged, orc.marching_cubes(iso, interp), "merged vs oracle")
