@@ -94,11 +94,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     dist = None
     torch = None
+    backend = os.environ.get("VCY_BENCH_BACKEND", "nccl")  # "gloo": debugging N ranks on one GPU
+    if "VCY_BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["VCY_BENCH_FORCE_DEVICE"])
     if world > 1:
         import torch  # device plumbing + RCCL only
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     from vacancy_amd import carver as vc
     from vacancy_amd import dist as vdist
@@ -148,7 +155,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -188,7 +195,7 @@ def main():
         mc_ms = mesh["device_ms"]
         nvert, nface = len(mesh["vertices"]) - mesh["n_foreign"], len(mesh["faces"])
         if dist is not None:
-            t = torch.tensor([mc_ms, float(nvert), float(nface)], dtype=torch.float64, device="cuda")
+            t = torch.tensor([mc_ms, float(nvert), float(nface)], dtype=torch.float64, device=red_dev)
             tmax = t.clone()
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -328,3 +328,24 @@ def test_z_slab_sharding_on_one_gpu(world):
         merged = vdist.merge_meshes(parts)
         assert_mesh_equal(merged, whole.ExtractIsoSurface(iso, interp), "merged vs single context")
         assert_mesh_equal(merged, orc.marching_cubes(iso, interp), "merged vs oracle")
+
+
+def test_torch_shares_device_memory_with_the_library():
+    """bench.py's multi-GPU halo exchange hands torch CUDA tensors to the C-ABI: the library and
+    torch must sit on the same HIP runtime in one process."""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    n = 24
+    opt = synth.sphere_option(n)
+    views, masks = synth.sphere_views(n, 2, 64, 48)
+    c = vc.VoxelCarver(opt)
+    assert c.Init(), vc.last_error()
+    for v, m in zip(views, masks):
+        assert c.CarveSilhouette(v, m)
+    nbytes = int(c._lib.vcy_halo_bytes(c.ctx))
+    t = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    assert c._lib.vcy_halo_pack(c.ctx, C.c_void_p(t.data_ptr())) == 0, vc.last_error()
+    c.sync()
+    assert np.array_equal(t.cpu().numpy(), c.halo_pack_host())
