@@ -177,6 +177,37 @@ orc_grid* orc_grid_create(const vcy_carver_option* o) {
   return g;
 }
 
+// A "grid" of arbitrary voxel centres (nx = n, ny = nz = 1): lets tests carve a SAMPLE of the
+// voxels of a grid that is too large for the CPU (1024^3 and up) with the same loop.
+orc_grid* orc_grid_from_positions(const vcy_update_option* uo, const float* pos, int n) {
+  orc_grid* g = new orc_grid;
+  g->opt = *uo;
+  for (int i = 0; i < 3; ++i) g->bb_max[i] = g->bb_min[i] = 0.0f;
+  g->resolution = 1.0f;
+  g->n[0] = n;
+  g->n[1] = g->n[2] = 1;
+  g->xy = n;
+  g->voxels.resize((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    Voxel& v = g->voxels[i];
+    v.index[0] = i;
+    v.index[1] = v.index[2] = 0;
+    v.id = i;
+    for (int k = 0; k < 3; ++k) v.pos[k] = pos[3 * i + k];
+    v.sdf = kInvalidSdf;
+  }
+  return g;
+}
+
+// Voxel::pos along one axis, voxel_carver.cc:308-326
+void orc_axis_positions(float bb_min, float bb_max, float resolution, float* out, int* n_out) {
+  const float diff = bb_max - bb_min;
+  const int n = static_cast<int>(diff / resolution);
+  const float offset = resolution * 0.5f;
+  for (int i = 0; i < n; ++i) out[i] = diff * (static_cast<float>(i) / static_cast<float>(n)) + bb_min + offset;
+  *n_out = n;
+}
+
 void orc_grid_destroy(orc_grid* g) { delete g; }
 
 void orc_grid_dims(const orc_grid* g, int32_t dims[3]) {

@@ -25,6 +25,10 @@ typedef struct orc_grid orc_grid;
 
 /* VoxelCarver::Init + VoxelGrid::Init.  NULL when the reference returns false. */
 orc_grid* orc_grid_create(const vcy_carver_option* option);
+/* Test helpers for grids too large for the CPU: carve an arbitrary SAMPLE of voxel centres with the
+ * same loop, and the per-axis voxel centres of VoxelGrid::Init. */
+orc_grid* orc_grid_from_positions(const vcy_update_option* uo, const float* pos, int n);
+void orc_axis_positions(float bb_min, float bb_max, float resolution, float* out, int* n_out);
 void orc_grid_destroy(orc_grid* g);
 void orc_grid_dims(const orc_grid* g, int32_t dims[3]);
 int orc_sizeof_voxel(void);

@@ -28,6 +28,9 @@ def load():
     lib.orc_grid_create.restype = vp
     lib.orc_grid_create.argtypes = [P(CarverOption)]
     lib.orc_grid_destroy.argtypes = [vp]
+    lib.orc_grid_from_positions.restype = vp
+    lib.orc_grid_from_positions.argtypes = [P(UpdateOption), vp, C.c_int]
+    lib.orc_axis_positions.argtypes = [C.c_float, C.c_float, C.c_float, vp, P(C.c_int)]
     lib.orc_grid_dims.argtypes = [vp, P(C.c_int32)]
     lib.orc_grid_download.argtypes = [vp, vp, vp]
     lib.orc_grid_upload.argtypes = [vp, vp, vp]
@@ -56,10 +59,22 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def axis_positions(bb_min, bb_max, resolution, n_max):
+    out = np.empty(n_max, np.float32)
+    n = C.c_int(0)
+    load().orc_axis_positions(bb_min, bb_max, resolution, _p(out), C.byref(n))
+    return out[: n.value].copy()
+
+
 class OracleGrid:
-    def __init__(self, option):
+    def __init__(self, option, positions=None):
         self.lib = load()
-        self.h = self.lib.orc_grid_create(C.byref(option))
+        if positions is not None:
+            self._pos = np.ascontiguousarray(positions, np.float32)
+            self.h = self.lib.orc_grid_from_positions(C.byref(option.update_option), _p(self._pos),
+                                                      len(self._pos))
+        else:
+            self.h = self.lib.orc_grid_create(C.byref(option))
         if not self.h:
             raise ValueError("oracle: invalid option (reference Init() returns false)")
         d = (C.c_int32 * 3)()

@@ -1,0 +1,132 @@
+"""Parity at BASELINE.json's full sizes (configs[1], configs[2]): the grids are too large for the
+CPU oracle, so the HIP path is checked through
+  * a random SAMPLE of voxels carved by the oracle (same loop, bit-exact),
+  * fused + view-dropping kernel == per-view generic kernel on the WHOLE grid (bit-exact),
+  * idempotence of kMax carving (a second pass over the same views changes nothing),
+  * mesh invariants of the extracted surface (closed 2-manifold, Euler characteristic of a
+    sphere-like hull, unique edge keys, faces in range) and slab-sharded == single-context."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from vacancy_amd import carver as vc
+from vacancy_amd import dist as vdist
+from vacancy_amd import synth
+from vacancy_amd.capi import UpdateOption
+
+pytestmark = pytest.mark.gpu
+
+
+def _sample_check(dev, opt, views, sdfs, n, nsample=400000, seed=5):
+    rng = np.random.RandomState(seed)
+    ix = rng.randint(0, n, (nsample, 3))
+    # include the grid corners and faces
+    ix[:8] = [[a, b, c] for a in (0, n - 1) for b in (0, n - 1) for c in (0, n - 1)]
+    ax = O.axis_positions(-n / 2.0, n / 2.0, 1.0, n)
+    pos = np.stack([ax[ix[:, 0]], ax[ix[:, 1]], ax[ix[:, 2]]], 1)
+    orc = O.OracleGrid(opt, positions=pos)
+    for v, s in zip(views, sdfs):
+        orc.carve(v, s)
+    os_, ou = orc.download()
+    ds, du = dev.download()
+    lin = (ix[:, 2].astype(np.int64) * n + ix[:, 1]) * n + ix[:, 0]
+    assert np.array_equal(du[lin], ou)
+    assert np.array_equal(ds[lin].view(np.uint32), os_.view(np.uint32))
+
+
+def _mesh_invariants(m, expect_closed=True):
+    f = m["faces"].astype(np.int64)
+    nv = len(m["vertices"])
+    assert f.min() >= 0 and f.max() < nv
+    d = m["keys"][:, 1] - m["keys"][:, 0]
+    step = np.unique(d)
+    assert len(step) <= 3 and (d > 0).all()  # +x, +y, +z neighbours only
+    code = m["keys"][:, 0] * 4 + np.searchsorted(step, d)
+    assert len(np.unique(code)) == nv  # every cut edge appears once
+    assert np.isfinite(m["vertices"]).all()
+    if expect_closed:
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+        e.sort(axis=1)
+        code = e[:, 0] * nv + e[:, 1]
+        uniq, counts = np.unique(code, return_counts=True)
+        assert (counts == 2).all(), "surface is not a closed 2-manifold"
+        assert nv - len(uniq) + len(f) == 2  # Euler characteristic of a sphere-like hull
+
+
+def test_config1_512_tsdf():
+    """configs[1]: 512^3, 16 sphere silhouettes at 640x480, TSDF fusion on."""
+    n, nv, w, h = 512, 16, 640, 480
+    uo = UpdateOption(voxel_update=1, use_truncation=True, truncation_band=0.1)
+    opt = synth.sphere_option(n, uo)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    sdfs = [vc.make_sdf(m, use_truncation=True, band=0.1) for m in masks]
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init(), vc.last_error()
+    d = [dev.upload_sdf(s) for s in sdfs]
+    assert dev.CarveBatchDevice(views, d), vc.last_error()
+    _sample_check(dev, opt, views, sdfs, n)
+    # per-view generic kernel on the whole grid
+    ref = vc.VoxelCarver(opt)
+    assert ref.Init()
+    ref.set_param("fused", 0)
+    assert ref.CarveBatchDevice(views, [ref.upload_sdf(s) for s in sdfs])
+    a, b = dev.download(), ref.download()
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    m = dev.ExtractIsoSurface(0.0, True)
+    assert len(m["faces"]) > 100000
+    _mesh_invariants(m, expect_closed=False)  # truncation leaves untouched voxels: open patches allowed
+
+
+def test_config2_1024_default():
+    """configs[2]: 1024^3, 32 views at 1280x720, default (kMax, bilinear)."""
+    n, nv, w, h = 1024, 32, 1280, 720
+    opt = synth.sphere_option(n)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    sdf0 = vc.make_sdf(masks[0])
+    sdfs = [sdf0] * nv
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init(), vc.last_error()
+    d0 = dev.upload_sdf(sdf0)
+    assert dev.CarveBatchDevice(views, [d0] * nv), vc.last_error()
+    _sample_check(dev, opt, views, sdfs, n)
+    a = dev.download()
+    # whole grid: per-view generic kernel, no fusion, no dropping
+    ref = vc.VoxelCarver(opt)
+    assert ref.Init()
+    ref.set_param("fused", 0)
+    assert ref.CarveBatchDevice(views, [ref.upload_sdf(sdf0)] * nv)
+    b = ref.download()
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    del b
+    ref.close()
+    # idempotence of kMax
+    assert dev.CarveBatchDevice(views, [d0] * nv)
+    c = dev.download()
+    assert np.array_equal(a[1], c[1]) and np.array_equal(a[0].view(np.uint32), c[0].view(np.uint32))
+    del c
+    m = dev.ExtractIsoSurface(0.0, True)
+    _mesh_invariants(m)
+    # every vertex lies between the two voxel centres of its edge key
+    ax = O.axis_positions(-n / 2.0, n / 2.0, 1.0, n)
+    k0, k1 = m["keys"][:, 0], m["keys"][:, 1]
+    p0 = np.stack([ax[k0 % n], ax[(k0 // n) % n], ax[k0 // (n * n)]], 1)
+    p1 = np.stack([ax[k1 % n], ax[(k1 // n) % n], ax[k1 // (n * n)]], 1)
+    lo, hi = np.minimum(p0, p1), np.maximum(p0, p1)
+    assert ((m["vertices"] >= lo) & (m["vertices"] <= hi)).all()
+    dev.close()
+    # configs[3]: the same grid sharded by z-slab (2 contexts on this GPU) gives the same mesh
+    parts, ranks = [], []
+    for r in range(2):
+        c = vc.VoxelCarver(opt, z_range=vdist.slab_range(n, r, 2))
+        assert c.Init(), vc.last_error()
+        assert c.CarveBatchDevice(views, [c.upload_sdf(sdf0)] * nv)
+        ranks.append(c)
+    g = np.concatenate([c.halo_pack_host() for c in ranks])
+    for r, c in enumerate(ranks):
+        c.halo_unpack_host(g, r, 2)
+        parts.append(c.ExtractIsoSurface(0.0, True))
+        c.close()
+    merged = vdist.merge_meshes(parts)
+    assert np.array_equal(merged["faces"], m["faces"])
+    assert np.array_equal(merged["keys"], m["keys"])
+    assert np.array_equal(merged["vertices"].view(np.uint32), m["vertices"].view(np.uint32))
