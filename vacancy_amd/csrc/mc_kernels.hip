@@ -3,25 +3,31 @@
 // Replaces MarchingCubes() (reference src/vacancy/marching_cubes.cc:63-228).  The reference
 // walks cells z,y,x from 1, deduplicates vertices with a std::map keyed by the voxel-id pair
 // of the cut edge, numbers vertices in order of first reference and faces in scan order.
-// The same numbering falls out of three data-parallel passes over cells in raster order:
+// The same numbering falls out of data-parallel passes in raster order:
 //
-//   classify  one thread per cell: validity (:88-112) + cube index (:121-128) -> 1 case byte,
-//             triangles per 256-cell block.
+//   bits      ONE streaming pass over the voxels (the only pass that touches the 4-6 B/voxel
+//             state): a wave ballots 64 consecutive x into three bit planes --
+//             IN  = sdf < iso_level          (marching_cubes.cc:121-128, float promoted to double)
+//             OK  = sdf != InvalidSdf::kVal  (:103-112)
+//             TC  = update_num >= 1          (:88-90, tested on corner 6 only)
+//   active    one thread per 64-cell word: the 8 corner planes of the cells are word shifts /
+//             row offsets of IN and OK; active = valid & ~all_inside & any_inside.
 //   owner     a cut edge belongs to the FIRST active cell (scan order) among the <= 4 cells
-//             that share it -- that cell is where the reference's map insert happens, so it
-//             also fixes the interpolation direction (Appendix D of SURVEY.md).  Each active
-//             cell finds the edges it owns from its 9 earlier neighbours' case bytes;
-//             wave prefix-sums give every cell its first vertex number inside the block.
-//   scan      exclusive scan of the per-block (vertex, triangle) counts.
+//             that share it -- where the reference's map insert happens, which also fixes the
+//             interpolation direction.  Active cells (sparse) find the
+//             edges they own from 9 neighbour ACT bits; per-word counts -> wave/block
+//             prefix sums -> per-block (vertex, triangle) totals.
+//   scan      exclusive scan of the per-block totals.
 //   emit      owned edges -> VertexInterp in fp64 (:25-57) -> vertices + edge keys;
 //             triangles -> vertex ids through the owner cell of every corner edge.
 //
 // Multi-GPU: the layer of cells below the slab (z = z0-1, owned by the previous rank) is
-// classified from the two halo slices as a ghost layer; vertices it owns on the shared plane
+// evaluated from the two halo slices as a ghost layer; vertices it owns on the shared plane
 // are emitted first and counted in n_foreign_vertices, so a host merge can map them onto the
 // previous rank's numbering by edge key.
 //
-// Memory-bound, no MFMA: 4 B (sdf) per cell algorithmic read + 12 B per vertex/triangle out.
+// Memory-bound, no MFMA: 4 B (sdf) per cell algorithmic; real traffic = one read of sdf +
+// update_num, everything else is 1 bit per voxel/cell, plus 12 B per vertex/triangle out.
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -32,19 +38,17 @@ namespace vcy {
 
 namespace {
 
+typedef unsigned long long u64;
+
 // ---- tables ------------------------------------------------------------------------------
 const char* const kCaseStrings[256] = {
 #include "vacancy_mc_cases.inc"
 };
 
 struct McTables {
-  int8_t tri[256][16];   // edge numbers, -1 terminated (reference kTriTable)
+  int8_t tri[256][16];     // edge numbers, -1 terminated (reference kTriTable)
   uint8_t ntri[256];
   uint16_t prec[256][12];  // prec[c][e] = edges whose vertex the serial scan creates before e's
-};
-
-struct McScratch {
-  McTables* d_tables = nullptr;
 };
 
 void build_tables(McTables* t) {
@@ -79,7 +83,7 @@ __device__ const int8_t kKeyA[12] = {0, 1, 3, 0, 4, 5, 7, 4, 0, 1, 2, 3};
 __device__ const int8_t kKeyB[12] = {1, 2, 2, 3, 5, 6, 6, 7, 4, 5, 6, 7};
 
 // For edge e of a cell: the earlier cells sharing it, in scan order, as (dx,dy,dl) and the
-// number the edge has inside that cell.  count = 0 means the cell itself always owns it.
+// number the edge has inside that cell.  n = 0 means the cell itself always owns it.
 struct Share { int8_t n; int8_t d[3][3]; int8_t e[3]; };
 __device__ const Share kShare[12] = {
     {3, {{0, -1, -1}, {0, 0, -1}, {0, -1, 0}}, {6, 4, 2}},    // e0
@@ -96,27 +100,139 @@ __device__ const Share kShare[12] = {
     {1, {{-1, 0, 0}, {0, 0, 0}, {0, 0, 0}}, {10, 0, 0}},      // e11
 };
 
+// Cell (x, y, z) is named by its max corner; bit b of word w of a row is x = 64*w + b.
+// Cell rows: layer li = 0 is the ghost layer (z = zc0-1), li = l+1 the slab's own layer l;
+// word index of (li, cy = y-1, w):  li == 0 ? cy*Wr + w : G + ((li-1)*Y + cy)*Wr + w,
+// G = ghost words rounded up to a whole block so that own cells start on a block boundary.
 struct McParams {
   const float* sdf;   // slab incl. halo slices
   const void* cnt;
   const float* px;
   const float* py;
   const float* pz;
+  const u64* in;      // bit planes [slice][y][Wr]
+  const u64* ok;
+  const u64* tc;
   int nx, ny;
-  int X, Y;           // cells per row / column = nx-1, ny-1
+  int nslices;        // stored voxel slices
+  int Wr;             // 64-bit words per row
+  int Y;              // cell rows per layer = ny-1
   int L;              // own cell layers
-  int zc0;            // global z of own layer 0 (its max-corner slice)
-  int zs0;            // global z of stored slice 0 (= z0 - halo_lo)
-  int has_ghost;      // ghost layer computed from halo slices (else all inactive)
-  int64_t XY;
-  int64_t G;          // cells reserved for the ghost layer: XY rounded up to a whole block,
-                      // so that own-layer cells (and their vertices) start on a block boundary
-  int64_t ncells;     // G + L*XY, ghost layer first
+  int zc0;            // global z of own layer 0
+  int zs0;            // global z of stored slice 0
+  int has_ghost;
+  int64_t G;          // words reserved for the ghost layer
+  int64_t nwords;     // G + L*Y*Wr
   double iso;
   int linear;
 };
 
-__device__ __forceinline__ bool case_active(uint8_t c) { return c != 0 && c != 255; }
+constexpr int kWordsPerBlock = 256;
+
+// ---- pass 0: bit planes ----------------------------------------------------------------------
+template <typename CountT>
+__global__ __launch_bounds__(256) void mc_bits_kernel(const float* __restrict__ sdf,
+                                                      const CountT* __restrict__ cnt, int nx, int Wr,
+                                                      int64_t nrows, double iso, u64* __restrict__ in,
+                                                      u64* __restrict__ ok, u64* __restrict__ tc) {
+  // one wave per 64-voxel word; 4 words per block
+  const int64_t word = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (word >= nrows * Wr) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = word / Wr;
+  const int w = (int)(word - row * Wr);
+  const int x = w * 64 + lane;
+  bool b_in = false, b_ok = false, b_tc = false;
+  if (x < nx) {
+    const float s = sdf[row * nx + x];
+    b_in = (double)s < iso;
+    b_ok = s != kInvalidSdf;
+    b_tc = (int)cnt[row * nx + x] >= 1;
+  }
+  const u64 m_in = __ballot(b_in), m_ok = __ballot(b_ok), m_tc = __ballot(b_tc);
+  if (lane == 0) {
+    in[word] = m_in;
+    ok[word] = m_ok;
+    tc[word] = m_tc;
+  }
+}
+
+// ---- shared cell-word helpers -----------------------------------------------------------------
+__device__ __forceinline__ bool decode_word(const McParams& p, int64_t cw, int* li, int* cy, int* w) {
+  int64_t r;
+  if (cw < p.G) {
+    if (cw >= (int64_t)p.Y * p.Wr) return false;  // padding
+    *li = 0;
+    r = cw;
+  } else {
+    const int64_t q = cw - p.G;
+    const int64_t layer = q / ((int64_t)p.Y * p.Wr);
+    *li = (int)layer + 1;
+    r = q - layer * ((int64_t)p.Y * p.Wr);
+  }
+  *cy = (int)(r / p.Wr);
+  *w = (int)(r - (int64_t)(*cy) * p.Wr);
+  return true;
+}
+
+__device__ __forceinline__ int64_t word_index(const McParams& p, int li, int cy, int w) {
+  return (li == 0 ? 0 : p.G + (int64_t)(li - 1) * p.Y * p.Wr) + (int64_t)cy * p.Wr + w;
+}
+
+// padded per-cell index (info array)
+__device__ __forceinline__ int64_t cell_slot(int64_t cw, int b) { return cw * 64 + b; }
+
+// the 8 corner planes of the 64 cells of word (li, cy, w) and their validity
+struct CellWord {
+  u64 c[8];
+  u64 valid;
+};
+
+__device__ __forceinline__ u64 shl1(const u64* row, int w) {
+  // bit b = voxel x-1: shift towards higher x, carry from the previous word
+  return (row[w] << 1) | (w > 0 ? row[w - 1] >> 63 : 0ull);
+}
+
+__device__ __forceinline__ void load_cell_word(const McParams& p, int li, int cy, int w, CellWord* o) {
+  const int z = p.zc0 + li - 1;   // global z of the max corner
+  const int y = cy + 1;
+  const int64_t rw = (int64_t)p.Wr;
+  const int64_t r11 = ((int64_t)(z - p.zs0) * p.ny + y) * rw;        // (y,   z)
+  const int64_t r01 = r11 - rw;                                      // (y-1, z)
+  const int64_t r10 = r11 - (int64_t)p.ny * rw;                      // (y,   z-1)
+  const int64_t r00 = r10 - rw;                                      // (y-1, z-1)
+  o->c[0] = shl1(p.in + r00, w);
+  o->c[1] = p.in[r00 + w];
+  o->c[2] = p.in[r10 + w];
+  o->c[3] = shl1(p.in + r10, w);
+  o->c[4] = shl1(p.in + r01, w);
+  o->c[5] = p.in[r01 + w];
+  o->c[6] = p.in[r11 + w];
+  o->c[7] = shl1(p.in + r11, w);
+  u64 v = p.tc[r11 + w];                                             // marching_cubes.cc:88-90
+  v &= p.ok[r00 + w] & p.ok[r10 + w] & p.ok[r01 + w] & p.ok[r11 + w];   // :103-112
+  v &= shl1(p.ok + r00, w) & shl1(p.ok + r10, w) & shl1(p.ok + r01, w) & shl1(p.ok + r11, w);
+  // x = 0 is not a cell; bits beyond nx are zero in every plane already
+  if (w == 0) v &= ~1ull;
+  o->valid = v;
+}
+
+__device__ __forceinline__ u64 active_mask(const CellWord& cw) {
+  u64 all = cw.c[0], any = cw.c[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) {
+    all &= cw.c[i];
+    any |= cw.c[i];
+  }
+  return cw.valid & any & ~all;   // kEdgeTable[cube] != 0  (:131-133)
+}
+
+__device__ __forceinline__ int case_of(const CellWord& cw, int b) {
+  int code = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) code |= (int)((cw.c[i] >> b) & 1ull) << i;
+  return code;
+}
 
 __device__ __forceinline__ int cut_edges(int c) {
   // an edge is cut iff its two corners differ (== reference kEdgeTable[c])
@@ -126,28 +242,31 @@ __device__ __forceinline__ int cut_edges(int c) {
   return m;
 }
 
-// false for the padding cells between the ghost layer and the first own layer
-__device__ __forceinline__ bool decode_cell(const McParams& p, int64_t c, int* cx, int* cy, int* l) {
-  int64_t r;
-  if (c < p.G) {
-    if (c >= p.XY) return false;
-    *l = -1;
-    r = c;
-  } else {
-    const int64_t layer = (c - p.G) / p.XY;
-    r = (c - p.G) - layer * p.XY;
-    *l = (int)layer;
+__device__ __forceinline__ bool neighbour_active(const McParams& p, const u64* __restrict__ act, int li,
+                                                 int cy, int x, int dx, int dy, int dl) {
+  const int nl = li + dl, ncy = cy + dy, nxx = x + dx;
+  if (nl < 0 || ncy < 0 || ncy >= p.Y || nxx < 1 || nxx >= p.nx) return false;
+  return (act[word_index(p, nl, ncy, nxx >> 6)] >> (nxx & 63)) & 1ull;
+}
+
+__device__ __forceinline__ int owned_edges(const McParams& p, const u64* __restrict__ act, int code, int li,
+                                           int cy, int x) {
+  const int cut = cut_edges(code);
+  int owned = 0;
+#pragma unroll
+  for (int e = 0; e < 12; ++e) {
+    if (!(cut & (1 << e))) continue;
+    bool earlier = false;
+    for (int k = 0; k < kShare[e].n; ++k)
+      earlier |= neighbour_active(p, act, li, cy, x, kShare[e].d[k][0], kShare[e].d[k][1], kShare[e].d[k][2]);
+    if (!earlier) owned |= 1 << e;
   }
-  *cy = (int)(r / p.X);
-  *cx = (int)(r - (int64_t)(*cy) * p.X);
-  return true;
+  // a ghost cell only contributes vertices on the plane it shares with the slab (e4..e7)
+  if (li == 0) owned &= 0xF0;
+  return owned;
 }
 
-__device__ __forceinline__ int64_t cell_index(const McParams& p, int cx, int cy, int l) {
-  return (l < 0 ? 0 : p.G + (int64_t)l * p.XY) + (int64_t)cy * p.X + cx;
-}
-
-// ---- block-level exclusive scan of small per-thread counts (256 threads = 4 waves) ---------
+// ---- block-level exclusive scan (256 threads = 4 waves) ---------------------------------------
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -175,108 +294,64 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total, int* sm /
   return base + incl - v;
 }
 
-// ---- pass 1: classify ---------------------------------------------------------------------
-template <typename CountT>
-__global__ __launch_bounds__(256) void mc_classify_kernel(McParams p, const McTables* __restrict__ T,
-                                                          uint8_t* __restrict__ cases,
-                                                          unsigned long long* __restrict__ block_counts) {
-  __shared__ int sm[4];
-  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int ntri = 0;
-  int cx, cy, l;
-  if (c < p.ncells && decode_cell(p, c, &cx, &cy, &l)) {
-    uint8_t code = 0;
-    if (l >= 0 || p.has_ghost) {
-      const int x = cx + 1, y = cy + 1, z = p.zc0 + l;  // max corner, global z
-      const int64_t slice = (int64_t)p.nx * p.ny;
-      const int64_t base6 = (int64_t)(z - p.zs0) * slice + (int64_t)y * p.nx + x;
-      const CountT* cnt = (const CountT*)p.cnt;
-      if ((int)cnt[base6] >= 1) {  // marching_cubes.cc:88-90
-        const float* s1 = p.sdf + base6;        // slice z
-        const float* s0 = s1 - slice;           // slice z-1
-        float v[8];
-        v[0] = s0[-p.nx - 1];
-        v[1] = s0[-p.nx];
-        v[2] = s0[0];
-        v[3] = s0[-1];
-        v[4] = s1[-p.nx - 1];
-        v[5] = s1[-p.nx];
-        v[6] = s1[0];
-        v[7] = s1[-1];
-        bool invalid = false;
-        int bits = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          invalid |= (v[i] == kInvalidSdf);                      // :103-112
-          bits |= ((double)v[i] < p.iso) ? (1 << i) : 0;         // :121-128
-        }
-        code = invalid ? 0 : (uint8_t)bits;
-      }
-    }
-    cases[c] = code;
-    if (l >= 0) ntri = T->ntri[code];
-  } else if (c < p.ncells) {
-    cases[c] = 0;  // padding
+// ---- pass 1: active cells ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restrict__ act) {
+  const int64_t cw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (cw >= p.nwords) return;
+  int li, cy, w;
+  u64 a = 0;
+  if (decode_word(p, cw, &li, &cy, &w) && (li > 0 || p.has_ghost)) {
+    CellWord c;
+    load_cell_word(p, li, cy, w, &c);
+    a = active_mask(c);
   }
-  int total;
-  (void)block_exclusive_scan(ntri, &total, sm);
-  if (threadIdx.x == 0) block_counts[blockIdx.x] = (unsigned long long)(unsigned)total;
+  act[cw] = a;
 }
 
-// ---- pass 2: edge ownership ---------------------------------------------------------------
-__device__ __forceinline__ bool neighbour_active(const McParams& p, const uint8_t* cases, int cx,
-                                                 int cy, int l, int dx, int dy, int dl) {
-  const int nx_ = cx + dx, ny_ = cy + dy, nl = l + dl;
-  if (nx_ < 0 || nx_ >= p.X || ny_ < 0 || ny_ >= p.Y || nl < -1) return false;
-  return case_active(cases[cell_index(p, nx_, ny_, nl)]);
-}
-
-__device__ __forceinline__ int owned_edges(const McParams& p, const uint8_t* cases, int code, int cx,
-                                           int cy, int l) {
-  const int cut = cut_edges(code);
-  int owned = 0;
-#pragma unroll
-  for (int e = 0; e < 12; ++e) {
-    if (!(cut & (1 << e))) continue;
-    bool earlier = false;
-    for (int k = 0; k < kShare[e].n; ++k)
-      earlier |= neighbour_active(p, cases, cx, cy, l, kShare[e].d[k][0], kShare[e].d[k][1],
-                                  kShare[e].d[k][2]);
-    if (!earlier) owned |= 1 << e;
-  }
-  // a ghost cell only contributes vertices on the plane it shares with the slab (e4..e7)
-  if (l < 0) owned &= 0xF0;
-  return owned;
-}
-
-__global__ __launch_bounds__(256) void mc_owner_kernel(McParams p, const uint8_t* __restrict__ cases,
+// ---- pass 2: edge ownership + counts ----------------------------------------------------------
+// info[cell] = owned edges (12 bits) | case << 12 | first vertex of the cell inside its word << 20
+__global__ __launch_bounds__(256) void mc_owner_kernel(McParams p, const McTables* __restrict__ T,
+                                                       const u64* __restrict__ act,
                                                        uint32_t* __restrict__ info,
-                                                       unsigned long long* __restrict__ block_counts) {
+                                                       uint32_t* __restrict__ word_vert_off,
+                                                       uint32_t* __restrict__ word_tri_off,
+                                                       u64* __restrict__ block_counts) {
   __shared__ int sm[4];
-  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int owned = 0;
-  bool active = false;
-  int cx, cy, l;
-  if (c < p.ncells && decode_cell(p, c, &cx, &cy, &l)) {
-    const uint8_t code = cases[c];
-    active = case_active(code);
-    if (active) owned = owned_edges(p, cases, code, cx, cy, l);
+  const int64_t cw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int nvert = 0, ntri = 0;
+  u64 a = (cw < p.nwords) ? act[cw] : 0ull;
+  if (a) {
+    int li, cy, w;
+    decode_word(p, cw, &li, &cy, &w);
+    CellWord c;
+    load_cell_word(p, li, cy, w, &c);
+    while (a) {
+      const int b = __ffsll((long long)a) - 1;
+      a &= a - 1;
+      const int code = case_of(c, b);
+      const int owned = owned_edges(p, act, code, li, cy, w * 64 + b);
+      info[cell_slot(cw, b)] = (uint32_t)owned | ((uint32_t)code << 12) | ((uint32_t)nvert << 20);
+      nvert += __popc(owned);
+      if (li > 0) ntri += T->ntri[code];
+    }
   }
-  const int nv = __popc(owned);
-  int total;
-  const int off = block_exclusive_scan(nv, &total, sm);
-  if (active) info[c] = (uint32_t)owned | ((uint32_t)off << 12);
-  if (threadIdx.x == 0) block_counts[blockIdx.x] |= ((unsigned long long)(unsigned)total) << 32;
+  int tot_v, tot_t;
+  const int off_v = block_exclusive_scan(nvert, &tot_v, sm);
+  const int off_t = block_exclusive_scan(ntri, &tot_t, sm);
+  if (cw < p.nwords) {
+    word_vert_off[cw] = (uint32_t)off_v;
+    word_tri_off[cw] = (uint32_t)off_t;
+  }
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = ((u64)(unsigned)tot_v << 32) | (u64)(unsigned)tot_t;
 }
 
-// ---- pass 3: exclusive scan of packed (verts<<32 | tris) block counts ---------------------
-__global__ __launch_bounds__(256) void scan_chunks_kernel(unsigned long long* __restrict__ data,
-                                                          int64_t n,
-                                                          unsigned long long* __restrict__ chunk_sums) {
+// ---- pass 3: exclusive scan of packed (verts<<32 | tris) block counts ---------------------------
+__global__ __launch_bounds__(256) void scan_chunks_kernel(u64* __restrict__ data, int64_t n,
+                                                          u64* __restrict__ chunk_sums) {
   // 1024 elements per block, 4 per thread
-  __shared__ unsigned long long sm[256];
+  __shared__ u64 sm[256];
   const int64_t base = (int64_t)blockIdx.x * 1024 + (int64_t)threadIdx.x * 4;
-  unsigned long long v[4], s = 0;
+  u64 v[4], s = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     v[k] = (base + k < n) ? data[base + k] : 0ull;
@@ -285,12 +360,12 @@ __global__ __launch_bounds__(256) void scan_chunks_kernel(unsigned long long* __
   sm[threadIdx.x] = s;
   __syncthreads();
   for (int d = 1; d < 256; d <<= 1) {
-    unsigned long long t = (threadIdx.x >= d) ? sm[threadIdx.x - d] : 0ull;
+    u64 t = (threadIdx.x >= d) ? sm[threadIdx.x - d] : 0ull;
     __syncthreads();
     sm[threadIdx.x] += t;
     __syncthreads();
   }
-  unsigned long long run = sm[threadIdx.x] - s;
+  u64 run = sm[threadIdx.x] - s;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (base + k < n) data[base + k] = run;
@@ -299,54 +374,41 @@ __global__ __launch_bounds__(256) void scan_chunks_kernel(unsigned long long* __
   if (threadIdx.x == 255) chunk_sums[blockIdx.x] = sm[255];
 }
 
-__global__ __launch_bounds__(256) void add_chunk_offsets_kernel(unsigned long long* __restrict__ data,
-                                                                int64_t n,
-                                                                const unsigned long long* __restrict__ offs) {
+__global__ __launch_bounds__(256) void add_chunk_offsets_kernel(u64* __restrict__ data, int64_t n,
+                                                                const u64* __restrict__ offs) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) data[i] += offs[i >> 10];
 }
 
-// in-place exclusive scan; *total (device) receives the grand total
-int exclusive_scan_u64(unsigned long long* d, int64_t n, unsigned long long* d_total,
-                       hipStream_t stream) {
+// in-place exclusive scan; *d_total (device) receives the grand total.  `scratch` holds the chunk
+// sums of every level (n/1024 + n/1024^2 + ... + a few elements).
+int exclusive_scan_u64(u64* d, int64_t n, u64* d_total, u64* scratch, hipStream_t stream) {
   const int64_t nchunks = (n + 1023) / 1024;
-  unsigned long long* sums = nullptr;
-  VCY_HIP_CHECK(hipMalloc(&sums, sizeof(unsigned long long) * (size_t)(nchunks + 1)));
-  hipLaunchKernelGGL(scan_chunks_kernel, dim3((unsigned)nchunks), dim3(256), 0, stream, d, n, sums);
-  int rc = VCY_OK;
+  hipLaunchKernelGGL(scan_chunks_kernel, dim3((unsigned)nchunks), dim3(256), 0, stream, d, n, scratch);
   if (nchunks > 1) {
-    rc = exclusive_scan_u64(sums, nchunks, d_total, stream);
-    if (rc == VCY_OK)
-      hipLaunchKernelGGL(add_chunk_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                         stream, d, n, sums);
+    int rc = exclusive_scan_u64(scratch, nchunks, d_total, scratch + nchunks, stream);
+    if (rc != VCY_OK) return rc;
+    hipLaunchKernelGGL(add_chunk_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d, n,
+                       scratch);
   } else {
-    hipError_t e = hipMemcpyAsync(d_total, sums, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream);
-    if (e != hipSuccess) rc = VCY_ERR_HIP;
+    VCY_HIP_CHECK(hipMemcpyAsync(d_total, scratch, sizeof(u64), hipMemcpyDeviceToDevice, stream));
   }
-  hipError_t e1 = hipStreamSynchronize(stream);
-  hipError_t e2 = hipFree(sums);
-  if (rc == VCY_OK && (e1 != hipSuccess || e2 != hipSuccess || hipGetLastError() != hipSuccess)) {
-    set_error("scan failed");
-    rc = VCY_ERR_HIP;
-  }
-  return rc;
+  VCY_HIP_CHECK(hipGetLastError());
+  return VCY_OK;
 }
 
-// ---- pass 4: emit -------------------------------------------------------------------------
-__device__ __forceinline__ int64_t vertex_id_of(const McParams& p, const McTables* T,
-                                                const uint8_t* cases, const uint32_t* info,
-                                                const unsigned long long* block_offs, int64_t cell,
-                                                int edge) {
-  const uint32_t inf = info[cell];
-  const int owned = inf & 0xFFF;
-  const int local = inf >> 12;
-  const int64_t block_base = (int64_t)(block_offs[cell >> 8] >> 32);
-  return block_base + local + __popc(owned & T->prec[cases[cell]][edge]);
+// ---- pass 4: emit -----------------------------------------------------------------------------
+__device__ __forceinline__ int64_t vertex_id_of(const McTables* T, const uint32_t* __restrict__ info,
+                                                const uint32_t* __restrict__ word_vert_off,
+                                                const u64* __restrict__ block_offs, int64_t cw, int b, int edge) {
+  const uint32_t inf = info[cell_slot(cw, b)];
+  const int owned = inf & 0xFFF, code = (inf >> 12) & 0xFF, in_word = inf >> 20;
+  return (int64_t)(block_offs[cw >> 8] >> 32) + word_vert_off[cw] + in_word + __popc(owned & T->prec[code][edge]);
 }
 
 // VertexInterp, marching_cubes.cc:25-57 (fp64, then cast)
-__device__ __forceinline__ void vertex_interp(double iso, const float pa[3], const float pb[3],
-                                              float va, float vb, bool linear, float out[3]) {
+__device__ __forceinline__ void vertex_interp(double iso, const float pa[3], const float pb[3], float va,
+                                              float vb, bool linear, float out[3]) {
   if (!linear) {
     out[0] = pa[0]; out[1] = pa[1]; out[2] = pa[2];
     return;
@@ -357,44 +419,41 @@ __device__ __forceinline__ void vertex_interp(double iso, const float pa[3], con
   if (fabs(v1 - v2) < 0.00001) { out[0] = pa[0]; out[1] = pa[1]; out[2] = pa[2]; return; }
   const double mu = (iso - v1) / (v2 - v1);
 #pragma unroll
-  for (int k = 0; k < 3; ++k)
-    out[k] = (float)((double)pa[k] + mu * ((double)pb[k] - (double)pa[k]));
+  for (int k = 0; k < 3; ++k) out[k] = (float)((double)pa[k] + mu * ((double)pb[k] - (double)pa[k]));
 }
 
 __global__ __launch_bounds__(256) void mc_emit_kernel(McParams p, const McTables* __restrict__ T,
-                                                      const uint8_t* __restrict__ cases,
+                                                      const u64* __restrict__ act,
                                                       const uint32_t* __restrict__ info,
-                                                      const unsigned long long* __restrict__ block_offs,
-                                                      float* __restrict__ verts,
-                                                      long long* __restrict__ keys,
+                                                      const uint32_t* __restrict__ word_vert_off,
+                                                      const uint32_t* __restrict__ word_tri_off,
+                                                      const u64* __restrict__ block_offs,
+                                                      float* __restrict__ verts, long long* __restrict__ keys,
                                                       int* __restrict__ faces) {
-  __shared__ int sm[4];
-  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  uint8_t code = 0;
-  int cx = 0, cy = 0, l = 0;
-  bool active = false;
-  if (c < p.ncells && decode_cell(p, c, &cx, &cy, &l)) {
-    code = cases[c];
-    active = case_active(code);
-  }
-  const int ntri = (active && l >= 0) ? T->ntri[code] : 0;
-  int total;
-  const int tri_off = block_exclusive_scan(ntri, &total, sm);
-  if (!active) return;
-
-  const int x = cx + 1, y = cy + 1, z = p.zc0 + l;
+  const int64_t cw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (cw >= p.nwords) return;
+  u64 a = act[cw];
+  if (!a) return;
+  int li, cy, w;
+  decode_word(p, cw, &li, &cy, &w);
+  const int y = cy + 1, z = p.zc0 + li - 1;
   const int64_t slice = (int64_t)p.nx * p.ny;
+  const int64_t vword = (int64_t)(block_offs[cw >> 8] >> 32) + word_vert_off[cw];
+  int64_t fnext = (int64_t)(block_offs[cw >> 8] & 0xFFFFFFFFull) + word_tri_off[cw];
+  while (a) {
+    const int b = __ffsll((long long)a) - 1;
+    a &= a - 1;
+    const int x = w * 64 + b;
+    const uint32_t inf = info[cell_slot(cw, b)];
+    const int owned = inf & 0xFFF, code = (inf >> 12) & 0xFF;
+    const int64_t vbase = vword + (inf >> 20);
 
-  // vertices of the edges this cell owns
-  const uint32_t inf = info[c];
-  const int owned = inf & 0xFFF;
-  if (owned) {
-    const int64_t vbase = (int64_t)(block_offs[c >> 8] >> 32) + (inf >> 12);
+    // vertices of the edges this cell owns
     for (int e = 0; e < 12; ++e) {
       if (!(owned & (1 << e))) continue;
-      const int a = kEdgeA[e], b = kEdgeB[e];
-      const int ax = x + kCornerOff[a][0], ay = y + kCornerOff[a][1], az = z + kCornerOff[a][2];
-      const int bx = x + kCornerOff[b][0], by = y + kCornerOff[b][1], bz = z + kCornerOff[b][2];
+      const int ca = kEdgeA[e], cb = kEdgeB[e];
+      const int ax = x + kCornerOff[ca][0], ay = y + kCornerOff[ca][1], az = z + kCornerOff[ca][2];
+      const int bx = x + kCornerOff[cb][0], by = y + kCornerOff[cb][1], bz = z + kCornerOff[cb][2];
       const float pa[3] = {p.px[ax], p.py[ay], p.pz[az]};
       const float pb[3] = {p.px[bx], p.py[by], p.pz[bz]};
       const float va = p.sdf[(int64_t)(az - p.zs0) * slice + (int64_t)ay * p.nx + ax];
@@ -406,35 +465,36 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(McParams p, const McTables
       verts[3 * vid + 1] = out[1];
       verts[3 * vid + 2] = out[2];
       const int ka = kKeyA[e], kb = kKeyB[e];
-      keys[2 * vid + 0] = (int64_t)(z + kCornerOff[ka][2]) * slice +
-                          (int64_t)(y + kCornerOff[ka][1]) * p.nx + (x + kCornerOff[ka][0]);
-      keys[2 * vid + 1] = (int64_t)(z + kCornerOff[kb][2]) * slice +
-                          (int64_t)(y + kCornerOff[kb][1]) * p.nx + (x + kCornerOff[kb][0]);
+      keys[2 * vid + 0] = (int64_t)(z + kCornerOff[ka][2]) * slice + (int64_t)(y + kCornerOff[ka][1]) * p.nx +
+                          (x + kCornerOff[ka][0]);
+      keys[2 * vid + 1] = (int64_t)(z + kCornerOff[kb][2]) * slice + (int64_t)(y + kCornerOff[kb][1]) * p.nx +
+                          (x + kCornerOff[kb][0]);
     }
-  }
-  if (ntri == 0) return;
+    if (li == 0) continue;  // ghost cells emit no triangles
 
-  // triangles, marching_cubes.cc:199-218
-  const int64_t fbase = (int64_t)(block_offs[c >> 8] & 0xFFFFFFFFull) + tri_off;
-  for (int t = 0; t < ntri; ++t) {
-    for (int j = 0; j < 3; ++j) {
-      const int e = T->tri[code][3 * t + (2 - j)];
-      int64_t vid;
-      if (owned & (1 << e)) {
-        vid = vertex_id_of(p, T, cases, info, block_offs, c, e);
-      } else {
-        vid = -1;
-        for (int k = 0; k < kShare[e].n; ++k) {
-          const int dx = kShare[e].d[k][0], dy = kShare[e].d[k][1], dl = kShare[e].d[k][2];
-          if (neighbour_active(p, cases, cx, cy, l, dx, dy, dl)) {
-            const int64_t oc = cell_index(p, cx + dx, cy + dy, l + dl);
-            vid = vertex_id_of(p, T, cases, info, block_offs, oc, kShare[e].e[k]);
-            break;
+    // triangles, marching_cubes.cc:199-218
+    const int ntri = T->ntri[code];
+    for (int t = 0; t < ntri; ++t) {
+      for (int j = 0; j < 3; ++j) {
+        const int e = T->tri[code][3 * t + (2 - j)];
+        int64_t vid = -1;
+        if (owned & (1 << e)) {
+          vid = vbase + __popc(owned & T->prec[code][e]);
+        } else {
+          for (int k = 0; k < kShare[e].n; ++k) {
+            const int dx = kShare[e].d[k][0], dy = kShare[e].d[k][1], dl = kShare[e].d[k][2];
+            if (neighbour_active(p, act, li, cy, x, dx, dy, dl)) {
+              const int ox = x + dx;
+              vid = vertex_id_of(T, info, word_vert_off, block_offs, word_index(p, li + dl, cy + dy, ox >> 6),
+                                 ox & 63, kShare[e].e[k]);
+              break;
+            }
           }
         }
+        faces[3 * (fnext + t) + j] = (int)vid;
       }
-      faces[3 * (fbase + t) + j] = (int)vid;
     }
+    fnext += ntri;
   }
 }
 
@@ -442,11 +502,10 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(McParams p, const McTables
 
 // ---- host driver ----------------------------------------------------------------------------
 
-template <typename CountT>
-static void launch_classify(const McParams& p, const McTables* T, uint8_t* cases,
-                            unsigned long long* counts, unsigned nblocks, hipStream_t s) {
-  hipLaunchKernelGGL((mc_classify_kernel<CountT>), dim3(nblocks), dim3(256), 0, s, p, T, cases, counts);
-}
+struct McScratch {
+  size_t bytes = 0;
+  char* base = nullptr;
+};
 
 int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   out->n_vertices = out->n_faces = out->n_foreign_vertices = 0;
@@ -465,7 +524,8 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   p.pz = c->d_pz;
   p.nx = c->nx;
   p.ny = c->ny;
-  p.X = c->nx - 1;
+  p.nslices = c->halo_lo + c->nz_local();
+  p.Wr = (c->nx + 63) / 64;
   p.Y = c->ny - 1;
   p.zc0 = std::max(c->z0, 1);
   p.L = c->z1 - p.zc0;
@@ -474,12 +534,14 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   p.iso = iso;
   p.linear = linear_interp;
   c->last_extract_device_ms = 0.0f;
-  if (p.X <= 0 || p.Y <= 0 || p.L <= 0) return VCY_OK;  // no cells (reference loops do not run)
-  p.XY = (int64_t)p.X * p.Y;
-  p.G = (p.XY + 255) / 256 * 256;
-  p.ncells = p.G + (int64_t)p.L * p.XY;
-  const int64_t nblocks64 = (p.ncells + 255) / 256;
-  if (nblocks64 > 0x7fffffffLL) {
+  if (c->nx < 2 || p.Y <= 0 || p.L <= 0) return VCY_OK;  // no cells (reference loops do not run)
+  const int64_t ghost_words = (int64_t)p.Y * p.Wr;
+  p.G = (ghost_words + kWordsPerBlock - 1) / kWordsPerBlock * kWordsPerBlock;
+  p.nwords = p.G + (int64_t)p.L * p.Y * p.Wr;
+  const int64_t nblocks64 = (p.nwords + kWordsPerBlock - 1) / kWordsPerBlock;
+  const int64_t vox_rows = (int64_t)p.nslices * c->ny;
+  const int64_t vox_words = vox_rows * p.Wr;
+  if (nblocks64 > 0x7fffffffLL || (vox_words + 3) / 4 > 0x7fffffffLL) {
     set_error("too many cells for one launch");
     return VCY_ERR_TOO_MANY_VOXELS;
   }
@@ -494,18 +556,42 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   }
   const McTables* T = (const McTables*)c->d_mc_tables;
 
-  uint8_t* cases = nullptr;
-  uint32_t* info = nullptr;
-  unsigned long long* counts = nullptr;
-  unsigned long long* d_total = nullptr;
-  float *d_verts = nullptr;
+  // scratch, cached in the context (grown on demand): bit planes, ACT, offsets, info
+  auto align = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t sz_plane = align(sizeof(u64) * (size_t)vox_words);
+  const size_t sz_act = align(sizeof(u64) * (size_t)p.nwords);
+  const size_t sz_woff = align(sizeof(uint32_t) * (size_t)p.nwords);
+  const size_t sz_counts = align(sizeof(u64) * ((size_t)nblocks + 1));
+  const size_t sz_scan = align(sizeof(u64) * ((size_t)nblocks / 1024 + 64) * 2);
+  const size_t sz_info = align(sizeof(uint32_t) * (size_t)p.nwords * 64);
+  const size_t need = 3 * sz_plane + sz_act + 2 * sz_woff + sz_counts + sz_scan + sz_info + 256;
+  if (c->mc_scratch_bytes < need) {
+    VCY_HIP_CHECK(hipStreamSynchronize(s));
+    if (c->d_mc_scratch) VCY_HIP_CHECK(hipFree(c->d_mc_scratch));
+    c->d_mc_scratch = nullptr;
+    c->mc_scratch_bytes = 0;
+    VCY_HIP_CHECK(hipMalloc(&c->d_mc_scratch, need));
+    c->mc_scratch_bytes = need;
+  }
+  char* base = (char*)c->d_mc_scratch;
+  u64* d_in = (u64*)base;                     base += sz_plane;
+  u64* d_ok = (u64*)base;                     base += sz_plane;
+  u64* d_tc = (u64*)base;                     base += sz_plane;
+  u64* d_act = (u64*)base;                    base += sz_act;
+  uint32_t* d_voff = (uint32_t*)base;         base += sz_woff;
+  uint32_t* d_toff = (uint32_t*)base;         base += sz_woff;
+  u64* d_counts = (u64*)base;                 base += sz_counts;
+  u64* d_scan = (u64*)base;                   base += sz_scan;
+  uint32_t* d_info = (uint32_t*)base;         base += sz_info;
+  u64* d_total = (u64*)base;
+  p.in = d_in;
+  p.ok = d_ok;
+  p.tc = d_tc;
+
+  float* d_verts = nullptr;
   long long* d_keys = nullptr;
   int* d_faces = nullptr;
   auto cleanup = [&]() {
-    (void)hipFree(cases);
-    (void)hipFree(info);
-    (void)hipFree(counts);
-    (void)hipFree(d_total);
     (void)hipFree(d_verts);
     (void)hipFree(d_keys);
     (void)hipFree(d_faces);
@@ -519,35 +605,40 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
       return VCY_ERR_HIP;                                                          \
     }                                                                              \
   } while (0)
-  MC_TRY(hipMalloc(&cases, (size_t)p.ncells));
-  MC_TRY(hipMalloc(&info, sizeof(uint32_t) * (size_t)p.ncells));
-  MC_TRY(hipMalloc(&counts, sizeof(unsigned long long) * (size_t)nblocks));
-  MC_TRY(hipMalloc(&d_total, sizeof(unsigned long long)));
 
   MC_TRY(hipEventRecord(c->ev_begin, s));
-  if (c->cnt_bytes == 1) launch_classify<uint8_t>(p, T, cases, counts, nblocks, s);
-  else if (c->cnt_bytes == 2) launch_classify<uint16_t>(p, T, cases, counts, nblocks, s);
-  else launch_classify<uint32_t>(p, T, cases, counts, nblocks, s);
-  hipLaunchKernelGGL(mc_owner_kernel, dim3(nblocks), dim3(256), 0, s, p, cases, info, counts);
+  const unsigned bits_blocks = (unsigned)((vox_words + 3) / 4);
+  if (c->cnt_bytes == 1)
+    hipLaunchKernelGGL((mc_bits_kernel<uint8_t>), dim3(bits_blocks), dim3(256), 0, s, c->d_sdf,
+                       (const uint8_t*)c->d_cnt, c->nx, p.Wr, vox_rows, iso, d_in, d_ok, d_tc);
+  else if (c->cnt_bytes == 2)
+    hipLaunchKernelGGL((mc_bits_kernel<uint16_t>), dim3(bits_blocks), dim3(256), 0, s, c->d_sdf,
+                       (const uint16_t*)c->d_cnt, c->nx, p.Wr, vox_rows, iso, d_in, d_ok, d_tc);
+  else
+    hipLaunchKernelGGL((mc_bits_kernel<uint32_t>), dim3(bits_blocks), dim3(256), 0, s, c->d_sdf,
+                       (const uint32_t*)c->d_cnt, c->nx, p.Wr, vox_rows, iso, d_in, d_ok, d_tc);
+  hipLaunchKernelGGL(mc_active_kernel, dim3(nblocks), dim3(256), 0, s, p, d_act);
+  hipLaunchKernelGGL(mc_owner_kernel, dim3(nblocks), dim3(256), 0, s, p, T, d_act, d_info, d_voff, d_toff,
+                     d_counts);
   MC_TRY(hipGetLastError());
-  int rc = exclusive_scan_u64(counts, nblocks, d_total, s);
+  int rc = exclusive_scan_u64(d_counts, nblocks, d_total, d_scan, s);
   if (rc != VCY_OK) {
     cleanup();
     return rc;
   }
-  unsigned long long total = 0;
-  MC_TRY(hipMemcpy(&total, d_total, sizeof(total), hipMemcpyDeviceToHost));
-  const int64_t nv = (int64_t)(total >> 32), nf = (int64_t)(total & 0xFFFFFFFFull);
+  // totals, and the vertex offset of the first own block (= vertices owned by ghost cells)
+  u64 h_tot[2] = {0, 0};
+  MC_TRY(hipMemcpyAsync(&h_tot[0], d_total, sizeof(u64), hipMemcpyDeviceToHost, s));
+  MC_TRY(hipMemcpyAsync(&h_tot[1], d_counts + p.G / kWordsPerBlock, sizeof(u64), hipMemcpyDeviceToHost, s));
+  MC_TRY(hipStreamSynchronize(s));
+  const int64_t nv = (int64_t)(h_tot[0] >> 32), nf = (int64_t)(h_tot[0] & 0xFFFFFFFFull);
+  out->n_foreign_vertices = (int64_t)(h_tot[1] >> 32);
 
-  // vertices owned by ghost cells come first in scan order; own cells start at block G/256
-  unsigned long long first_own = 0;
-  MC_TRY(hipMemcpy(&first_own, counts + p.G / 256, sizeof(first_own), hipMemcpyDeviceToHost));
-  out->n_foreign_vertices = (int64_t)(first_own >> 32);
   MC_TRY(hipMalloc(&d_verts, sizeof(float) * 3 * (size_t)std::max<int64_t>(nv, 1)));
   MC_TRY(hipMalloc(&d_keys, sizeof(long long) * 2 * (size_t)std::max<int64_t>(nv, 1)));
   MC_TRY(hipMalloc(&d_faces, sizeof(int) * 3 * (size_t)std::max<int64_t>(nf, 1)));
-  hipLaunchKernelGGL(mc_emit_kernel, dim3(nblocks), dim3(256), 0, s, p, T, cases, info, counts, d_verts,
-                     d_keys, d_faces);
+  hipLaunchKernelGGL(mc_emit_kernel, dim3(nblocks), dim3(256), 0, s, p, T, d_act, d_info, d_voff, d_toff,
+                     d_counts, d_verts, d_keys, d_faces);
   MC_TRY(hipGetLastError());
   MC_TRY(hipEventRecord(c->ev_end, s));
   MC_TRY(hipEventSynchronize(c->ev_end));
@@ -563,8 +654,7 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
     MC_TRY(hipMemcpy(out->vertices, d_verts, sizeof(float) * 3 * (size_t)nv, hipMemcpyDeviceToHost));
     MC_TRY(hipMemcpy(out->edge_keys, d_keys, sizeof(long long) * 2 * (size_t)nv, hipMemcpyDeviceToHost));
   }
-  if (nf > 0)
-    MC_TRY(hipMemcpy(out->faces, d_faces, sizeof(int) * 3 * (size_t)nf, hipMemcpyDeviceToHost));
+  if (nf > 0) MC_TRY(hipMemcpy(out->faces, d_faces, sizeof(int) * 3 * (size_t)nf, hipMemcpyDeviceToHost));
   out->n_vertices = nv;
   out->n_faces = nf;
 #undef MC_TRY

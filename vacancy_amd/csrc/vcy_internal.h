@@ -65,6 +65,8 @@ struct vcy_ctx {
   void* d_fused_scratch = nullptr;    // view blocks + z tables of the fused carve kernel
   size_t fused_scratch_bytes = 0;
   void* d_mc_tables = nullptr;        // marching-cubes case tables (mc_kernels.hip)
+  void* d_mc_scratch = nullptr;       // bit planes, active words, offsets, per-cell info
+  size_t mc_scratch_bytes = 0;
   float last_extract_device_ms = 0.0f;
 
   // upper bound on any voxel's update_num (each carved view adds at most one)
