@@ -147,6 +147,12 @@ int vcy_make_sdf(const uint8_t* mask, int width, int height,
                  int minmax_normalize, int use_truncation, float truncation_band,
                  float* sdf_out);
 
+/* MakeSignedDistanceField on the device: uploads the 8-bit mask, builds the SDF in HBM and returns
+ * the device image (release with vcy_device_free); feed it to vcy_carve_device / _batch_device. */
+int vcy_make_sdf_device(vcy_ctx* ctx, const uint8_t* mask_host, int width, int height,
+                        const int32_t roi_min[2], const int32_t roi_max[2], int minmax_normalize,
+                        int use_truncation, float truncation_band, float** sdf_device_out);
+
 /* ---- surface extraction ------------------------------------------------- */
 
 /* Replaces void VoxelCarver::ExtractIsoSurface(Mesh*, double iso_level,

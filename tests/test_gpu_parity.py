@@ -349,3 +349,29 @@ def test_torch_shares_device_memory_with_the_library():
     assert c._lib.vcy_halo_pack(c.ctx, C.c_void_p(t.data_ptr())) == 0, vc.last_error()
     c.sync()
     assert np.array_equal(t.cpu().numpy(), c.halo_pack_host())
+
+
+def test_device_sdf_builder_equals_oracle():
+    """MakeSignedDistanceField on the device (row f1): silhouettes, noise, all-255 / all-0 masks,
+    sub-ROIs, odd sizes, every normalise / truncate combination -- bit-exact."""
+    opt = synth.sphere_option(16)
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init()
+    rng = np.random.RandomState(2)
+    masks = B.load_masks()[:2]
+    noise = (rng.rand(97, 131) < 0.4).astype(np.uint8) * 255
+    noise[rng.rand(97, 131) < 0.1] = 128
+    sparse = np.full((333, 1283), 255, np.uint8)
+    sparse[rng.randint(0, 333, 5), rng.randint(0, 1283, 5)] = 0
+    cases = [(m, None, None) for m in masks] + [
+        (masks[0], (10, 20), (300, 200)), (noise, None, None), (noise, (5, 7), (100, 60)),
+        (np.full((20, 30), 255, np.uint8), None, None), (np.zeros((20, 30), np.uint8), None, None),
+        (sparse, None, None), (sparse, (1, 1), (1281, 331)), (synth.sphere_views(64, 1, 1280, 720)[1][0], None, None)]
+    for mask, rmin, rmax in cases:
+        for norm in (True, False):
+            for trunc in (False, True):
+                d = dev.make_sdf_device(mask, rmin, rmax, norm, trunc, 0.1)
+                got = dev.download_image(d, mask.shape)
+                dev.free_device(d)
+                ref = O.make_sdf(mask, rmin, rmax, norm, trunc, 0.1)
+                assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (mask.shape, rmin, norm, trunc)

@@ -95,6 +95,24 @@ class VoxelCarver:
             raise RuntimeError(last_error())
         return out
 
+    def make_sdf_device(self, mask, roi_min=None, roi_max=None, normalize=True, use_truncation=False, band=0.1):
+        """MakeSignedDistanceField on the device; returns a device pointer (free_device it)."""
+        mask = np.ascontiguousarray(mask, np.uint8)
+        h, w = mask.shape
+        rmin = (C.c_int32 * 2)(*(roi_min or (0, 0)))
+        rmax = (C.c_int32 * 2)(*(roi_max or (w - 1, h - 1)))
+        out = C.c_void_p()
+        rc = self._lib.vcy_make_sdf_device(self._ctx, _p(mask), w, h, rmin, rmax, int(normalize),
+                                           int(use_truncation), band, C.byref(out))
+        if rc != 0:
+            raise RuntimeError(last_error())
+        return out
+
+    def download_image(self, ptr, shape):
+        out = np.empty(shape, np.float32)
+        assert self._lib.vcy_memcpy_d2h(self._ctx, _p(out), ptr, out.nbytes) == 0, last_error()
+        return out
+
     def free_device(self, ptr):
         self._lib.vcy_device_free(self._ctx, ptr)
 

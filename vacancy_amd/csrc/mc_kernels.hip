@@ -130,30 +130,49 @@ struct McParams {
 constexpr int kWordsPerBlock = 256;
 
 // ---- pass 0: bit planes ----------------------------------------------------------------------
+// One wave turns kBitsWordsPerWave consecutive 64-voxel words into plane words; all loads of a
+// wave are issued before the first ballot so that a wave keeps ~3 KB in flight.
+constexpr int kBitsWordsPerWave = 8;
+
 template <typename CountT>
 __global__ __launch_bounds__(256) void mc_bits_kernel(const float* __restrict__ sdf,
                                                       const CountT* __restrict__ cnt, int nx, int Wr,
-                                                      int64_t nrows, double iso, u64* __restrict__ in,
+                                                      int64_t nwords, double iso, u64* __restrict__ in,
                                                       u64* __restrict__ ok, u64* __restrict__ tc) {
-  // one wave per 64-voxel word; 4 words per block
-  const int64_t word = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (word >= nrows * Wr) return;
   const int lane = threadIdx.x & 63;
-  const int64_t row = word / Wr;
-  const int w = (int)(word - row * Wr);
-  const int x = w * 64 + lane;
-  bool b_in = false, b_ok = false, b_tc = false;
-  if (x < nx) {
-    const float s = sdf[row * nx + x];
-    b_in = (double)s < iso;
-    b_ok = s != kInvalidSdf;
-    b_tc = (int)cnt[row * nx + x] >= 1;
+  const int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kBitsWordsPerWave;
+  if (first >= nwords) return;
+  float s[kBitsWordsPerWave];
+  int n[kBitsWordsPerWave];
+#pragma unroll
+  for (int k = 0; k < kBitsWordsPerWave; ++k) {
+    const int64_t word = first + k;
+    const int64_t row = word / Wr;
+    const int x = (int)(word - row * Wr) * 64 + lane;
+    const bool live = word < nwords && x < nx;
+    s[k] = live ? sdf[row * nx + x] : kInvalidSdf;
+    n[k] = live ? (int)cnt[row * nx + x] : 0;
   }
-  const u64 m_in = __ballot(b_in), m_ok = __ballot(b_ok), m_tc = __ballot(b_tc);
-  if (lane == 0) {
-    in[word] = m_in;
-    ok[word] = m_ok;
-    tc[word] = m_tc;
+  u64 m_in = 0, m_ok = 0, m_tc = 0;
+#pragma unroll
+  for (int k = 0; k < kBitsWordsPerWave; ++k) {
+    const int64_t word = first + k;
+    const int64_t row = word / Wr;
+    const int x = (int)(word - row * Wr) * 64 + lane;
+    const bool live = word < nwords && x < nx;
+    const u64 a = __ballot(live && (double)s[k] < iso);
+    const u64 b = __ballot(live && s[k] != kInvalidSdf);
+    const u64 c = __ballot(live && n[k] >= 1);
+    if (lane == k) {
+      m_in = a;
+      m_ok = b;
+      m_tc = c;
+    }
+  }
+  if (lane < kBitsWordsPerWave && first + lane < nwords) {
+    in[first + lane] = m_in;
+    ok[first + lane] = m_ok;
+    tc[first + lane] = m_tc;
   }
 }
 
@@ -591,11 +610,7 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   float* d_verts = nullptr;
   long long* d_keys = nullptr;
   int* d_faces = nullptr;
-  auto cleanup = [&]() {
-    (void)hipFree(d_verts);
-    (void)hipFree(d_keys);
-    (void)hipFree(d_faces);
-  };
+  auto cleanup = [&]() {};
 #define MC_TRY(expr)                                                               \
   do {                                                                             \
     hipError_t _e = (expr);                                                        \
@@ -607,16 +622,16 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   } while (0)
 
   MC_TRY(hipEventRecord(c->ev_begin, s));
-  const unsigned bits_blocks = (unsigned)((vox_words + 3) / 4);
+  const unsigned bits_blocks = (unsigned)((vox_words + 4 * kBitsWordsPerWave - 1) / (4 * kBitsWordsPerWave));
   if (c->cnt_bytes == 1)
     hipLaunchKernelGGL((mc_bits_kernel<uint8_t>), dim3(bits_blocks), dim3(256), 0, s, c->d_sdf,
-                       (const uint8_t*)c->d_cnt, c->nx, p.Wr, vox_rows, iso, d_in, d_ok, d_tc);
+                       (const uint8_t*)c->d_cnt, c->nx, p.Wr, vox_words, iso, d_in, d_ok, d_tc);
   else if (c->cnt_bytes == 2)
     hipLaunchKernelGGL((mc_bits_kernel<uint16_t>), dim3(bits_blocks), dim3(256), 0, s, c->d_sdf,
-                       (const uint16_t*)c->d_cnt, c->nx, p.Wr, vox_rows, iso, d_in, d_ok, d_tc);
+                       (const uint16_t*)c->d_cnt, c->nx, p.Wr, vox_words, iso, d_in, d_ok, d_tc);
   else
     hipLaunchKernelGGL((mc_bits_kernel<uint32_t>), dim3(bits_blocks), dim3(256), 0, s, c->d_sdf,
-                       (const uint32_t*)c->d_cnt, c->nx, p.Wr, vox_rows, iso, d_in, d_ok, d_tc);
+                       (const uint32_t*)c->d_cnt, c->nx, p.Wr, vox_words, iso, d_in, d_ok, d_tc);
   hipLaunchKernelGGL(mc_active_kernel, dim3(nblocks), dim3(256), 0, s, p, d_act);
   hipLaunchKernelGGL(mc_owner_kernel, dim3(nblocks), dim3(256), 0, s, p, T, d_act, d_info, d_voff, d_toff,
                      d_counts);
@@ -634,9 +649,23 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   const int64_t nv = (int64_t)(h_tot[0] >> 32), nf = (int64_t)(h_tot[0] & 0xFFFFFFFFull);
   out->n_foreign_vertices = (int64_t)(h_tot[1] >> 32);
 
-  MC_TRY(hipMalloc(&d_verts, sizeof(float) * 3 * (size_t)std::max<int64_t>(nv, 1)));
-  MC_TRY(hipMalloc(&d_keys, sizeof(long long) * 2 * (size_t)std::max<int64_t>(nv, 1)));
-  MC_TRY(hipMalloc(&d_faces, sizeof(int) * 3 * (size_t)std::max<int64_t>(nf, 1)));
+  // output staging, cached in the context and grown on demand
+  {
+    const size_t sz_v = align(sizeof(float) * 3 * (size_t)std::max<int64_t>(nv, 1));
+    const size_t sz_k = align(sizeof(long long) * 2 * (size_t)std::max<int64_t>(nv, 1));
+    const size_t sz_f = align(sizeof(int) * 3 * (size_t)std::max<int64_t>(nf, 1));
+    if (c->mc_out_bytes < sz_v + sz_k + sz_f) {
+      if (c->d_mc_out) MC_TRY(hipFree(c->d_mc_out));
+      c->d_mc_out = nullptr;
+      c->mc_out_bytes = 0;
+      const size_t want = (sz_v + sz_k + sz_f) + (sz_v + sz_k + sz_f) / 4;  // headroom for the next view
+      MC_TRY(hipMalloc(&c->d_mc_out, want));
+      c->mc_out_bytes = want;
+    }
+    d_verts = (float*)c->d_mc_out;
+    d_keys = (long long*)((char*)c->d_mc_out + sz_v);
+    d_faces = (int*)((char*)c->d_mc_out + sz_v + sz_k);
+  }
   hipLaunchKernelGGL(mc_emit_kernel, dim3(nblocks), dim3(256), 0, s, p, T, d_act, d_info, d_voff, d_toff,
                      d_counts, d_verts, d_keys, d_faces);
   MC_TRY(hipGetLastError());

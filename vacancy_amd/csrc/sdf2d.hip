@@ -126,4 +126,178 @@ void host_make_sdf(const uint8_t* mask, int w, int h, const int32_t* rmin, const
   }
 }
 
+
+// ---- device version ----------------------------------------------------------------------------
+// Same separable integer L1 transform as above, as HIP kernels: rows by one wave each (segment
+// scan + wave carry), columns by one thread each (coalesced across x), then sign /
+// min-max normalisation / truncation exactly as MakeSignedDistanceField (:169-237).  Keeps the
+// per-view pre-step off the host: ~0.05 ms instead of ~5 ms for a 1280x720 silhouette.
+
+namespace {
+
+__device__ __forceinline__ int wave_excl_scan_max(int v, int identity) {
+  const int lane = threadIdx.x & 63;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl = max(incl, t);
+  }
+  const int prev = __shfl_up(incl, 1, 64);
+  return lane == 0 ? identity : prev;
+}
+
+__device__ __forceinline__ int wave_excl_scan_min_from_right(int v, int identity) {
+  const int lane = threadIdx.x & 63;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_down(incl, d, 64);
+    if (lane + d < 64) incl = min(incl, t);
+  }
+  const int next = __shfl_down(incl, 1, 64);
+  return lane == 63 ? identity : next;
+}
+
+constexpr int kFar = 1 << 28;
+// a distance measured against the 'no seed' sentinel -> kInf
+__device__ __forceinline__ int far_to_inf(int d) { return d >= (1 << 24) ? kInf : d; }
+
+// g_in[y][x]  = distance along the row to the nearest pixel != 255 (kInf if none)
+// g_out[y][x] = distance along the row to the nearest pixel == 255
+__global__ __launch_bounds__(256) void sdf_rows_kernel(const uint8_t* __restrict__ mask, int W, int rx0,
+                                                       int rx1, int ry0, int ry1, int* __restrict__ g_in,
+                                                       int* __restrict__ g_out) {
+  const int row = ry0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row > ry1) return;
+  const int lane = threadIdx.x & 63;
+  const int rw = rx1 - rx0 + 1;
+  const int seg = (rw + 63) / 64;
+  const int xs = min(rx0 + lane * seg, rx1 + 1), xe = min(xs + seg, rx1 + 1);
+  const uint8_t* m = mask + (int64_t)row * W;
+  int* gi = g_in + (int64_t)row * W;
+  int* go = g_out + (int64_t)row * W;
+  // nearest seed to the left
+  int last_n = -kFar, last_s = -kFar;  // last non-255 / last 255 inside my segment
+  for (int x = xs; x < xe; ++x) {
+    if (m[x] != 255) last_n = x; else last_s = x;
+  }
+  int ln = wave_excl_scan_max(last_n, -kFar), ls = wave_excl_scan_max(last_s, -kFar);
+  for (int x = xs; x < xe; ++x) {
+    if (m[x] != 255) ln = x; else ls = x;
+    gi[x] = far_to_inf(x - ln);
+    go[x] = far_to_inf(x - ls);
+  }
+  // nearest seed to the right
+  int next_n = kFar, next_s = kFar;
+  for (int x = xe - 1; x >= xs; --x) {
+    if (m[x] != 255) next_n = x; else next_s = x;
+  }
+  int rn = wave_excl_scan_min_from_right(next_n, kFar), rs = wave_excl_scan_min_from_right(next_s, kFar);
+  for (int x = xe - 1; x >= xs; --x) {
+    if (m[x] != 255) rn = x; else rs = x;
+    gi[x] = min(gi[x], far_to_inf(rn - x));
+    go[x] = min(go[x], far_to_inf(rs - x));
+  }
+}
+
+__global__ __launch_bounds__(64) void sdf_cols_kernel(int W, int rx0, int rx1, int ry0, int ry1,
+                                                      int* __restrict__ g_in, int* __restrict__ g_out) {
+  const int x = rx0 + blockIdx.x * 64 + threadIdx.x;
+  if (x > rx1) return;
+  int ri = kInf, ro = kInf;
+  for (int y = ry0; y <= ry1; ++y) {
+    const int64_t i = (int64_t)y * W + x;
+    ri = min(g_in[i], min(ri + 1, kInf));
+    ro = min(g_out[i], min(ro + 1, kInf));
+    g_in[i] = ri;
+    g_out[i] = ro;
+  }
+  ri = ro = kInf;
+  for (int y = ry1; y >= ry0; --y) {
+    const int64_t i = (int64_t)y * W + x;
+    ri = min(g_in[i], min(ri + 1, kInf));
+    ro = min(g_out[i], min(ro + 1, kInf));
+    g_in[i] = ri;
+    g_out[i] = ro;
+  }
+}
+
+__device__ __forceinline__ float signed_dist(uint8_t m, int din, int dout) {
+  if (m == 255) {
+    float v = din >= kInf ? 3.402823466e+38f : (float)din;
+    if (v > 0) v *= -1;  // voxel_carver.cc:176-182
+    return v;
+  }
+  return dout >= kInf ? 3.402823466e+38f : (float)dout;  // :197-203
+}
+
+// pass 1: raw signed distance into `out` (0 outside the ROI) + max |v| over the ROI
+__global__ __launch_bounds__(256) void sdf_sign_kernel(const uint8_t* __restrict__ mask, int W, int H, int rx0,
+                                                       int rx1, int ry0, int ry1, const int* __restrict__ g_in,
+                                                       const int* __restrict__ g_out, float* __restrict__ out,
+                                                       unsigned* __restrict__ absmax_bits) {
+  __shared__ unsigned sm[256];
+  unsigned local = 0;
+  const int64_t n = (int64_t)W * H;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+    float v = 0.0f;
+    if (x >= rx0 && x <= rx1 && y >= ry0 && y <= ry1) v = signed_dist(mask[i], g_in[i], g_out[i]);
+    out[i] = v;
+    local = max(local, __float_as_uint(fabsf(v)));  // non-negative floats order like their bits
+  }
+  sm[threadIdx.x] = local;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sm[threadIdx.x] = max(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicMax(absmax_bits, sm[0]);
+}
+
+// pass 2: min-max normalisation (:205-222) and truncation (:225-236) inside the ROI
+__global__ __launch_bounds__(256) void sdf_finish_kernel(int W, int H, int rx0, int rx1, int ry0, int ry1,
+                                                         const unsigned* __restrict__ absmax_bits, int normalize,
+                                                         int truncate, float band, float* __restrict__ out) {
+  const float abs_max = __uint_as_float(*absmax_bits);
+  const bool do_norm = normalize && abs_max > 1.17549435e-38f;
+  const float norm = do_norm ? 1.0f / abs_max : 1.0f;
+  const int64_t n = (int64_t)W * H;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+    if (x < rx0 || x > rx1 || y < ry0 || y > ry1) continue;
+    float d = out[i];
+    if (do_norm) d *= norm;
+    if (truncate) d = (-band >= d) ? kInvalidSdf : fminf(1.0f, d / band);
+    out[i] = d;
+  }
+}
+
+}  // namespace
+
+// mask_dev: uint8 [h][w] on the device.  sdf_dev: float [h][w] output.  scratch: 2*w*h ints + 1 word.
+int device_make_sdf(hipStream_t stream, const uint8_t* mask_dev, int w, int h, const int32_t* rmin,
+                    const int32_t* rmax, bool normalize, bool truncate, float band, void* scratch,
+                    float* sdf_dev) {
+  int* g_in = (int*)scratch;
+  int* g_out = g_in + (size_t)w * h;
+  unsigned* absmax = (unsigned*)(g_out + (size_t)w * h);
+  const int rh = rmax[1] - rmin[1] + 1, rw = rmax[0] - rmin[0] + 1;
+  VCY_HIP_CHECK(hipMemsetAsync(absmax, 0, sizeof(unsigned), stream));
+  hipLaunchKernelGGL(sdf_rows_kernel, dim3((rh + 3) / 4), dim3(256), 0, stream, mask_dev, w, rmin[0], rmax[0],
+                     rmin[1], rmax[1], g_in, g_out);
+  hipLaunchKernelGGL(sdf_cols_kernel, dim3((rw + 63) / 64), dim3(64), 0, stream, w, rmin[0], rmax[0], rmin[1],
+                     rmax[1], g_in, g_out);
+  const int grid = (int)std::min<int64_t>(((int64_t)w * h + 255) / 256, 2048);
+  hipLaunchKernelGGL(sdf_sign_kernel, dim3(grid), dim3(256), 0, stream, mask_dev, w, h, rmin[0], rmax[0], rmin[1],
+                     rmax[1], g_in, g_out, sdf_dev, absmax);
+  hipLaunchKernelGGL(sdf_finish_kernel, dim3(grid), dim3(256), 0, stream, w, h, rmin[0], rmax[0], rmin[1],
+                     rmax[1], absmax, normalize ? 1 : 0, truncate ? 1 : 0, band, sdf_dev);
+  VCY_HIP_CHECK(hipGetLastError());
+  return VCY_OK;
+}
+
+size_t device_make_sdf_scratch_bytes(int w, int h) { return sizeof(int) * 2 * (size_t)w * h + 256; }
+
 }  // namespace vcy

@@ -212,6 +212,7 @@ void vcy_destroy(vcy_ctx* c) {
   (void)hipFree(c->d_pz);
   (void)hipFree(c->d_mc_tables);
   (void)hipFree(c->d_mc_scratch);
+  (void)hipFree(c->d_mc_out);
   (void)hipFree(c->d_fused_scratch);
   delete[] c->h_pz;
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
@@ -520,18 +521,70 @@ int vcy_carve_silhouette(vcy_ctx* c, const vcy_view* view, const uint8_t* mask, 
     set_error("null silhouette");
     return VCY_ERR_INVALID_ARG;
   }
-  std::vector<float> tmp;
-  float* sdf = sdf_out;
-  if (!sdf) {
-    tmp.resize((size_t)view->width * view->height);
-    sdf = tmp.data();
-  }
+  VCY_HIP_CHECK(hipSetDevice(c->device));
   const vcy_update_option& u = c->opt.update_option;
+  const size_t npx = (size_t)view->width * view->height;
+  // device staging: [mask u8][sdf f32][transform scratch]
+  const size_t off_sdf = (npx + 255) / 256 * 256;
+  const size_t off_scr = off_sdf + npx * sizeof(float);
+  const size_t need = off_scr + device_make_sdf_scratch_bytes(view->width, view->height);
+  char* d = nullptr;
+  VCY_HIP_CHECK(hipMalloc(&d, need));
+  auto done = [&](int code) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    return code;
+  };
+  if (hipMemcpyAsync(d, mask, npx, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+    set_error("mask upload failed");
+    return done(VCY_ERR_HIP);
+  }
   // MakeSignedDistanceField(silhouette, roi_min, roi_max, sdf, option_.sdf_minmax_normalize,
-  //   use_truncation, truncation_band), reference voxel_carver.cc:405-408
-  host_make_sdf(mask, view->width, view->height, view->roi_min, view->roi_max,
-                c->opt.sdf_minmax_normalize != 0, u.use_truncation != 0, u.truncation_band, sdf);
-  return vcy_carve(c, view, sdf);
+  //   use_truncation, truncation_band), reference voxel_carver.cc:405-408 -- on the device
+  rc = device_make_sdf(c->stream, (const uint8_t*)d, view->width, view->height, view->roi_min, view->roi_max,
+                       c->opt.sdf_minmax_normalize != 0, u.use_truncation != 0, u.truncation_band, d + off_scr,
+                       (float*)(d + off_sdf));
+  if (rc != VCY_OK) return done(rc);
+  if (sdf_out && hipMemcpyAsync(sdf_out, d + off_sdf, npx * sizeof(float), hipMemcpyDeviceToHost, c->stream) !=
+                     hipSuccess) {
+    set_error("sdf download failed");
+    return done(VCY_ERR_HIP);
+  }
+  rc = vcy_carve_device(c, view, (const float*)(d + off_sdf));
+  return done(rc);
+}
+
+int vcy_make_sdf_device(vcy_ctx* c, const uint8_t* mask_host, int w, int h, const int32_t rmin[2],
+                        const int32_t rmax[2], int normalize, int truncate, float band, float** sdf_device_out) {
+  if (!c || !mask_host || !sdf_device_out || w <= 0 || h <= 0 || rmin[0] < 0 || rmin[1] < 0 || rmax[0] >= w ||
+      rmax[1] >= h || rmin[0] > rmax[0] || rmin[1] > rmax[1]) {
+    set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  const size_t npx = (size_t)w * h;
+  char* tmp = nullptr;
+  float* sdf = nullptr;
+  const size_t off_scr = (npx + 255) / 256 * 256;
+  VCY_HIP_CHECK(hipMalloc(&sdf, npx * sizeof(float)));
+  if (hipMalloc(&tmp, off_scr + device_make_sdf_scratch_bytes(w, h)) != hipSuccess) {
+    (void)hipFree(sdf);
+    set_error("out of device memory");
+    return VCY_ERR_HIP;
+  }
+  int rc = VCY_OK;
+  if (hipMemcpyAsync(tmp, mask_host, npx, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = VCY_ERR_HIP;
+  if (rc == VCY_OK)
+    rc = device_make_sdf(c->stream, (const uint8_t*)tmp, w, h, rmin, rmax, normalize != 0, truncate != 0, band,
+                         tmp + off_scr, sdf);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(tmp);
+  if (rc != VCY_OK) {
+    (void)hipFree(sdf);
+    return rc;
+  }
+  *sdf_device_out = sdf;
+  return VCY_OK;
 }
 
 int vcy_distance_transform_l1(const uint8_t* mask, int w, int h, const int32_t rmin[2],

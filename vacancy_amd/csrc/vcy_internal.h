@@ -67,6 +67,8 @@ struct vcy_ctx {
   void* d_mc_tables = nullptr;        // marching-cubes case tables (mc_kernels.hip)
   void* d_mc_scratch = nullptr;       // bit planes, active words, offsets, per-cell info
   size_t mc_scratch_bytes = 0;
+  void* d_mc_out = nullptr;           // device staging of the extracted mesh
+  size_t mc_out_bytes = 0;
   float last_extract_device_ms = 0.0f;
 
   // upper bound on any voxel's update_num (each carved view adds at most one)
@@ -95,6 +97,10 @@ void host_distance_transform_l1(const uint8_t* mask, int w, int h, const int32_t
                                 const int32_t* rmax, float* out);
 void host_make_sdf(const uint8_t* mask, int w, int h, const int32_t* rmin, const int32_t* rmax,
                    bool normalize, bool truncate, float band, float* out);
+int device_make_sdf(hipStream_t stream, const uint8_t* mask_dev, int w, int h, const int32_t* rmin,
+                    const int32_t* rmax, bool normalize, bool truncate, float band, void* scratch,
+                    float* sdf_dev);
+size_t device_make_sdf_scratch_bytes(int w, int h);
 // utility kernels (vcy_api.hip)
 int fill_state(vcy_ctx* ctx);
 

@@ -139,10 +139,10 @@ bool VoxelCarver::Carve(const std::vector<const Camera*>& cameras, const std::ve
     const Image1b& s = silhouettes[i];
     const int32_t rmin[2] = {0, 0}, rmax[2] = {s.width() - 1, s.height() - 1};
     views[i] = ToView(*cameras[i], Eigen::Vector2i(0, 0), Eigen::Vector2i(rmax[0], rmax[1]), s.width(), s.height());
-    std::vector<float> sdf(static_cast<size_t>(s.width()) * s.height());
-    ok = vcy_make_sdf(s.data().data(), s.width(), s.height(), rmin, rmax, o.sdf_minmax_normalize,
-                      o.update_option.use_truncation, o.update_option.truncation_band, sdf.data()) == VCY_OK &&
-         vcy_sdf_upload(impl_->ctx, sdf.data(), s.width(), s.height(), &dev[i]) == VCY_OK;
+    // MakeSignedDistanceField on the device: only the 8-bit mask crosses PCIe
+    ok = vcy_make_sdf_device(impl_->ctx, s.data().data(), s.width(), s.height(), rmin, rmax,
+                             o.sdf_minmax_normalize, o.update_option.use_truncation,
+                             o.update_option.truncation_band, &dev[i]) == VCY_OK;
   }
   if (ok) ok = vcy_carve_batch_device(impl_->ctx, n, views.data(), dev.data()) == VCY_OK;
   if (!ok) LOGE("%s\n", vcy_last_error());
