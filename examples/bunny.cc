@@ -73,6 +73,9 @@ int main(int argc, char* argv[]) {
     vis.WritePng(out_dir + "/sdf_" + num + ".png");
 
     vacancy::Mesh mesh;
+    carver.ExtractVoxel(&mesh);  // cube per voxel: large and slow to write, like the reference says
+    mesh.WritePlyBinary(out_dir + "/voxel_" + num + ".ply");
+    const size_t voxel_verts = mesh.vertices().size();
     carver.ExtractIsoSurface(&mesh, 0.0);
     mesh.WritePly(out_dir + "/surface_" + num + ".ply");
     const size_t nv = mesh.vertices().size(), nf = mesh.vertex_indices().size();
@@ -81,8 +84,9 @@ int main(int argc, char* argv[]) {
       for (int k = 0; k < 3; ++k) sum[k] += v[k];
     carver.ExtractIsoSurface(&mesh, 0.0, false);
     mesh.WritePly(out_dir + "/surface_nointerp_" + num + ".ply");
-    std::printf("RESULT view %zu verts %zu faces %zu nointerp_verts %zu nointerp_faces %zu vsum %.6f %.6f %.6f\n", i,
-                nv, nf, mesh.vertices().size(), mesh.vertex_indices().size(), sum[0], sum[1], sum[2]);
+    std::printf("RESULT view %zu verts %zu faces %zu nointerp_verts %zu nointerp_faces %zu vsum %.6f %.6f %.6f "
+                "voxel_verts %zu\n",
+                i, nv, nf, mesh.vertices().size(), mesh.vertex_indices().size(), sum[0], sum[1], sum[2], voxel_verts);
   }
   return 0;
 }

@@ -161,6 +161,11 @@ int vcy_make_sdf_device(vcy_ctx* ctx, const uint8_t* mask_host, int width, int h
  * reference's serial scan (first reference in z,y,x order). */
 int vcy_extract_iso(vcy_ctx* ctx, double iso_level, int linear_interp,
                     vcy_mesh* out);
+/* Replaces void VoxelCarver::ExtractVoxel(Mesh*, bool inside_empty) (voxel_carver.cc:530-538 ->
+ * extract_voxel.cc:258-317): one cube (24 vertices, 12 triangles) per kept voxel.  Runs on the
+ * host on the downloaded state (the reference's drifting-cube arithmetic is serial by
+ * construction); needs the whole grid in one context.  edge_keys is unused. */
+int vcy_extract_voxel(vcy_ctx* ctx, int inside_empty, vcy_mesh* out);
 void vcy_mesh_free(vcy_mesh* mesh);
 /* Milliseconds the device kernels of the last vcy_extract_iso took (hipEvents on the
  * context's stream: classify + owner + scan + emit; the mesh download is not included).

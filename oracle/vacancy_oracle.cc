@@ -575,6 +575,67 @@ double orc_marching_cubes_slab(const orc_grid* g, double iso, int linear_interp,
   return ms;
 }
 
+/* ------------------------------------------------------------ ExtractVoxel -- */
+// src/vacancy/extract_voxel.cc:15-79 (UpdateOnSurface), :258-317 (ExtractVoxel) and
+// src/vacancy/mesh.cc:728-798 (MakeCube; R = I, t = 0 leave the corners at +-h exactly).
+double orc_extract_voxel(orc_grid* g, int inside_empty, vcy_mesh* out) {
+  const double t0 = now_ms();
+  const int nx = g->n[0], ny = g->n[1], nz = g->n[2];
+  const float h = g->resolution / 2;
+  float cube[24][3];
+  auto set = [&](int i, float x, float y, float z) { cube[i][0] = x; cube[i][1] = y; cube[i][2] = z; };
+  auto cpy = [&](int i, int j) { for (int k = 0; k < 3; ++k) cube[i][k] = cube[j][k]; };
+  set(0, -h, h, -h); set(1, h, h, -h); set(2, h, h, h); set(3, -h, h, h);
+  set(4, -h, -h, -h); set(5, h, -h, -h); set(6, h, -h, h); set(7, -h, -h, h);
+  cpy(8, 1); cpy(9, 2); cpy(10, 6); cpy(11, 5);
+  cpy(12, 0); cpy(13, 3); cpy(14, 7); cpy(15, 4);
+  cpy(16, 0); cpy(17, 1); cpy(18, 5); cpy(19, 4);
+  cpy(20, 3); cpy(21, 2); cpy(22, 6); cpy(23, 7);
+  static const int kFaces[12][3] = {{0, 2, 1}, {0, 3, 2}, {4, 5, 6}, {4, 6, 7}, {8, 9, 10}, {8, 10, 11},
+                                    {12, 14, 13}, {12, 15, 14}, {16, 17, 18}, {16, 18, 19}, {20, 22, 21}, {20, 23, 22}};
+  if (inside_empty) {
+    for (Voxel& v : g->voxels) v.on_surface = false;  // ResetOnSurface
+    constexpr float e = std::numeric_limits<float>::min();
+    auto visit = [&](const Voxel& prev, Voxel* v) {
+      if (v->update_num < 1 || prev.update_num < 1) return;
+      if (v->sdf * prev.sdf < 0) v->on_surface = true;
+      if (std::abs(v->sdf) < e) v->on_surface = true;
+    };
+    for (int z = 0; z < nz; z++) for (int y = 0; y < ny; y++) for (int x = 1; x < nx; x++)
+      visit(g->get(x - 1, y, z), g->get_ptr(x, y, z));
+    for (int z = 0; z < nz; z++) for (int x = 0; x < nx; x++) for (int y = 1; y < ny; y++)
+      visit(g->get(x, y - 1, z), g->get_ptr(x, y, z));
+    for (int y = 0; y < ny; y++) for (int x = 0; x < nx; x++) for (int z = 1; z < nz; z++)
+      visit(g->get(x, y, z - 1), g->get_ptr(x, y, z));
+  }
+  std::vector<float> verts;
+  std::vector<int> faces;
+  for (int z = 0; z < nz; z++)
+    for (int y = 0; y < ny; y++)
+      for (int x = 0; x < nx; x++) {
+        const Voxel& v = g->get(x, y, z);
+        if (inside_empty) {
+          if (!v.on_surface) continue;
+        } else if (v.sdf > 0 || v.update_num < 1) {
+          continue;
+        }
+        for (int i = 0; i < 24; ++i) for (int k = 0; k < 3; ++k) cube[i][k] += v.pos[k];     // Translate(pos)
+        const int off = (int)(verts.size() / 3);
+        for (int i = 0; i < 24; ++i) for (int k = 0; k < 3; ++k) verts.push_back(cube[i][k]);
+        for (int i = 0; i < 12; ++i) for (int k = 0; k < 3; ++k) faces.push_back(kFaces[i][k] + off);
+        for (int i = 0; i < 24; ++i) for (int k = 0; k < 3; ++k) cube[i][k] += -v.pos[k];    // Translate(-pos)
+      }
+  out->n_vertices = (int64_t)(verts.size() / 3);
+  out->n_faces = (int64_t)(faces.size() / 3);
+  out->n_foreign_vertices = 0;
+  out->vertices = (float*)std::malloc(sizeof(float) * std::max<size_t>(3, verts.size()));
+  out->faces = (int32_t*)std::malloc(sizeof(int32_t) * std::max<size_t>(3, faces.size()));
+  out->edge_keys = (int64_t*)std::malloc(sizeof(int64_t) * 2);
+  std::memcpy(out->vertices, verts.data(), sizeof(float) * verts.size());
+  std::memcpy(out->faces, faces.data(), sizeof(int32_t) * faces.size());
+  return now_ms() - t0;
+}
+
 void orc_mesh_free(vcy_mesh* m) {
   std::free(m->vertices);
   std::free(m->faces);

@@ -58,6 +58,8 @@ double orc_marching_cubes(const orc_grid* g, double iso_level, int linear_interp
  * a ghost layer (what one rank of the multi-GPU path computes); see the .cc. */
 double orc_marching_cubes_slab(const orc_grid* g, double iso_level, int linear_interp,
                                int z_begin, int z_end, vcy_mesh* out);
+/* ExtractVoxel(), extract_voxel.cc:258-317 (cube per kept voxel; edge_keys unused). */
+double orc_extract_voxel(orc_grid* g, int inside_empty, vcy_mesh* out);
 void orc_mesh_free(vcy_mesh* m);
 
 /* Pose arithmetic of the harness (Eigen operations restated, see .cc). */

@@ -44,6 +44,8 @@ def load():
     lib.orc_marching_cubes.argtypes = [vp, C.c_double, C.c_int, P(Mesh)]
     lib.orc_marching_cubes_slab.restype = C.c_double
     lib.orc_marching_cubes_slab.argtypes = [vp, C.c_double, C.c_int, C.c_int, C.c_int, P(Mesh)]
+    lib.orc_extract_voxel.restype = C.c_double
+    lib.orc_extract_voxel.argtypes = [vp, C.c_int, P(Mesh)]
     lib.orc_mesh_free.argtypes = [P(Mesh)]
     lib.orc_pose_from_tum.argtypes = [vp, vp, vp]
     lib.orc_affine_inverse.argtypes = [vp, vp]
@@ -109,6 +111,15 @@ class OracleGrid:
         p = np.empty((self.n, 3), np.float32)
         self.lib.orc_grid_positions(self.h, _p(p))
         return p
+
+    def extract_voxel(self, inside_empty=False):
+        m = Mesh()
+        self.lib.orc_extract_voxel(self.h, int(inside_empty), C.byref(m))
+        nv, nf = m.n_vertices, m.n_faces
+        out = {"vertices": np.ctypeslib.as_array(m.vertices, shape=(max(nv, 1) * 3,))[: nv * 3].reshape(nv, 3).copy(),
+               "faces": np.ctypeslib.as_array(m.faces, shape=(max(nf, 1) * 3,))[: nf * 3].reshape(nf, 3).copy()}
+        self.lib.orc_mesh_free(C.byref(m))
+        return out
 
     def marching_cubes(self, iso=0.0, linear_interp=True):
         m = Mesh()

@@ -53,9 +53,15 @@ def test_bunny_all_views(mode):
         for interp in (True, False):
             assert_mesh_equal(dev.ExtractIsoSurface(0.0, interp), orc.marching_cubes(0.0, interp),
                               "%s view %d interp=%s" % (mode, i, interp))
+    for inside_empty in (False, True):
+        dv, ov = dev.ExtractVoxel(inside_empty), orc.extract_voxel(inside_empty)
+        assert np.array_equal(dv["faces"], ov["faces"])
+        assert np.array_equal(dv["vertices"].view(np.uint32), ov["vertices"].view(np.uint32))
     if mode == "default":
         m = dev.ExtractIsoSurface(0.0, True)
         assert (len(m["vertices"]), len(m["faces"])) == (8672, 17270)
+        v = dev.ExtractVoxel(False)
+        assert (len(v["vertices"]), len(v["faces"])) == (683400, 341700)
 
 
 def test_bunny_fine_grid():
@@ -278,6 +284,7 @@ def test_cpp_bunny_example(tmp_path):
         exp = gold["modes"]["default"][i]
         assert (int(r[4]), int(r[6])) == (exp[5], exp[6]), (i, r)
     assert (int(rows[5][8]), int(rows[5][10])) == tuple(gold["final_nointerp"])
+    assert int(rows[5][16]) == 683400  # ExtractVoxel, SURVEY Appendix C
     vsum = [float(x) for x in rows[5][12:15]]
     assert np.allclose(vsum, gold["final_vertex_sums"], rtol=0, atol=1e-4)
     # ASCII PLY in the reference's format

@@ -73,6 +73,8 @@ def test_per_view_known_answers(mode, views, masks):
                                    GOLD["final_vertex_sums"], rtol=0, atol=1e-5)
         m2 = g.marching_cubes(0.0, False)
         assert [len(m2["vertices"]), len(m2["faces"])] == GOLD["final_nointerp"]
+        ev = g.extract_voxel(False)  # ExtractVoxel: 28 475 cubes x 24 / 12 (Appendix C)
+        assert (len(ev["vertices"]), len(ev["faces"])) == (683400, 341700)
         assert fnv1a64(g.positions()) == GOLD["fnv1a64"]["res10_pos"]
         assert fnv1a64(s) == GOLD["fnv1a64"]["res10_sdf"]
 

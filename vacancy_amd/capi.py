@@ -122,6 +122,7 @@ def load():
         "vcy_make_sdf_device": (C.c_int, [vp, vp, C.c_int, C.c_int, P(C.c_int32), P(C.c_int32),
                                           C.c_int, C.c_int, C.c_float, P(vp)]),
         "vcy_extract_iso": (C.c_int, [vp, C.c_double, C.c_int, P(Mesh)]),
+        "vcy_extract_voxel": (C.c_int, [vp, C.c_int, P(Mesh)]),
         "vcy_mesh_free": (None, [P(Mesh)]),
         "vcy_last_extract_ms": (C.c_int, [vp, P(C.c_float)]),
         "vcy_download": (C.c_int, [vp, vp, vp]),

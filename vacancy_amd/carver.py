@@ -146,6 +146,21 @@ class VoxelCarver:
         out["device_ms"] = ms.value
         return out
 
+    # -- ExtractVoxel(mesh, inside_empty)  (voxel_carver.cc:530-538)
+    def ExtractVoxel(self, inside_empty=False):
+        m = Mesh()
+        rc = self._lib.vcy_extract_voxel(self._ctx, int(inside_empty), C.byref(m))
+        if rc != 0:
+            self._lib.vcy_mesh_free(C.byref(m))
+            raise RuntimeError(last_error())
+        nv, nf = m.n_vertices, m.n_faces
+        out = {
+            "vertices": np.ctypeslib.as_array(m.vertices, shape=(max(nv, 1) * 3,))[: nv * 3].reshape(nv, 3).copy(),
+            "faces": np.ctypeslib.as_array(m.faces, shape=(max(nf, 1) * 3,))[: nf * 3].reshape(nf, 3).copy(),
+        }
+        self._lib.vcy_mesh_free(C.byref(m))
+        return out
+
     # -- state access
     def download(self):
         n = self.slab_voxels

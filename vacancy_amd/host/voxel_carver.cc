@@ -174,11 +174,23 @@ void VoxelCarver::ExtractIsoSurface(Mesh* mesh, double iso_level, bool linear_in
 }
 
 void VoxelCarver::ExtractVoxel(Mesh* mesh, bool inside_empty) {
-  (void)inside_empty;
-  // The cube-per-voxel visualisation mesh (reference extract_voxel.cc) is a host-side consumer
-  // of the grid state and not part of the accelerated path yet.
   mesh->Clear();
-  LOGW("VoxelCarver::ExtractVoxel is not available in this build; use Download() for the voxel state\n");
+  if (!impl_->ctx) return;
+  const double t0 = NowMs();
+  vcy_mesh m;
+  if (vcy_extract_voxel(impl_->ctx, inside_empty ? 1 : 0, &m) != VCY_OK) {
+    LOGE("%s\n", vcy_last_error());
+    vcy_mesh_free(&m);
+    return;
+  }
+  std::vector<Eigen::Vector3f>* v = mesh->mutable_vertices();
+  std::vector<Eigen::Vector3i>* f = mesh->mutable_vertex_indices();
+  v->resize(static_cast<size_t>(m.n_vertices));
+  f->resize(static_cast<size_t>(m.n_faces));
+  if (m.n_vertices) std::memcpy(static_cast<void*>(v->data()), m.vertices, sizeof(float) * 3 * m.n_vertices);
+  if (m.n_faces) std::memcpy(static_cast<void*>(f->data()), m.faces, sizeof(int) * 3 * m.n_faces);
+  vcy_mesh_free(&m);
+  LOGI("VoxelCarver::ExtractVoxel %02f\n", NowMs() - t0);
 }
 
 Eigen::Vector3i VoxelCarver::voxel_num() const {
