@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="1: fused multi-view carve; 0: one launch per view")
     ap.add_argument("--cull", type=int, default=1,
                     help="1: drop (brick, view) pairs that provably cannot change the brick (results identical)")
+    ap.add_argument("--slabs-per-gpu", type=int, default=0,
+                    help="z-slabs per GPU, dealt cyclically (0: 1 on one GPU, 2 on several -- evens out "
+                         "the data-dependent cost of view dropping)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -120,12 +123,19 @@ def main():
     sdf0 = vc.make_sdf(masks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
     sdfs = [sdf0] * nv  # every view sees the same centred disc; the cameras differ
 
-    z0, z1 = vdist.slab_range(n, rank, world)
-    dev = vc.VoxelCarver(opt, device_id=local_rank, z_range=(z0, z1))
-    if not dev.Init():
-        raise SystemExit("vcy_create failed: " + vc.last_error())
-    dev.set_param("fused", args.batch)
-    dev.set_param("cull", args.cull)
+    k_slabs = args.slabs_per_gpu if args.slabs_per_gpu > 0 else (1 if world == 1 else 2)
+    my_slabs = vdist.slabs_of_rank(n, rank, world, k_slabs)
+    devs = []
+    for _, z0, z1 in my_slabs:
+        c = vc.VoxelCarver(opt, device_id=local_rank, z_range=(z0, z1))
+        if not c.Init():
+            raise SystemExit("vcy_create failed: " + vc.last_error())
+        if devs:
+            c.use_stream_of(devs[0])  # one stream per GPU: slabs run back to back
+        c.set_param("fused", args.batch)
+        c.set_param("cull", args.cull)
+        devs.append(c)
+    dev = devs[0]
     d_sdf = [dev.upload_sdf(s) for s in sdfs]  # inputs resident in HBM before the timed region
 
     def barrier():
@@ -137,9 +147,10 @@ def main():
     kernel_ms = []
 
     def step(record):
-        dev.reset()
+        for c in devs:
+            c.reset()
         dev.timer_begin()
-        ok = dev.CarveBatchDevice(views, d_sdf)
+        ok = all(c.CarveBatchDevice(views, d_sdf) for c in devs)
         ms = dev.timer_end()
         if not ok:
             raise SystemExit("carve failed: " + vc.last_error())
@@ -165,8 +176,8 @@ def main():
     # roofline of the dominant kernel (carve), this rank's slab: algorithmic bytes per launch /
     # launch duration from HIP events on the launch stream.
     bytes_per_vv = 4.0 if args.mode == "default" else 4.0 + (1 if uo.voxel_max_update_num <= 254 else 2)
-    slab_vox = dev.slab_voxels
-    launches_per_step = 1 if args.batch else nv
+    slab_vox = sum(c.slab_voxels for c in devs) / float(len(devs))  # per launch
+    launches_per_step = (1 if args.batch else nv) * len(devs)
     views_per_launch = nv if args.batch else 1
     avg_launch_ms = sum(kernel_ms) / len(kernel_ms) / launches_per_step
     achieved = slab_vox * views_per_launch * bytes_per_vv / (avg_launch_ms * 1e-3) / 1e9
@@ -188,12 +199,14 @@ def main():
     # marching cubes (second half of the metric), outside the timed region
     mc = None
     if not args.no_mc:
-        vdist.exchange_halo(dev, rank, world)
-        mesh = dev.ExtractIsoSurface(0.0, True)
-        mesh = dev.ExtractIsoSurface(0.0, True)  # second run: scratch allocation warmed
-        cells_local = (n - 1) * (n - 1) * (z1 - max(z0, 1))
-        mc_ms = mesh["device_ms"]
-        nvert, nface = len(mesh["vertices"]) - mesh["n_foreign"], len(mesh["faces"])
+        vdist.exchange_halo(devs, rank, world)
+        mc_ms, nvert, nface = 0.0, 0, 0
+        for c in devs:
+            mesh = c.ExtractIsoSurface(0.0, True)
+            mesh = c.ExtractIsoSurface(0.0, True)  # second run: scratch allocation warmed
+            mc_ms += mesh["device_ms"]
+            nvert += len(mesh["vertices"]) - mesh["n_foreign"]
+            nface += len(mesh["faces"])
         if dist is not None:
             t = torch.tensor([mc_ms, float(nvert), float(nface)], dtype=torch.float64, device=red_dev)
             tmax = t.clone()
@@ -204,7 +217,6 @@ def main():
         mc = {"mcells_per_s": round(cells / (mc_ms * 1e-3) / 1e6, 1), "device_ms": round(mc_ms, 3),
               "vertices": int(nvert), "faces": int(nface),
               "roofline_frac": round(cells * 4.0 / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        del cells_local
 
     out = {
         "metric": "Mvoxel*views/s (Carve)", "value": round(value, 1), "unit": "Mvoxel*views/s",
@@ -214,7 +226,8 @@ def main():
         "config": {"workload": "%d^3 grid x %d views at %dx%d, %s mode, z-slab sharded over %d GPU(s)"
                                % (n, nv, args.width, args.height, args.mode, world),
                    "grid": n, "views": nv, "image": [args.width, args.height], "mode": args.mode,
-                   "fused_views_per_launch": views_per_launch, "view_dropping": bool(args.cull)},
+                   "fused_views_per_launch": views_per_launch, "view_dropping": bool(args.cull),
+                   "slabs_per_gpu": k_slabs},
         "roofline": roofline, "mc": mc,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -223,7 +236,8 @@ def main():
         print(json.dumps(out))
     for p in d_sdf:
         dev.free_device(p)
-    dev.close()
+    for c in reversed(devs):
+        c.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -193,6 +193,9 @@ int vcy_halo_pack(vcy_ctx* ctx, void* send_device);
 /* Installs the neighbours' slices from the all-gathered buffer
  * (world * vcy_halo_bytes bytes, rank-major). */
 int vcy_halo_unpack(vcy_ctx* ctx, const void* gathered_device, int rank, int world);
+/* Same, given directly the pack (vcy_halo_bytes bytes, device) of the slab that ends at this
+ * context's z_begin -- for layouts where slabs are not ordered by rank (several slabs per GPU). */
+int vcy_halo_install(vcy_ctx* ctx, const void* prev_slab_pack_device);
 
 /* ---- device memory / stream / timing helpers ----------------------------- */
 
@@ -211,6 +214,7 @@ int vcy_reset(vcy_ctx* ctx);
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all launches. */
 int vcy_set_stream(vcy_ctx* ctx, void* hip_stream);
+int vcy_get_stream(vcy_ctx* ctx, void** hip_stream_out);
 int vcy_sync(vcy_ctx* ctx);
 /* hipEvent pair recorded on the context's stream around whatever is launched
  * between begin and end; vcy_timer_end synchronises and returns milliseconds. */

@@ -19,6 +19,7 @@ def test_slab_range_partitions_the_grid():
             if nz < 2 * world:
                 continue
             r = [vdist.slab_range(nz, k, world) for k in range(world)]
+            assert [z for _, *z in vdist.slabs_of_rank(nz, 0, 1, world)] == [list(x) for x in r]
             assert r[0][0] == 0 and r[-1][1] == nz
             for a, b in zip(r, r[1:]):
                 assert a[1] == b[0]
@@ -29,25 +30,31 @@ def test_slab_range_partitions_the_grid():
 class FakeSlabCarver:
     """Host stand-in with the halo interface of vacancy_amd.carver.VoxelCarver."""
 
+    class _Lib:
+        def __init__(self, nbytes):
+            self._n = nbytes
+
+        def vcy_halo_bytes(self, ctx):
+            return self._n
+
     def __init__(self, sdf, cnt, z0, z1, slice_voxels):
         self.sdf, self.cnt = sdf, cnt
         self.z0, self.z1, self.s = z0, z1, slice_voxels
         self.halo = None
+        self.ctx = None
+        self._lib = FakeSlabCarver._Lib(2 * slice_voxels * 6)
 
     def halo_pack_host(self):
         a = self.sdf[(self.z1 - 2) * self.s:self.z1 * self.s].astype(np.float32).tobytes()
         b = self.cnt[(self.z1 - 2) * self.s:self.z1 * self.s].astype(np.uint16).tobytes()
         return np.frombuffer(a + b, np.uint8).copy()
 
-    def halo_unpack_host(self, gathered, rank, world):
-        n = len(gathered) // world
-        if rank == 0:
-            return
-        part = gathered[(rank - 1) * n:rank * n].tobytes()
+    def halo_install_host(self, pack):
+        part = np.ascontiguousarray(pack, np.uint8).tobytes()
         self.halo = (np.frombuffer(part[:2 * self.s * 4], np.float32), np.frombuffer(part[2 * self.s * 4:], np.uint16))
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, k, ret):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -58,29 +65,27 @@ def _worker(rank, world, port, ret):
         for i in range(6):
             g.carve(views[i], O.make_sdf(masks[i]))
         nx, ny, nz = g.dims
-        z0, z1 = vdist.slab_range(nz, rank, world)
         sdf, cnt = g.download()
+        slabs = vdist.slabs_of_rank(nz, rank, world, k)
+        assert [s for s, _, _ in slabs] == list(range(rank, world * k, world))
         # halo exchange through the real collective code path (gloo branch)
-        fake = FakeSlabCarver(sdf, cnt, z0, z1, nx * ny)
-
-        class Shim:  # what exchange_halo needs from the carver
-            _lib = None
-            ctx = None
-        shim = Shim()
-        shim.halo_pack_host = fake.halo_pack_host
-        shim.halo_unpack_host = fake.halo_unpack_host
-        shim._lib = type("L", (), {"vcy_halo_bytes": staticmethod(lambda ctx: 2 * nx * ny * 6)})()
-        vdist.exchange_halo(shim, rank, world)
-        if rank > 0:
-            hs, hc = fake.halo
+        fakes = [FakeSlabCarver(sdf, cnt, z0, z1, nx * ny) for _, z0, z1 in slabs]
+        vdist.exchange_halo(fakes, rank, world)
+        for (sid, z0, z1), f in zip(slabs, fakes):
+            if sid == 0:
+                assert f.halo is None
+                continue
+            hs, hc = f.halo
             assert np.array_equal(hs, sdf[(z0 - 2) * nx * ny:z0 * nx * ny])
             assert np.array_equal(hc, cnt[(z0 - 2) * nx * ny:z0 * nx * ny].astype(np.uint16))
-        # per-rank extraction + gather + merge on rank 0
-        mine = O.marching_cubes_slab(g, z0, z1)
+        # per-slab extraction + gather + merge on rank 0
+        mine = [(sid, O.marching_cubes_slab(g, z0, z1)) for sid, z0, z1 in slabs]
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         if rank == 0:
-            merged = vdist.merge_meshes(gathered)
+            by_slab = sorted((item for part in gathered for item in part), key=lambda t: t[0])
+            assert [s for s, _ in by_slab] == list(range(world * k))
+            merged = vdist.merge_meshes([m for _, m in by_slab])
             full = g.marching_cubes()
             ok = (np.array_equal(merged["vertices"].view(np.uint32), full["vertices"].view(np.uint32))
                   and np.array_equal(merged["faces"], full["faces"]) and np.array_equal(merged["keys"], full["keys"]))
@@ -90,8 +95,8 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_slab_sharded_extraction_merges_to_the_serial_mesh(world):
+@pytest.mark.parametrize("world,k", [(2, 1), (3, 1), (2, 2)])
+def test_slab_sharded_extraction_merges_to_the_serial_mesh(world, k):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -99,6 +104,6 @@ def test_slab_sharded_extraction_merges_to_the_serial_mesh(world):
     s.close()
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, k, ret), nprocs=world, join=True)
         assert ret.get("ok") is True
         assert ret["nv"] == 8672

@@ -131,6 +131,7 @@ def load():
         "vcy_halo_bytes": (C.c_int64, [vp]),
         "vcy_halo_pack": (C.c_int, [vp, vp]),
         "vcy_halo_unpack": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+        "vcy_halo_install": (C.c_int, [vp, vp]),
         "vcy_device_count": (C.c_int, [P(C.c_int)]),
         "vcy_sdf_upload": (C.c_int, [vp, vp, C.c_int, C.c_int, P(vp)]),
         "vcy_device_free": (C.c_int, [vp, vp]),
@@ -140,6 +141,7 @@ def load():
         "vcy_reset": (C.c_int, [vp]),
         "vcy_set_param": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "vcy_set_stream": (C.c_int, [vp, vp]),
+        "vcy_get_stream": (C.c_int, [vp, P(vp)]),
         "vcy_sync": (C.c_int, [vp]),
         "vcy_timer_begin": (C.c_int, [vp]),
         "vcy_timer_end": (C.c_int, [vp, P(C.c_float)]),

@@ -207,6 +207,21 @@ class VoxelCarver:
         assert self._lib.vcy_halo_unpack(self._ctx, dev, rank, world) == 0, last_error()
         self._lib.vcy_device_free(self._ctx, dev)
 
+    def halo_install_host(self, pack):
+        import ctypes as C_
+        pack = np.ascontiguousarray(pack, np.uint8)
+        dev = C_.c_void_p()
+        assert self._lib.vcy_device_alloc(self._ctx, pack.nbytes, C_.byref(dev)) == 0, last_error()
+        assert self._lib.vcy_memcpy_h2d(self._ctx, dev, _p(pack), pack.nbytes) == 0, last_error()
+        assert self._lib.vcy_halo_install(self._ctx, dev) == 0, last_error()
+        self._lib.vcy_device_free(self._ctx, dev)
+
+    def use_stream_of(self, other):
+        """Launch on another context's stream (several slabs of one GPU in sequence)."""
+        st = C.c_void_p()
+        assert self._lib.vcy_get_stream(other._ctx, C.byref(st)) == 0, last_error()
+        assert self._lib.vcy_set_stream(self._ctx, st) == 0, last_error()
+
     def set_param(self, name, value):
         assert self._lib.vcy_set_param(self._ctx, name.encode(), int(value)) == 0, last_error()
 

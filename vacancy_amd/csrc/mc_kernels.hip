@@ -142,27 +142,29 @@ __global__ __launch_bounds__(256) void mc_bits_kernel(const float* __restrict__ 
   const int lane = threadIdx.x & 63;
   const int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kBitsWordsPerWave;
   if (first >= nwords) return;
+  // (row, word-in-row) of the first word by one division, the rest by stepping
+  int64_t row = first / Wr;
+  int w = (int)(first - row * Wr);
   float s[kBitsWordsPerWave];
   int n[kBitsWordsPerWave];
+  bool live[kBitsWordsPerWave];
 #pragma unroll
   for (int k = 0; k < kBitsWordsPerWave; ++k) {
-    const int64_t word = first + k;
-    const int64_t row = word / Wr;
-    const int x = (int)(word - row * Wr) * 64 + lane;
-    const bool live = word < nwords && x < nx;
-    s[k] = live ? sdf[row * nx + x] : kInvalidSdf;
-    n[k] = live ? (int)cnt[row * nx + x] : 0;
+    const int x = w * 64 + lane;
+    live[k] = first + k < nwords && x < nx;
+    s[k] = live[k] ? sdf[row * nx + x] : kInvalidSdf;
+    n[k] = live[k] ? (int)cnt[row * nx + x] : 0;
+    if (++w == Wr) {
+      w = 0;
+      ++row;
+    }
   }
   u64 m_in = 0, m_ok = 0, m_tc = 0;
 #pragma unroll
   for (int k = 0; k < kBitsWordsPerWave; ++k) {
-    const int64_t word = first + k;
-    const int64_t row = word / Wr;
-    const int x = (int)(word - row * Wr) * 64 + lane;
-    const bool live = word < nwords && x < nx;
-    const u64 a = __ballot(live && (double)s[k] < iso);
-    const u64 b = __ballot(live && s[k] != kInvalidSdf);
-    const u64 c = __ballot(live && n[k] >= 1);
+    const u64 a = __ballot(live[k] && (double)s[k] < iso);
+    const u64 b = __ballot(live[k] && s[k] != kInvalidSdf);
+    const u64 c = __ballot(live[k] && n[k] >= 1);
     if (lane == k) {
       m_in = a;
       m_ok = b;

@@ -260,6 +260,12 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
   return VCY_ERR_INVALID_ARG;
 }
 
+int vcy_get_stream(vcy_ctx* c, void** out) {
+  if (!c || !out) return VCY_ERR_INVALID_ARG;
+  *out = (void*)c->stream;
+  return VCY_OK;
+}
+
 int vcy_sync(vcy_ctx* c) {
   if (!c) return VCY_ERR_NOT_INITIALIZED;
   VCY_HIP_CHECK(hipSetDevice(c->device));
@@ -432,6 +438,23 @@ int vcy_halo_pack(vcy_ctx* c, void* send) {
   VCY_HIP_CHECK(hipMemcpyAsync(send, sdf_src, 2 * s * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
   VCY_HIP_CHECK(hipMemcpyAsync((char*)send + 2 * s * sizeof(float), cnt_src, 2 * s * c->cnt_bytes,
                                hipMemcpyDeviceToDevice, c->stream));
+  return VCY_OK;
+}
+
+int vcy_halo_install(vcy_ctx* c, const void* prev_pack) {
+  if (!c) return VCY_ERR_INVALID_ARG;
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  if (c->halo_lo == 0) {
+    c->halo_valid = true;  // first slab: nothing below
+    return VCY_OK;
+  }
+  if (!prev_pack) return VCY_ERR_INVALID_ARG;
+  const int64_t s = c->slice;
+  const char* src = (const char*)prev_pack;
+  VCY_HIP_CHECK(hipMemcpyAsync(c->d_sdf, src, 2 * s * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  VCY_HIP_CHECK(hipMemcpyAsync(c->d_cnt, src + 2 * s * sizeof(float), 2 * s * c->cnt_bytes,
+                               hipMemcpyDeviceToDevice, c->stream));
+  c->halo_valid = true;
   return VCY_OK;
 }
 

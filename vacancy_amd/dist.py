@@ -1,58 +1,95 @@
 """z-slab sharding of the voxel grid across the GPUs of one node (one process per GPU).
 
 Carving needs no communication: voxels are independent (reference voxel_carver.cc:442-491
-touches only its own voxel) and z is the slowest index, so rank r owns the contiguous slab
-z in [r*nz/G, (r+1)*nz/G).  Marching cubes needs the two slices below each slab: ONE
-all-gather of every rank's last two slices (RCCL when the backend is nccl), after which
-every rank extracts its own cells.  The per-rank meshes are stitched on the host by edge key.
+touches only its own voxel) and z is the slowest index, so a contiguous z-range is one slab of
+HBM.  The grid is cut into S = world * k slabs and slab s belongs to rank s % world (cyclic):
+with k = 1 every rank owns one slab; k = 2 pairs an outer slab with a central one, which evens
+out the data-dependent cost of view dropping (bricks far from the object finish early).
+Marching cubes needs the two slices below each slab: ONE all-gather of every slab's last two
+slices (RCCL when the backend is nccl), after which every slab is extracted on its own GPU.
+The per-slab meshes are stitched on the host by edge key (merge_meshes).
 """
 import ctypes as C
 
 import numpy as np
 
 
-def slab_range(nz, rank, world):
-    """Contiguous z-range of `rank`; the first nz % world ranks get one extra slice."""
-    base, rem = divmod(nz, world)
-    z0 = rank * base + min(rank, rem)
-    z1 = z0 + base + (1 if rank < rem else 0)
+def slab_range(nz, index, count):
+    """Contiguous z-range of slab `index` of `count`; the first nz % count slabs get one extra."""
+    base, rem = divmod(nz, count)
+    z0 = index * base + min(index, rem)
+    z1 = z0 + base + (1 if index < rem else 0)
     return z0, z1
 
 
-def exchange_halo(carver, rank, world):
-    """Installs rank-1's last two slices as this rank's halo.  world == 1: nothing to do."""
-    lib = carver._lib
+def slabs_of_rank(nz, rank, world, k=1):
+    """[(slab_id, z0, z1)] owned by `rank` under the cyclic distribution."""
+    count = world * k
+    return [(s, *slab_range(nz, s, count)) for s in range(rank, count, world)]
+
+
+def _pack_offset(slab_id, world, k, nbytes):
+    """Offset of slab `slab_id`'s pack in the rank-major all-gather output."""
+    rank, kk = slab_id % world, slab_id // world
+    return (rank * k + kk) * nbytes
+
+
+def exchange_halo(carvers, rank, world):
+    """carvers: this rank's slab contexts ordered by slab id (slab ids rank, rank+world, ...).
+    Installs, for every slab but the first of the grid, the last two slices of the slab below."""
+    if not isinstance(carvers, (list, tuple)):
+        carvers = [carvers]
+    k = len(carvers)
+    lib = carvers[0]._lib
+    if world * k == 1:
+        return
+    nbytes = int(lib.vcy_halo_bytes(carvers[0].ctx))
+    slab_ids = [rank + i * world for i in range(k)]
     if world == 1:
+        # all slabs live in this process: hand the packs over directly
+        packs = [c.halo_pack_host() for c in carvers]
+        for i, c in enumerate(carvers):
+            if slab_ids[i] > 0:
+                c.halo_install_host(packs[i - 1])
         return
     import torch
     import torch.distributed as dist
 
-    nbytes = int(lib.vcy_halo_bytes(carver.ctx))
     on_gpu = dist.get_backend() == "nccl"
     if on_gpu:
-        send = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        recv = torch.empty(nbytes * world, dtype=torch.uint8, device="cuda")
-        rc = lib.vcy_halo_pack(carver.ctx, C.c_void_p(send.data_ptr()))
-        assert rc == 0, lib.vcy_last_error()
-        carver.sync()
+        send = torch.empty(nbytes * k, dtype=torch.uint8, device="cuda")
+        recv = torch.empty(nbytes * k * world, dtype=torch.uint8, device="cuda")
+        for i, c in enumerate(carvers):
+            rc = lib.vcy_halo_pack(c.ctx, C.c_void_p(send.data_ptr() + i * nbytes))
+            assert rc == 0, lib.vcy_last_error()
+            c.sync()
         dist.all_gather_into_tensor(recv, send)   # the single RCCL collective of the path
         torch.cuda.synchronize()
-        rc = lib.vcy_halo_unpack(carver.ctx, C.c_void_p(recv.data_ptr()), rank, world)
-        assert rc == 0, lib.vcy_last_error()
-        carver.sync()
+        for i, c in enumerate(carvers):
+            s = slab_ids[i]
+            if s > 0:
+                off = _pack_offset(s - 1, world, k, nbytes)
+                rc = lib.vcy_halo_install(c.ctx, C.c_void_p(recv.data_ptr() + off))
+                assert rc == 0, lib.vcy_last_error()
+                c.sync()
     else:
-        # gloo (CPU tests / same-device debugging): stage the same bytes through the host
-        send = torch.from_numpy(carver.halo_pack_host())
+        # gloo (CPU tests / several ranks on one GPU): stage the same bytes through the host
+        send = torch.from_numpy(np.concatenate([c.halo_pack_host() for c in carvers]))
         parts = [torch.empty_like(send) for _ in range(world)]
         dist.all_gather(parts, send)
-        carver.halo_unpack_host(np.concatenate([p.numpy() for p in parts]), rank, world)
+        flat = np.concatenate([p.numpy() for p in parts])
+        for i, c in enumerate(carvers):
+            s = slab_ids[i]
+            if s > 0:
+                off = _pack_offset(s - 1, world, k, nbytes)
+                c.halo_install_host(flat[off:off + nbytes])
 
 
 def merge_meshes(meshes):
-    """Stitches per-rank meshes (rank order) into the mesh a single-GPU extraction returns.
+    """Stitches per-slab meshes (in slab order) into the mesh a single-GPU extraction returns.
 
-    Rank r's first n_foreign vertices duplicate vertices owned by rank r-1 (edges on the shared
-    plane); they are dropped and the faces that use them are re-pointed by edge key.  Own
+    A slab's first n_foreign vertices duplicate vertices owned by the slab below (edges on the
+    shared plane); they are dropped and the faces that use them are re-pointed by edge key.  Own
     vertices keep their order, so the result is vertex-for-vertex the serial scan's numbering.
     """
     verts, keys, faces = [], [], []
@@ -69,7 +106,7 @@ def merge_meshes(meshes):
         verts.append(v[nf_:])
         keys.append(k[nf_:])
         faces.append(remap[f] if len(f) else f.astype(np.int64))
-        # only vertices on this slab's top plane can be referenced by the next rank
+        # only vertices on this slab's top plane can be referenced by the next slab
         prev_key_to_gid = {(int(a), int(b)): offset + i for i, (a, b) in enumerate(k[nf_:])} \
             if len(meshes) > 1 else {}
         offset += nown
