@@ -485,6 +485,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     if (c->d_fused_scratch) VCY_HIP_CHECK(hipFree(c->d_fused_scratch));
     c->d_fused_scratch = nullptr;
     c->fused_scratch_bytes = 0;
+    c->fused_cache_valid = false;
     VCY_HIP_CHECK(hipMalloc(&c->d_fused_scratch, c2_bytes + fv_bytes));
     c->fused_scratch_bytes = c2_bytes + fv_bytes;
   }
@@ -496,11 +497,22 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     fv[vi].v = vp[vi];
     samef = samef && (vp[vi].fx == vp[vi].fy);
   }
-  // the scratch may still be read by the previous launch on this stream
-  VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
-  VCY_HIP_CHECK(hipMemcpyAsync(d_c2, c2.data(), c2_bytes, hipMemcpyHostToDevice, c->stream));
-  VCY_HIP_CHECK(hipMemcpyAsync(d_views, fv.data(), fv_bytes, hipMemcpyHostToDevice, c->stream));
-  VCY_HIP_CHECK(hipStreamSynchronize(c->stream));  // host vectors die at return
+  // Upload the view blocks and z tables unless the device copy already holds exactly these
+  // (repeated carves of the same views, e.g. after vcy_reset).
+  const bool cached = c->fused_cache_valid && c->fused_cache_views.size() == fv_bytes &&
+                      c->fused_cache_c2.size() == c2.size() &&
+                      std::memcmp(c->fused_cache_views.data(), fv.data(), fv_bytes) == 0 &&
+                      std::memcmp(c->fused_cache_c2.data(), c2.data(), c2_bytes) == 0;
+  if (!cached) {
+    // the scratch may still be read by the previous launch on this stream
+    VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+    VCY_HIP_CHECK(hipMemcpyAsync(d_c2, c2.data(), c2_bytes, hipMemcpyHostToDevice, c->stream));
+    VCY_HIP_CHECK(hipMemcpyAsync(d_views, fv.data(), fv_bytes, hipMemcpyHostToDevice, c->stream));
+    VCY_HIP_CHECK(hipStreamSynchronize(c->stream));  // host vectors die at return
+    c->fused_cache_views.assign((const char*)fv.data(), (const char*)fv.data() + fv_bytes);
+    c->fused_cache_c2 = c2;
+    c->fused_cache_valid = true;
+  }
 
   const int nbx = (c->nx + BX - 1) / BX, nby = (c->ny + BY - 1) / BY, nbz = (nzl + BZ - 1) / BZ;
   const int64_t nblocks = (int64_t)nbx * nby * nbz;

@@ -315,58 +315,89 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total, int* sm /
   return base + incl - v;
 }
 
-// ---- pass 1: active cells ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restrict__ act) {
-  const int64_t cw = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (cw >= p.nwords) return;
-  int li, cy, w;
-  u64 a = 0;
-  if (decode_word(p, cw, &li, &cy, &w) && (li > 0 || p.has_ghost)) {
-    CellWord c;
-    load_cell_word(p, li, cy, w, &c);
-    a = active_mask(c);
-  }
-  act[cw] = a;
-}
-
-// ---- pass 2: edge ownership + counts ----------------------------------------------------------
-// info[cell] = owned edges (12 bits) | case << 12 | first vertex of the cell inside its word << 20
-__global__ __launch_bounds__(256) void mc_owner_kernel(McParams p, const McTables* __restrict__ T,
-                                                       const u64* __restrict__ act,
-                                                       uint32_t* __restrict__ info,
-                                                       uint32_t* __restrict__ word_vert_off,
-                                                       uint32_t* __restrict__ word_tri_off,
-                                                       u64* __restrict__ block_counts) {
+// ---- pass 1: active cells, counted per word --------------------------------------------------
+__global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restrict__ act,
+                                                        uint32_t* __restrict__ word_cell_off,
+                                                        u64* __restrict__ block_cells) {
   __shared__ int sm[4];
   const int64_t cw = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int nvert = 0, ntri = 0;
-  u64 a = (cw < p.nwords) ? act[cw] : 0ull;
-  if (a) {
+  u64 a = 0;
+  if (cw < p.nwords) {
     int li, cy, w;
-    decode_word(p, cw, &li, &cy, &w);
-    CellWord c;
-    load_cell_word(p, li, cy, w, &c);
-    while (a) {
-      const int b = __ffsll((long long)a) - 1;
-      a &= a - 1;
-      const int code = case_of(c, b);
-      const int owned = owned_edges(p, act, code, li, cy, w * 64 + b);
-      info[cell_slot(cw, b)] = (uint32_t)owned | ((uint32_t)code << 12) | ((uint32_t)nvert << 20);
-      nvert += __popc(owned);
-      if (li > 0) ntri += T->ntri[code];
+    if (decode_word(p, cw, &li, &cy, &w) && (li > 0 || p.has_ghost)) {
+      CellWord c;
+      load_cell_word(p, li, cy, w, &c);
+      a = active_mask(c);
     }
+    act[cw] = a;
+  }
+  int total;
+  const int off = block_exclusive_scan(__popcll(a), &total, sm);
+  if (cw < p.nwords) word_cell_off[cw] = (uint32_t)off;
+  if (threadIdx.x == 0) block_cells[blockIdx.x] = (u64)(unsigned)total;
+}
+
+// ---- pass 2: compact the active cells into a list (raster order is preserved) ------------------
+// cell_list[i] = padded cell slot (word * 64 + bit); cell_index[slot] = i for the owner lookups.
+__global__ __launch_bounds__(256) void mc_compact_kernel(McParams p, const u64* __restrict__ act,
+                                                         const uint32_t* __restrict__ word_cell_off,
+                                                         const u64* __restrict__ block_cell_offs,
+                                                         u64* __restrict__ cell_list,
+                                                         uint32_t* __restrict__ cell_index) {
+  const int64_t cw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (cw >= p.nwords) return;
+  u64 a = act[cw];
+  if (!a) return;
+  int64_t i = (int64_t)block_cell_offs[blockIdx.x] + word_cell_off[cw];
+  while (a) {
+    const int b = __ffsll((long long)a) - 1;
+    a &= a - 1;
+    cell_list[i] = (u64)cell_slot(cw, b);
+    cell_index[cell_slot(cw, b)] = (uint32_t)i;
+    ++i;
+  }
+}
+
+// cube index of one cell from the IN plane (marching_cubes.cc:121-128)
+__device__ __forceinline__ int case_at(const McParams& p, int li, int cy, int x) {
+  const int z = p.zc0 + li - 1, y = cy + 1;
+  const int64_t rw = (int64_t)p.Wr;
+  const int64_t r11 = ((int64_t)(z - p.zs0) * p.ny + y) * rw;
+  const int64_t r01 = r11 - rw, r10 = r11 - (int64_t)p.ny * rw, r00 = r10 - rw;
+  const int w = x >> 6, b = x & 63, wp = (x - 1) >> 6, bp = (x - 1) & 63;  // x >= 1 for a cell
+  auto bit = [&](int64_t row, int ww, int bb) -> int { return (int)((p.in[row + ww] >> bb) & 1ull); };
+  return bit(r00, wp, bp) | bit(r00, w, b) << 1 | bit(r10, w, b) << 2 | bit(r10, wp, bp) << 3 |
+         bit(r01, wp, bp) << 4 | bit(r01, w, b) << 5 | bit(r11, w, b) << 6 | bit(r11, wp, bp) << 7;
+}
+
+// ---- pass 3: edge ownership + counts, one thread per active cell ----------------------------------
+// info[i] = owned edges (12 bits) | case << 12 | first vertex of the cell inside its block << 20
+__global__ __launch_bounds__(256) void mc_owner_kernel(McParams p, const McTables* __restrict__ T,
+                                                       const u64* __restrict__ act,
+                                                       const u64* __restrict__ cell_list, int64_t ncells,
+                                                       uint32_t* __restrict__ info,
+                                                       u64* __restrict__ block_counts) {
+  __shared__ int sm[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int nvert = 0, ntri = 0, owned = 0, code = 0;
+  if (i < ncells) {
+    const int64_t slot = (int64_t)cell_list[i];
+    int li, cy, w;
+    decode_word(p, slot >> 6, &li, &cy, &w);
+    const int x = w * 64 + (int)(slot & 63);
+    code = case_at(p, li, cy, x);
+    owned = owned_edges(p, act, code, li, cy, x);
+    nvert = __popc(owned);
+    if (li > 0) ntri = T->ntri[code];
   }
   int tot_v, tot_t;
   const int off_v = block_exclusive_scan(nvert, &tot_v, sm);
-  const int off_t = block_exclusive_scan(ntri, &tot_t, sm);
-  if (cw < p.nwords) {
-    word_vert_off[cw] = (uint32_t)off_v;
-    word_tri_off[cw] = (uint32_t)off_t;
-  }
+  (void)block_exclusive_scan(ntri, &tot_t, sm);
+  if (i < ncells) info[i] = (uint32_t)owned | ((uint32_t)code << 12) | ((uint32_t)off_v << 20);
   if (threadIdx.x == 0) block_counts[blockIdx.x] = ((u64)(unsigned)tot_v << 32) | (u64)(unsigned)tot_t;
 }
 
-// ---- pass 3: exclusive scan of packed (verts<<32 | tris) block counts ---------------------------
+// ---- exclusive scan of packed block counts (used twice: cells per word block, (verts<<32 | tris)) ---------------------------
 __global__ __launch_bounds__(256) void scan_chunks_kernel(u64* __restrict__ data, int64_t n,
                                                           u64* __restrict__ chunk_sums) {
   // 1024 elements per block, 4 per thread
@@ -418,13 +449,12 @@ int exclusive_scan_u64(u64* d, int64_t n, u64* d_total, u64* scratch, hipStream_
   return VCY_OK;
 }
 
-// ---- pass 4: emit -----------------------------------------------------------------------------
+// ---- pass 4: emit, one thread per active cell -----------------------------------------------------
 __device__ __forceinline__ int64_t vertex_id_of(const McTables* T, const uint32_t* __restrict__ info,
-                                                const uint32_t* __restrict__ word_vert_off,
-                                                const u64* __restrict__ block_offs, int64_t cw, int b, int edge) {
-  const uint32_t inf = info[cell_slot(cw, b)];
-  const int owned = inf & 0xFFF, code = (inf >> 12) & 0xFF, in_word = inf >> 20;
-  return (int64_t)(block_offs[cw >> 8] >> 32) + word_vert_off[cw] + in_word + __popc(owned & T->prec[code][edge]);
+                                                const u64* __restrict__ block_offs, int64_t i, int edge) {
+  const uint32_t inf = info[i];
+  const int owned = inf & 0xFFF, code = (inf >> 12) & 0xFF, in_block = inf >> 20;
+  return (int64_t)(block_offs[i >> 8] >> 32) + in_block + __popc(owned & T->prec[code][edge]);
 }
 
 // VertexInterp, marching_cubes.cc:25-57 (fp64, then cast)
@@ -445,88 +475,84 @@ __device__ __forceinline__ void vertex_interp(double iso, const float pa[3], con
 
 __global__ __launch_bounds__(256) void mc_emit_kernel(McParams p, const McTables* __restrict__ T,
                                                       const u64* __restrict__ act,
+                                                      const u64* __restrict__ cell_list, int64_t ncells,
+                                                      const uint32_t* __restrict__ cell_index,
                                                       const uint32_t* __restrict__ info,
-                                                      const uint32_t* __restrict__ word_vert_off,
-                                                      const uint32_t* __restrict__ word_tri_off,
                                                       const u64* __restrict__ block_offs,
                                                       float* __restrict__ verts, long long* __restrict__ keys,
                                                       int* __restrict__ faces) {
-  const int64_t cw = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (cw >= p.nwords) return;
-  u64 a = act[cw];
-  if (!a) return;
-  int li, cy, w;
-  decode_word(p, cw, &li, &cy, &w);
+  __shared__ int sm[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int li = 0, cy = 0, x = 0, owned = 0, code = 0, ntri = 0;
+  uint32_t inf = 0;
+  if (i < ncells) {
+    const int64_t slot = (int64_t)cell_list[i];
+    int w;
+    decode_word(p, slot >> 6, &li, &cy, &w);
+    x = w * 64 + (int)(slot & 63);
+    inf = info[i];
+    owned = inf & 0xFFF;
+    code = (inf >> 12) & 0xFF;
+    if (li > 0) ntri = T->ntri[code];
+  }
+  int tot_t;
+  const int tri_off = block_exclusive_scan(ntri, &tot_t, sm);
+  if (i >= ncells) return;
   const int y = cy + 1, z = p.zc0 + li - 1;
   const int64_t slice = (int64_t)p.nx * p.ny;
-  const int64_t vword = (int64_t)(block_offs[cw >> 8] >> 32) + word_vert_off[cw];
-  int64_t fnext = (int64_t)(block_offs[cw >> 8] & 0xFFFFFFFFull) + word_tri_off[cw];
-  while (a) {
-    const int b = __ffsll((long long)a) - 1;
-    a &= a - 1;
-    const int x = w * 64 + b;
-    const uint32_t inf = info[cell_slot(cw, b)];
-    const int owned = inf & 0xFFF, code = (inf >> 12) & 0xFF;
-    const int64_t vbase = vword + (inf >> 20);
+  const u64 boff = block_offs[i >> 8];
+  const int64_t vbase = (int64_t)(boff >> 32) + (inf >> 20);
 
-    // vertices of the edges this cell owns
-    for (int e = 0; e < 12; ++e) {
-      if (!(owned & (1 << e))) continue;
-      const int ca = kEdgeA[e], cb = kEdgeB[e];
-      const int ax = x + kCornerOff[ca][0], ay = y + kCornerOff[ca][1], az = z + kCornerOff[ca][2];
-      const int bx = x + kCornerOff[cb][0], by = y + kCornerOff[cb][1], bz = z + kCornerOff[cb][2];
-      const float pa[3] = {p.px[ax], p.py[ay], p.pz[az]};
-      const float pb[3] = {p.px[bx], p.py[by], p.pz[bz]};
-      const float va = p.sdf[(int64_t)(az - p.zs0) * slice + (int64_t)ay * p.nx + ax];
-      const float vb = p.sdf[(int64_t)(bz - p.zs0) * slice + (int64_t)by * p.nx + bx];
-      float out[3];
-      vertex_interp(p.iso, pa, pb, va, vb, p.linear != 0, out);
-      const int64_t vid = vbase + __popc(owned & T->prec[code][e]);
-      verts[3 * vid + 0] = out[0];
-      verts[3 * vid + 1] = out[1];
-      verts[3 * vid + 2] = out[2];
-      const int ka = kKeyA[e], kb = kKeyB[e];
-      keys[2 * vid + 0] = (int64_t)(z + kCornerOff[ka][2]) * slice + (int64_t)(y + kCornerOff[ka][1]) * p.nx +
-                          (x + kCornerOff[ka][0]);
-      keys[2 * vid + 1] = (int64_t)(z + kCornerOff[kb][2]) * slice + (int64_t)(y + kCornerOff[kb][1]) * p.nx +
-                          (x + kCornerOff[kb][0]);
-    }
-    if (li == 0) continue;  // ghost cells emit no triangles
+  // vertices of the edges this cell owns
+  for (int e = 0; e < 12; ++e) {
+    if (!(owned & (1 << e))) continue;
+    const int ca = kEdgeA[e], cb = kEdgeB[e];
+    const int ax = x + kCornerOff[ca][0], ay = y + kCornerOff[ca][1], az = z + kCornerOff[ca][2];
+    const int bx = x + kCornerOff[cb][0], by = y + kCornerOff[cb][1], bz = z + kCornerOff[cb][2];
+    const float pa[3] = {p.px[ax], p.py[ay], p.pz[az]};
+    const float pb[3] = {p.px[bx], p.py[by], p.pz[bz]};
+    const float va = p.sdf[(int64_t)(az - p.zs0) * slice + (int64_t)ay * p.nx + ax];
+    const float vb = p.sdf[(int64_t)(bz - p.zs0) * slice + (int64_t)by * p.nx + bx];
+    float out[3];
+    vertex_interp(p.iso, pa, pb, va, vb, p.linear != 0, out);
+    const int64_t vid = vbase + __popc(owned & T->prec[code][e]);
+    verts[3 * vid + 0] = out[0];
+    verts[3 * vid + 1] = out[1];
+    verts[3 * vid + 2] = out[2];
+    const int ka = kKeyA[e], kb = kKeyB[e];
+    keys[2 * vid + 0] = (int64_t)(z + kCornerOff[ka][2]) * slice + (int64_t)(y + kCornerOff[ka][1]) * p.nx +
+                        (x + kCornerOff[ka][0]);
+    keys[2 * vid + 1] = (int64_t)(z + kCornerOff[kb][2]) * slice + (int64_t)(y + kCornerOff[kb][1]) * p.nx +
+                        (x + kCornerOff[kb][0]);
+  }
 
-    // triangles, marching_cubes.cc:199-218
-    const int ntri = T->ntri[code];
-    for (int t = 0; t < ntri; ++t) {
-      for (int j = 0; j < 3; ++j) {
-        const int e = T->tri[code][3 * t + (2 - j)];
-        int64_t vid = -1;
-        if (owned & (1 << e)) {
-          vid = vbase + __popc(owned & T->prec[code][e]);
-        } else {
-          for (int k = 0; k < kShare[e].n; ++k) {
-            const int dx = kShare[e].d[k][0], dy = kShare[e].d[k][1], dl = kShare[e].d[k][2];
-            if (neighbour_active(p, act, li, cy, x, dx, dy, dl)) {
-              const int ox = x + dx;
-              vid = vertex_id_of(T, info, word_vert_off, block_offs, word_index(p, li + dl, cy + dy, ox >> 6),
-                                 ox & 63, kShare[e].e[k]);
-              break;
-            }
+  // triangles, marching_cubes.cc:199-218 (ghost cells have ntri == 0)
+  const int64_t fbase = (int64_t)(boff & 0xFFFFFFFFull) + tri_off;
+  for (int t = 0; t < ntri; ++t) {
+    for (int j = 0; j < 3; ++j) {
+      const int e = T->tri[code][3 * t + (2 - j)];
+      int64_t vid = -1;
+      if (owned & (1 << e)) {
+        vid = vbase + __popc(owned & T->prec[code][e]);
+      } else {
+        for (int k = 0; k < kShare[e].n; ++k) {
+          const int dx = kShare[e].d[k][0], dy = kShare[e].d[k][1], dl = kShare[e].d[k][2];
+          if (neighbour_active(p, act, li, cy, x, dx, dy, dl)) {
+            const int ox = x + dx;
+            const int64_t oslot = cell_slot(word_index(p, li + dl, cy + dy, ox >> 6), ox & 63);
+            vid = vertex_id_of(T, info, block_offs, (int64_t)cell_index[oslot], kShare[e].e[k]);
+            break;
           }
         }
-        faces[3 * (fnext + t) + j] = (int)vid;
       }
+      faces[3 * (fbase + t) + j] = (int)vid;
     }
-    fnext += ntri;
   }
 }
 
 }  // namespace
 
 // ---- host driver ----------------------------------------------------------------------------
-
-struct McScratch {
-  size_t bytes = 0;
-  char* base = nullptr;
-};
 
 int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   out->n_vertices = out->n_faces = out->n_foreign_vertices = 0;
@@ -577,15 +603,16 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   }
   const McTables* T = (const McTables*)c->d_mc_tables;
 
-  // scratch, cached in the context (grown on demand): bit planes, ACT, offsets, info
+  // scratch, cached in the context (grown on demand): bit planes, ACT, per-word offsets, block
+  // counts, and the dense slot -> list-index map (4 B per padded cell, touched only at active cells)
   auto align = [](size_t v) { return (v + 255) / 256 * 256; };
   const size_t sz_plane = align(sizeof(u64) * (size_t)vox_words);
   const size_t sz_act = align(sizeof(u64) * (size_t)p.nwords);
   const size_t sz_woff = align(sizeof(uint32_t) * (size_t)p.nwords);
   const size_t sz_counts = align(sizeof(u64) * ((size_t)nblocks + 1));
   const size_t sz_scan = align(sizeof(u64) * ((size_t)nblocks / 1024 + 64) * 2);
-  const size_t sz_info = align(sizeof(uint32_t) * (size_t)p.nwords * 64);
-  const size_t need = 3 * sz_plane + sz_act + 2 * sz_woff + sz_counts + sz_scan + sz_info + 256;
+  const size_t sz_index = align(sizeof(uint32_t) * (size_t)p.nwords * 64);
+  const size_t need = 3 * sz_plane + sz_act + sz_woff + sz_counts + sz_scan + sz_index + 256;
   if (c->mc_scratch_bytes < need) {
     VCY_HIP_CHECK(hipStreamSynchronize(s));
     if (c->d_mc_scratch) VCY_HIP_CHECK(hipFree(c->d_mc_scratch));
@@ -599,11 +626,10 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   u64* d_ok = (u64*)base;                     base += sz_plane;
   u64* d_tc = (u64*)base;                     base += sz_plane;
   u64* d_act = (u64*)base;                    base += sz_act;
-  uint32_t* d_voff = (uint32_t*)base;         base += sz_woff;
-  uint32_t* d_toff = (uint32_t*)base;         base += sz_woff;
-  u64* d_counts = (u64*)base;                 base += sz_counts;
+  uint32_t* d_woff = (uint32_t*)base;         base += sz_woff;
+  u64* d_wcounts = (u64*)base;                base += sz_counts;
   u64* d_scan = (u64*)base;                   base += sz_scan;
-  uint32_t* d_info = (uint32_t*)base;         base += sz_info;
+  uint32_t* d_index = (uint32_t*)base;        base += sz_index;
   u64* d_total = (u64*)base;
   p.in = d_in;
   p.ok = d_ok;
@@ -634,25 +660,65 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   else
     hipLaunchKernelGGL((mc_bits_kernel<uint32_t>), dim3(bits_blocks), dim3(256), 0, s, c->d_sdf,
                        (const uint32_t*)c->d_cnt, c->nx, p.Wr, vox_words, iso, d_in, d_ok, d_tc);
-  hipLaunchKernelGGL(mc_active_kernel, dim3(nblocks), dim3(256), 0, s, p, d_act);
-  hipLaunchKernelGGL(mc_owner_kernel, dim3(nblocks), dim3(256), 0, s, p, T, d_act, d_info, d_voff, d_toff,
-                     d_counts);
+  hipLaunchKernelGGL(mc_active_kernel, dim3(nblocks), dim3(256), 0, s, p, d_act, d_woff, d_wcounts);
   MC_TRY(hipGetLastError());
-  int rc = exclusive_scan_u64(d_counts, nblocks, d_total, d_scan, s);
-  if (rc != VCY_OK) {
-    cleanup();
-    return rc;
-  }
-  // totals, and the vertex offset of the first own block (= vertices owned by ghost cells)
-  u64 h_tot[2] = {0, 0};
-  MC_TRY(hipMemcpyAsync(&h_tot[0], d_total, sizeof(u64), hipMemcpyDeviceToHost, s));
-  MC_TRY(hipMemcpyAsync(&h_tot[1], d_counts + p.G / kWordsPerBlock, sizeof(u64), hipMemcpyDeviceToHost, s));
+  int rc = exclusive_scan_u64(d_wcounts, nblocks, d_total, d_scan, s);
+  if (rc != VCY_OK) return rc;
+  // number of active cells, and how many of them are ghost cells (words below G)
+  u64 h_cells[2] = {0, 0};
+  MC_TRY(hipMemcpyAsync(&h_cells[0], d_total, sizeof(u64), hipMemcpyDeviceToHost, s));
+  MC_TRY(hipMemcpyAsync(&h_cells[1], d_wcounts + p.G / kWordsPerBlock, sizeof(u64), hipMemcpyDeviceToHost, s));
   MC_TRY(hipStreamSynchronize(s));
-  const int64_t nv = (int64_t)(h_tot[0] >> 32), nf = (int64_t)(h_tot[0] & 0xFFFFFFFFull);
-  out->n_foreign_vertices = (int64_t)(h_tot[1] >> 32);
+  const int64_t ncells = (int64_t)h_cells[0], nghost = (int64_t)h_cells[1];
+  if (ncells > 0xFFFFFFFFLL) {
+    set_error("too many surface cells");
+    return VCY_ERR_TOO_MANY_VOXELS;
+  }
+  int64_t nv = 0, nf = 0;
+  if (ncells > 0) {
+    // per-active-cell arrays, cached in the context
+    const unsigned cblocks = (unsigned)((ncells + 255) / 256);
+    const size_t sz_list = align(sizeof(u64) * (size_t)ncells);
+    const size_t sz_info = align(sizeof(uint32_t) * (size_t)ncells);
+    const size_t sz_cc = align(sizeof(u64) * ((size_t)cblocks + 1));
+    const size_t sz_cs = align(sizeof(u64) * ((size_t)cblocks / 1024 + 64) * 2);
+    const size_t need2 = sz_list + sz_info + sz_cc + sz_cs + 256;
+    if (c->mc_cells_bytes < need2) {
+      if (c->d_mc_cells) MC_TRY(hipFree(c->d_mc_cells));
+      c->d_mc_cells = nullptr;
+      c->mc_cells_bytes = 0;
+      MC_TRY(hipMalloc(&c->d_mc_cells, need2 + need2 / 4));
+      c->mc_cells_bytes = need2 + need2 / 4;
+    }
+    char* b2 = (char*)c->d_mc_cells;
+    u64* d_list = (u64*)b2;                   b2 += sz_list;
+    uint32_t* d_info = (uint32_t*)b2;         b2 += sz_info;
+    u64* d_counts = (u64*)b2;                 b2 += sz_cc;
+    u64* d_scan2 = (u64*)b2;                  b2 += sz_cs;
+    u64* d_total2 = (u64*)b2;
 
-  // output staging, cached in the context and grown on demand
-  {
+    hipLaunchKernelGGL(mc_compact_kernel, dim3(nblocks), dim3(256), 0, s, p, d_act, d_woff, d_wcounts, d_list,
+                       d_index);
+    hipLaunchKernelGGL(mc_owner_kernel, dim3(cblocks), dim3(256), 0, s, p, T, d_act, d_list, ncells, d_info,
+                       d_counts);
+    MC_TRY(hipGetLastError());
+    rc = exclusive_scan_u64(d_counts, cblocks, d_total2, d_scan2, s);
+    if (rc != VCY_OK) return rc;
+    // totals; vertices owned by ghost cells = vertex prefix of list entry `nghost`
+    u64 h_tot = 0, h_goff = 0;
+    uint32_t h_ginfo = 0;
+    MC_TRY(hipMemcpyAsync(&h_tot, d_total2, sizeof(u64), hipMemcpyDeviceToHost, s));
+    if (nghost > 0 && nghost < ncells) {
+      MC_TRY(hipMemcpyAsync(&h_goff, d_counts + (nghost >> 8), sizeof(u64), hipMemcpyDeviceToHost, s));
+      MC_TRY(hipMemcpyAsync(&h_ginfo, d_info + nghost, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
+    MC_TRY(hipStreamSynchronize(s));
+    nv = (int64_t)(h_tot >> 32);
+    nf = (int64_t)(h_tot & 0xFFFFFFFFull);
+    if (nghost >= ncells) out->n_foreign_vertices = nv;
+    else if (nghost > 0) out->n_foreign_vertices = (int64_t)(h_goff >> 32) + (h_ginfo >> 20);
+
+    // output staging, cached in the context and grown on demand
     const size_t sz_v = align(sizeof(float) * 3 * (size_t)std::max<int64_t>(nv, 1));
     const size_t sz_k = align(sizeof(long long) * 2 * (size_t)std::max<int64_t>(nv, 1));
     const size_t sz_f = align(sizeof(int) * 3 * (size_t)std::max<int64_t>(nf, 1));
@@ -667,10 +733,10 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
     d_verts = (float*)c->d_mc_out;
     d_keys = (long long*)((char*)c->d_mc_out + sz_v);
     d_faces = (int*)((char*)c->d_mc_out + sz_v + sz_k);
+    hipLaunchKernelGGL(mc_emit_kernel, dim3(cblocks), dim3(256), 0, s, p, T, d_act, d_list, ncells, d_index, d_info,
+                       d_counts, d_verts, d_keys, d_faces);
+    MC_TRY(hipGetLastError());
   }
-  hipLaunchKernelGGL(mc_emit_kernel, dim3(nblocks), dim3(256), 0, s, p, T, d_act, d_info, d_voff, d_toff,
-                     d_counts, d_verts, d_keys, d_faces);
-  MC_TRY(hipGetLastError());
   MC_TRY(hipEventRecord(c->ev_end, s));
   MC_TRY(hipEventSynchronize(c->ev_end));
   MC_TRY(hipEventElapsedTime(&c->last_extract_device_ms, c->ev_begin, c->ev_end));

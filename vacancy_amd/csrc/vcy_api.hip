@@ -213,6 +213,7 @@ void vcy_destroy(vcy_ctx* c) {
   (void)hipFree(c->d_mc_tables);
   (void)hipFree(c->d_mc_scratch);
   (void)hipFree(c->d_mc_out);
+  (void)hipFree(c->d_mc_cells);
   (void)hipFree(c->d_fused_scratch);
   delete[] c->h_pz;
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "vacancy_hip.h"
 
@@ -64,9 +65,14 @@ struct vcy_ctx {
   float* h_pz = nullptr;              // host copy of d_pz (per-view z tables of the fused carve)
   void* d_fused_scratch = nullptr;    // view blocks + z tables of the fused carve kernel
   size_t fused_scratch_bytes = 0;
+  bool fused_cache_valid = false;     // host mirror of what d_fused_scratch holds
+  std::vector<char> fused_cache_views;
+  std::vector<float> fused_cache_c2;
   void* d_mc_tables = nullptr;        // marching-cubes case tables (mc_kernels.hip)
   void* d_mc_scratch = nullptr;       // bit planes, active words, offsets, per-cell info
   size_t mc_scratch_bytes = 0;
+  void* d_mc_cells = nullptr;         // per-active-cell arrays of the extraction
+  size_t mc_cells_bytes = 0;
   void* d_mc_out = nullptr;           // device staging of the extracted mesh
   size_t mc_out_bytes = 0;
   float last_extract_device_ms = 0.0f;
