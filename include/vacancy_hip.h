@@ -137,6 +137,13 @@ int vcy_carve_batch_device(vcy_ctx* ctx, int n_views, const vcy_view* views,
 int vcy_carve_silhouette(vcy_ctx* ctx, const vcy_view* view,
                          const uint8_t* mask_host, float* sdf_out_host);
 
+/* Replaces bool VoxelCarver::Carve(const std::vector<Camera>&, const std::vector<Image1b>&)
+ * (voxel_carver.cc:516-528) end to end: every silhouette is uploaded (8 bit), turned into its SDF
+ * on the device and fused, in chunks of 32 views; the upload + SDF build of chunk i+1 runs on a
+ * second stream while chunk i is carved.  Result identical to n calls of vcy_carve_silhouette. */
+int vcy_carve_batch_silhouettes(vcy_ctx* ctx, int n_views, const vcy_view* views,
+                                const uint8_t* const* masks_host);
+
 /* Replaces void DistanceTransformL1(...) (voxel_carver.cc:102-167). */
 int vcy_distance_transform_l1(const uint8_t* mask, int width, int height,
                               const int32_t roi_min[2], const int32_t roi_max[2],
@@ -179,6 +186,8 @@ int vcy_last_extract_ms(const vcy_ctx* ctx, float* device_ms);
  * id = z*nx*ny + y*nx + x (voxel_carver.cc:333,349-355).  Either may be NULL. */
 int vcy_download(vcy_ctx* ctx, float* sdf, int32_t* update_num);
 int vcy_upload(vcy_ctx* ctx, const float* sdf, const int32_t* update_num);
+/* Point query: state of `n` voxels given by global id (must lie in this context's slab). */
+int vcy_download_voxels(vcy_ctx* ctx, int64_t n, const int64_t* voxel_ids, float* sdf, int32_t* update_num);
 /* Voxel centres of the slab, 3 floats per voxel (Voxel::pos, voxel_carver.cc:315-337). */
 int vcy_download_positions(vcy_ctx* ctx, float* pos);
 

@@ -34,6 +34,23 @@ def _sample_check(dev, opt, views, sdfs, n, nsample=400000, seed=5):
     assert np.array_equal(ds[lin].view(np.uint32), os_.view(np.uint32))
 
 
+def _sample_check_queries(dev, opt, views, sdfs, n, nsample=300000, seed=9):
+    """Like _sample_check but through vcy_download_voxels (no 50 GB download)."""
+    rng = np.random.RandomState(seed)
+    ix = rng.randint(0, n, (nsample, 3))
+    ix[:8] = [[a, b, c] for a in (0, n - 1) for b in (0, n - 1) for c in (0, n - 1)]
+    ax = O.axis_positions(-n / 2.0, n / 2.0, 1.0, n)
+    pos = np.stack([ax[ix[:, 0]], ax[ix[:, 1]], ax[ix[:, 2]]], 1)
+    orc = O.OracleGrid(opt, positions=pos)
+    for v, s in zip(views, sdfs):
+        orc.carve(v, s)
+    os_, ou = orc.download()
+    lin = (ix[:, 2].astype(np.int64) * n + ix[:, 1]) * n + ix[:, 0]
+    ds, du = dev.download_voxels(lin)
+    assert np.array_equal(du, ou)
+    assert np.array_equal(ds.view(np.uint32), os_.view(np.uint32))
+
+
 def _mesh_invariants(m, expect_closed=True):
     f = m["faces"].astype(np.int64)
     nv = len(m["vertices"])
@@ -130,3 +147,20 @@ def test_config2_1024_default():
     assert np.array_equal(merged["faces"], m["faces"])
     assert np.array_equal(merged["keys"], m["keys"])
     assert np.array_equal(merged["vertices"].view(np.uint32), m["vertices"].view(np.uint32))
+
+
+def test_config4_2048_64_views_streamed():
+    """configs[4] on ONE GPU (the reference cannot represent this grid: 32-bit voxel ids): 2048^3,
+    64 views at 1920x1080, silhouettes streamed (upload + device SDF overlapped with the fused carve)."""
+    n, nv, w, h = 2048, 64, 1920, 1080
+    opt = synth.sphere_option(n)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init(), vc.last_error()
+    assert dev.dims == (n, n, n)
+    assert dev.CarveBatchSilhouettes(views, masks), vc.last_error()
+    sdf0 = O.make_sdf(masks[0])
+    _sample_check_queries(dev, opt, views, [sdf0] * nv, n)
+    m = dev.ExtractIsoSurface(0.0, True)
+    assert len(m["faces"]) > 15_000_000
+    _mesh_invariants(m)

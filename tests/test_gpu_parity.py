@@ -385,3 +385,25 @@ def test_device_sdf_builder_equals_oracle():
                 dev.free_device(d)
                 ref = O.make_sdf(mask, rmin, rmax, norm, trunc, 0.1)
                 assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (mask.shape, rmin, norm, trunc)
+
+
+def test_streamed_silhouette_batch_equals_per_view_calls():
+    """vcy_carve_batch_silhouettes (upload + device SDF on a second stream, fused carve in chunks of
+    32 views; BASELINE config 5 shape) == one vcy_carve_silhouette per view, for 70 views (3 chunks)."""
+    n, nv, w, h = 40, 70, 96, 72
+    for kw in (dict(), dict(voxel_update=1, use_truncation=True)):
+        opt = synth.sphere_option(n, UpdateOption(**kw))
+        views, masks = synth.sphere_views(n, nv, w, h)
+        rng = np.random.RandomState(4)
+        masks = [np.where(rng.rand(h, w) < 0.02, 0, m).astype(np.uint8) for m in masks]  # distinct images
+        a, b = vc.VoxelCarver(opt), vc.VoxelCarver(opt)
+        assert a.Init() and b.Init()
+        assert a.CarveBatchSilhouettes(views, masks), vc.last_error()
+        for v, m in zip(views, masks):
+            assert b.CarveSilhouette(v, m)
+        sa, ua = a.download()
+        sb, ub = b.download()
+        assert np.array_equal(ua, ub) and np.array_equal(sa.view(np.uint32), sb.view(np.uint32))
+        ids = rng.randint(0, n ** 3, 1000)
+        qs, qu = a.download_voxels(ids)
+        assert np.array_equal(qs.view(np.uint32), sa[ids].view(np.uint32)) and np.array_equal(qu, ua[ids])

@@ -86,6 +86,23 @@ class VoxelCarver:
                                             _p(sdf) if return_sdf else None)
         return (rc == 0, sdf) if return_sdf else rc == 0
 
+    # -- Carve(vector<Camera>, vector<Image1b>) (voxel_carver.cc:516-528), streamed + fused
+    def CarveBatchSilhouettes(self, views, silhouettes):
+        n = len(views)
+        arr = (View * n)(*views)
+        masks = [np.ascontiguousarray(m, np.uint8) for m in silhouettes]
+        ptrs = (C.c_void_p * n)(*[m.ctypes.data for m in masks])
+        return self._lib.vcy_carve_batch_silhouettes(self._ctx, n, arr, ptrs) == 0
+
+    def download_voxels(self, ids):
+        ids = np.ascontiguousarray(ids, np.int64)
+        s = np.empty(len(ids), np.float32)
+        u = np.empty(len(ids), np.int32)
+        rc = self._lib.vcy_download_voxels(self._ctx, len(ids), _p(ids), _p(s), _p(u))
+        if rc != 0:
+            raise RuntimeError(last_error())
+        return s, u
+
     # -- device-resident SDF images (bench / streaming)
     def upload_sdf(self, sdf):
         sdf = np.ascontiguousarray(sdf, dtype=np.float32)

@@ -134,7 +134,7 @@ constexpr int kWordsPerBlock = 256;
 // wave are issued before the first ballot so that a wave keeps ~3 KB in flight.
 constexpr int kBitsWordsPerWave = 8;
 
-template <typename CountT>
+template <typename CountT, bool ISO_F32>
 __global__ __launch_bounds__(256) void mc_bits_kernel(const float* __restrict__ sdf,
                                                       const CountT* __restrict__ cnt, int nx, int Wr,
                                                       int64_t nwords, double iso, u64* __restrict__ in,
@@ -162,7 +162,9 @@ __global__ __launch_bounds__(256) void mc_bits_kernel(const float* __restrict__ 
   u64 m_in = 0, m_ok = 0, m_tc = 0;
 #pragma unroll
   for (int k = 0; k < kBitsWordsPerWave; ++k) {
-    const u64 a = __ballot(live[k] && (double)s[k] < iso);
+    // `sdf < iso_level` promotes the float to double (marching_cubes.cc:121-128); when iso_level is
+    // itself a float value the comparison is the same in single precision
+    const u64 a = __ballot(live[k] && (ISO_F32 ? s[k] < (float)iso : (double)s[k] < iso));
     const u64 b = __ballot(live[k] && s[k] != kInvalidSdf);
     const u64 c = __ballot(live[k] && n[k] >= 1);
     if (lane == k) {
@@ -651,15 +653,14 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
 
   MC_TRY(hipEventRecord(c->ev_begin, s));
   const unsigned bits_blocks = (unsigned)((vox_words + 4 * kBitsWordsPerWave - 1) / (4 * kBitsWordsPerWave));
-  if (c->cnt_bytes == 1)
-    hipLaunchKernelGGL((mc_bits_kernel<uint8_t>), dim3(bits_blocks), dim3(256), 0, s, c->d_sdf,
-                       (const uint8_t*)c->d_cnt, c->nx, p.Wr, vox_words, iso, d_in, d_ok, d_tc);
-  else if (c->cnt_bytes == 2)
-    hipLaunchKernelGGL((mc_bits_kernel<uint16_t>), dim3(bits_blocks), dim3(256), 0, s, c->d_sdf,
-                       (const uint16_t*)c->d_cnt, c->nx, p.Wr, vox_words, iso, d_in, d_ok, d_tc);
-  else
-    hipLaunchKernelGGL((mc_bits_kernel<uint32_t>), dim3(bits_blocks), dim3(256), 0, s, c->d_sdf,
-                       (const uint32_t*)c->d_cnt, c->nx, p.Wr, vox_words, iso, d_in, d_ok, d_tc);
+  const bool iso_f32 = (double)(float)iso == iso;
+#define VCY_BITS(CT, F32)                                                                                  \
+  hipLaunchKernelGGL((mc_bits_kernel<CT, F32>), dim3(bits_blocks), dim3(256), 0, s, c->d_sdf,           \
+                     (const CT*)c->d_cnt, c->nx, p.Wr, vox_words, iso, d_in, d_ok, d_tc)
+  if (c->cnt_bytes == 1) { if (iso_f32) VCY_BITS(uint8_t, true); else VCY_BITS(uint8_t, false); }
+  else if (c->cnt_bytes == 2) { if (iso_f32) VCY_BITS(uint16_t, true); else VCY_BITS(uint16_t, false); }
+  else { if (iso_f32) VCY_BITS(uint32_t, true); else VCY_BITS(uint32_t, false); }
+#undef VCY_BITS
   hipLaunchKernelGGL(mc_active_kernel, dim3(nblocks), dim3(256), 0, s, p, d_act, d_woff, d_wcounts);
   MC_TRY(hipGetLastError());
   int rc = exclusive_scan_u64(d_wcounts, nblocks, d_total, d_scan, s);

@@ -611,6 +611,147 @@ int vcy_make_sdf_device(vcy_ctx* c, const uint8_t* mask_host, int w, int h, cons
   return VCY_OK;
 }
 
+// Streams n silhouettes through the device: masks are uploaded and turned into SDFs on a second
+// stream in chunks of 32 views while the previous chunk is being fused into the grid on the
+// context's stream (two sets of SDF buffers, ordered with events; BASELINE config 5).
+int vcy_carve_batch_silhouettes(vcy_ctx* c, int n_views, const vcy_view* views,
+                                const uint8_t* const* masks_host) {
+  if (!c) {
+    set_error("VoxelCarver::Carve voxel grid has not been initialized");
+    return VCY_ERR_NOT_INITIALIZED;
+  }
+  if (n_views <= 0 || !views || !masks_host) {
+    set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  size_t max_px = 0;
+  for (int i = 0; i < n_views; ++i) {
+    int rc = check_view(c, &views[i]);
+    if (rc != VCY_OK) return rc;
+    if (!masks_host[i]) {
+      set_error("null silhouette");
+      return VCY_ERR_INVALID_ARG;
+    }
+    max_px = std::max(max_px, (size_t)views[i].width * views[i].height);
+  }
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  const vcy_update_option& u = c->opt.update_option;
+  const int chunk = fused_max_views();
+  const int per_set = std::min(chunk, n_views);
+  const size_t px_al = (max_px + 255) / 256 * 256;
+  // [2 sets][per_set] SDF images + [2 sets][per_set] masks + one transform scratch
+  const size_t sz_sdf = px_al * sizeof(float), sz_mask = px_al;
+  const size_t total = 2 * per_set * (sz_sdf + sz_mask) + device_make_sdf_scratch_bytes(1, (int)max_px) + 256;
+  char* pool = nullptr;
+  hipStream_t aux = nullptr;
+  hipEvent_t ready[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+  int rc = VCY_OK;
+  auto fail_hip = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == VCY_OK) {
+      set_error("%s failed: %s", what, hipGetErrorString(e));
+      rc = VCY_ERR_HIP;
+    }
+    return e != hipSuccess;
+  };
+  if (fail_hip(hipMalloc(&pool, total), "hipMalloc")) return rc;
+  fail_hip(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking), "hipStreamCreate");
+  for (int k = 0; k < 2 && rc == VCY_OK; ++k) {
+    fail_hip(hipEventCreateWithFlags(&ready[k], hipEventDisableTiming), "hipEventCreate");
+    fail_hip(hipEventCreateWithFlags(&consumed[k], hipEventDisableTiming), "hipEventCreate");
+  }
+  char* scratch = pool + 2 * per_set * (sz_sdf + sz_mask);
+  auto sdf_buf = [&](int set, int j) { return (float*)(pool + ((size_t)set * per_set + j) * sz_sdf); };
+  auto mask_buf = [&](int set, int j) {
+    return (uint8_t*)(pool + 2 * per_set * sz_sdf + ((size_t)set * per_set + j) * sz_mask);
+  };
+  const int n_chunks = (n_views + chunk - 1) / chunk;
+  // producer for chunk ci: upload + SDF on the aux stream
+  auto produce = [&](int ci) {
+    const int set = ci & 1, first = ci * chunk, m = std::min(chunk, n_views - first);
+    if (ci >= 2) fail_hip(hipStreamWaitEvent(aux, consumed[set], 0), "hipStreamWaitEvent");
+    for (int j = 0; j < m && rc == VCY_OK; ++j) {
+      const vcy_view& v = views[first + j];
+      const size_t npx = (size_t)v.width * v.height;
+      if (fail_hip(hipMemcpyAsync(mask_buf(set, j), masks_host[first + j], npx, hipMemcpyHostToDevice, aux),
+                   "mask upload"))
+        break;
+      // MakeSignedDistanceField(...), reference voxel_carver.cc:405-408
+      int r2 = device_make_sdf(aux, mask_buf(set, j), v.width, v.height, v.roi_min, v.roi_max,
+                               c->opt.sdf_minmax_normalize != 0, u.use_truncation != 0, u.truncation_band, scratch,
+                               sdf_buf(set, j));
+      if (r2 != VCY_OK && rc == VCY_OK) rc = r2;
+    }
+    fail_hip(hipEventRecord(ready[set], aux), "hipEventRecord");
+  };
+  if (rc == VCY_OK) produce(0);
+  for (int ci = 0; ci < n_chunks && rc == VCY_OK; ++ci) {
+    const int set = ci & 1, first = ci * chunk, m = std::min(chunk, n_views - first);
+    if (ci + 1 < n_chunks) produce(ci + 1);  // next chunk's SDFs build while this chunk carves
+    if (rc != VCY_OK) break;
+    fail_hip(hipStreamWaitEvent(c->stream, ready[set], 0), "hipStreamWaitEvent");
+    std::vector<const float*> ptrs(m);
+    for (int j = 0; j < m; ++j) ptrs[j] = sdf_buf(set, j);
+    int r2 = launch_carve(c, m, views + first, ptrs.data());
+    if (r2 != VCY_OK) rc = r2;
+    fail_hip(hipEventRecord(consumed[set], c->stream), "hipEventRecord");
+  }
+  (void)hipStreamSynchronize(c->stream);
+  if (aux) (void)hipStreamSynchronize(aux);
+  for (int k = 0; k < 2; ++k) {
+    if (ready[k]) (void)hipEventDestroy(ready[k]);
+    if (consumed[k]) (void)hipEventDestroy(consumed[k]);
+  }
+  if (aux) (void)hipStreamDestroy(aux);
+  (void)hipFree(pool);
+  return rc;
+}
+
+// Voxel state at arbitrary voxel ids (global ids of this slab), gathered on the device.
+__global__ void gather_state_kernel(const float* __restrict__ sdf, const void* __restrict__ cnt, int cnt_bytes,
+                                    const long long* __restrict__ ids, int64_t n, long long first_id,
+                                    float* __restrict__ out_sdf, int* __restrict__ out_cnt) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long local = ids[i] - first_id;
+  out_sdf[i] = sdf[local];
+  out_cnt[i] = cnt_bytes == 1 ? (int)((const uint8_t*)cnt)[local]
+             : cnt_bytes == 2 ? (int)((const uint16_t*)cnt)[local] : ((const int*)cnt)[local];
+}
+
+int vcy_download_voxels(vcy_ctx* c, int64_t n, const int64_t* voxel_ids, float* sdf, int32_t* update_num) {
+  if (!c || n < 0 || (n > 0 && (!voxel_ids || !sdf || !update_num))) {
+    set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  if (n == 0) return VCY_OK;
+  const int64_t first = (int64_t)c->z0 * c->slice, last = (int64_t)c->z1 * c->slice;
+  for (int64_t i = 0; i < n; ++i)
+    if (voxel_ids[i] < first || voxel_ids[i] >= last) {
+      set_error("voxel id %lld outside this slab", (long long)voxel_ids[i]);
+      return VCY_ERR_INVALID_ARG;
+    }
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  char* d = nullptr;
+  VCY_HIP_CHECK(hipMalloc(&d, (size_t)n * 16));
+  long long* d_ids = (long long*)d;
+  float* d_s = (float*)(d + (size_t)n * 8);
+  int* d_n = (int*)(d + (size_t)n * 12);
+  hipError_t e = hipMemcpyAsync(d_ids, voxel_ids, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(gather_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       c->owned_slab_sdf(), c->owned_slab_cnt(), c->cnt_bytes, d_ids, n, (long long)first, d_s, d_n);
+    e = hipMemcpyAsync(sdf, d_s, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(update_num, d_n, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) {
+    set_error("vcy_download_voxels: %s", hipGetErrorString(e));
+    return VCY_ERR_HIP;
+  }
+  return VCY_OK;
+}
+
 int vcy_distance_transform_l1(const uint8_t* mask, int w, int h, const int32_t rmin[2],
                               const int32_t rmax[2], float* out) {
   if (!mask || !out || w <= 0 || h <= 0 || rmin[0] < 0 || rmin[1] < 0 || rmax[0] >= w || rmax[1] >= h) {

@@ -129,25 +129,19 @@ bool VoxelCarver::Carve(const Camera& camera, const Image1f& sdf) {
 }
 
 bool VoxelCarver::Carve(const std::vector<const Camera*>& cameras, const std::vector<Image1b>& silhouettes) {
-  if (!impl_->ctx || cameras.size() != silhouettes.size()) return false;
-  const VoxelCarverOption& o = impl_->option;
+  if (!impl_->ctx || cameras.size() != silhouettes.size() || cameras.empty()) return false;
   const int n = static_cast<int>(cameras.size());
   std::vector<vcy_view> views(n);
-  std::vector<float*> dev(n, nullptr);
-  bool ok = true;
-  for (int i = 0; i < n && ok; ++i) {
+  std::vector<const uint8_t*> masks(n);
+  for (int i = 0; i < n; ++i) {
     const Image1b& s = silhouettes[i];
-    const int32_t rmin[2] = {0, 0}, rmax[2] = {s.width() - 1, s.height() - 1};
-    views[i] = ToView(*cameras[i], Eigen::Vector2i(0, 0), Eigen::Vector2i(rmax[0], rmax[1]), s.width(), s.height());
-    // MakeSignedDistanceField on the device: only the 8-bit mask crosses PCIe
-    ok = vcy_make_sdf_device(impl_->ctx, s.data().data(), s.width(), s.height(), rmin, rmax,
-                             o.sdf_minmax_normalize, o.update_option.use_truncation,
-                             o.update_option.truncation_band, &dev[i]) == VCY_OK;
+    views[i] = ToView(*cameras[i], Eigen::Vector2i(0, 0), Eigen::Vector2i(s.width() - 1, s.height() - 1), s.width(),
+                      s.height());
+    masks[i] = s.data().data();
   }
-  if (ok) ok = vcy_carve_batch_device(impl_->ctx, n, views.data(), dev.data()) == VCY_OK;
+  // masks are streamed to the device, SDFs built there, views fused in chunks of 32
+  const bool ok = vcy_carve_batch_silhouettes(impl_->ctx, n, views.data(), masks.data()) == VCY_OK;
   if (!ok) LOGE("%s\n", vcy_last_error());
-  for (float* p : dev)
-    if (p) vcy_device_free(impl_->ctx, p);
   return ok;
 }
 
