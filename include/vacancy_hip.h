@@ -219,7 +219,9 @@ int vcy_memcpy_d2h(vcy_ctx* ctx, void* dst_host, const void* src_device, int64_t
  * asynchronous on the context's stream. */
 int vcy_reset(vcy_ctx* ctx);
 /* Tuning knobs that never change results.  "fused" (default 1): 0 forces one kernel launch
- * per view (the generic kernel) instead of the fused multi-view kernel. */
+ * per view (the generic kernel) instead of the fused multi-view kernel.  "cull" (default 1): 0 never
+ * drops provably idle (brick, view) pairs.  "tile" (default 0 = chosen from the pixel footprint of a
+ * voxel): 1 / 2 force the small / big LDS tile of the fused kernel. */
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all launches. */
 int vcy_set_stream(vcy_ctx* ctx, void* hip_stream);

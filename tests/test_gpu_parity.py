@@ -207,17 +207,18 @@ def test_view_dropping_is_exact(kw):
     for i in range(nv):
         orc.carve(views[i], sdfs[i])
     os_, ou = orc.download()
-    for fused, cull in ((1, 1), (1, 0), (0, 0)):
+    for fused, cull, tile in ((1, 1, 0), (1, 1, 2), (1, 0, 1), (0, 0, 0)):
         dev = vc.VoxelCarver(opt)
         assert dev.Init()
         dev.set_param("fused", fused)
         dev.set_param("cull", cull)
+        dev.set_param("tile", tile)
         devs = [dev.upload_sdf(s) for s in sdfs]
         assert dev.CarveBatchDevice(views, devs), vc.last_error()
         ds, du = dev.download()
         for d in devs:
             dev.free_device(d)
-        assert np.array_equal(du, ou), (kw, fused, cull, int((du != ou).sum()))
+        assert np.array_equal(du, ou), (kw, fused, cull, tile, int((du != ou).sum()))
         # NaN voxels (only the NaN/inf-poisoned SDFs produce them) must be NaN on both sides;
         # their sign/payload is not defined by IEEE-754 and differs between x86 and gfx950
         # for generated NaNs (inf - inf).  Everything else is compared bit for bit.
@@ -407,3 +408,25 @@ def test_streamed_silhouette_batch_equals_per_view_calls():
         ids = rng.randint(0, n ** 3, 1000)
         qs, qu = a.download_voxels(ids)
         assert np.array_equal(qs.view(np.uint32), sa[ids].view(np.uint32)) and np.array_equal(qu, ua[ids])
+
+
+@pytest.mark.parametrize("res", [10.0, 3.0])
+def test_bunny_scale_big_tiles(res):
+    """Voxels of >= 1 pixel (the reference's own demo scale): the fused kernel with the big LDS tile,
+    the small one (mostly the generic in-kernel path) and the per-view kernel all equal the oracle."""
+    opt = B.bunny_option(res)
+    views = B.bunny_views(lambda t, q: synth.affine_inverse(synth.pose_from_tum(t, q)))
+    masks = B.load_masks()
+    sdfs = [O.make_sdf(m) for m in masks]
+    orc = O.OracleGrid(opt)
+    for v, s in zip(views, sdfs):
+        orc.carve(v, s)
+    os_, ou = orc.download()
+    for tile in (0, 1, 2):
+        dev = vc.VoxelCarver(opt)
+        assert dev.Init()
+        dev.set_param("tile", tile)
+        devs = [dev.upload_sdf(s) for s in sdfs]
+        assert dev.CarveBatchDevice(views, devs), vc.last_error()
+        ds, du = dev.download()
+        assert np.array_equal(du, ou) and np.array_equal(ds.view(np.uint32), os_.view(np.uint32)), (res, tile)

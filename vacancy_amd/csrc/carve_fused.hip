@@ -35,7 +35,8 @@ namespace {
 constexpr int BX = 32, BY = 8, BZ = 8;  // voxels per workgroup: four 8x8x8 wave bricks along x
 constexpr int WX = 8;                    // wave brick is WX x BY x BZ, lane = (x & 7) | (y << 3)
 constexpr int kMaxFusedViews = 32;
-constexpr int kTileQuads = 128;          // per wave and buffer (2 KB); 2 quads per lane at most
+constexpr int kTileSmall = 128;          // quads per wave tile (2 KB): <= 2 per lane, prefetched in registers
+constexpr int kTileBig = 512;            // 8 KB per wave: footprints up to ~1.4 px per voxel, filled in place
 
 struct FusedView {
   ViewParams v;
@@ -47,7 +48,7 @@ struct TileInfo {
   float pitchf;
   int base;                      // -(ty0*tw + tx0)
   int tx0, ty0, tw, nq;          // nq = tw*th quads; 0: no tile for this view
-  unsigned magic;                // ceil(2^16 / tw): q / tw == (q * magic) >> 16 for q < 128
+  float inv_tw;                  // 1 / tw: q / tw == (int)((q + 0.5f) * inv_tw) for q < 2^12
   float ub;                      // upper bound of any sample taken from this tile (+inf: unknown)
 };
 
@@ -107,6 +108,10 @@ __device__ __forceinline__ void apply_sample(bool ok, float dist, float wgt, flo
   }
 }
 
+// q / d for 0 <= q < 4096, 1 <= d <= 1024, given inv = 1.0f / d: (q + 0.5) / d is never within
+// 0.5 / d of an integer, far more than the float rounding of the product.
+__device__ __forceinline__ int div_small(int q, float inv) { return (int)(((float)q + 0.5f) * inv); }
+
 struct QuadRegs {
   float4 q0, q1;
 };
@@ -120,10 +125,10 @@ __device__ __forceinline__ void tile_prefetch(const ViewParams& v, const TileInf
   const int tw = __builtin_amdgcn_readfirstlane(ti.tw);
   const int tx0 = __builtin_amdgcn_readfirstlane(ti.tx0);
   const int ty0 = __builtin_amdgcn_readfirstlane(ti.ty0);
-  const unsigned magic = __builtin_amdgcn_readfirstlane(ti.magic);
+  const float inv_tw = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ti.inv_tw)));
   gfloat_ptr img = (gfloat_ptr)v.sdf;
   if (lane < nq) {
-    const int j = (int)(((unsigned)lane * magic) >> 16), i = lane - j * tw;
+    const int j = div_small(lane, inv_tw), i = lane - j * tw;
     const int xx = tx0 + i, yy = ty0 + j;
     const int xx1 = min(xx + 1, v.roi_max_xi), yy1 = min(yy + 1, v.roi_max_yi);
     gfloat_ptr r0 = img + (int64_t)v.width * yy;
@@ -132,7 +137,7 @@ __device__ __forceinline__ void tile_prefetch(const ViewParams& v, const TileInf
   }
   if (nq > 64 && lane + 64 < nq) {
     const int q = lane + 64;
-    const int j = (int)(((unsigned)q * magic) >> 16), i = q - j * tw;
+    const int j = div_small(q, inv_tw), i = q - j * tw;
     const int xx = tx0 + i, yy = ty0 + j;
     const int xx1 = min(xx + 1, v.roi_max_xi), yy1 = min(yy + 1, v.roi_max_yi);
     gfloat_ptr r0 = img + (int64_t)v.width * yy;
@@ -148,13 +153,32 @@ __device__ __forceinline__ float wave_min(float v) {
   return v;
 }
 
-template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX>
+// Fills a whole (big) tile in place: lane q, q+64, ... (no register prefetch).
+__device__ __forceinline__ void tile_fill(const ViewParams& v, const TileInfo& ti, int lane, float4* tile) {
+  const int nq = __builtin_amdgcn_readfirstlane(ti.nq);
+  const int tw = __builtin_amdgcn_readfirstlane(ti.tw);
+  const int tx0 = __builtin_amdgcn_readfirstlane(ti.tx0);
+  const int ty0 = __builtin_amdgcn_readfirstlane(ti.ty0);
+  const float inv_tw = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ti.inv_tw)));
+  gfloat_ptr img = (gfloat_ptr)v.sdf;
+  for (int q = lane; q < nq; q += 64) {
+    const int j = div_small(q, inv_tw), i = q - j * tw;
+    const int xx = tx0 + i, yy = ty0 + j;
+    const int xx1 = min(xx + 1, v.roi_max_xi), yy1 = min(yy + 1, v.roi_max_yi);
+    gfloat_ptr r0 = img + (int64_t)v.width * yy;
+    gfloat_ptr r1 = img + (int64_t)v.width * yy1;
+    tile[q] = make_float4(r0[xx], r0[xx1], r1[xx], r1[xx1]);
+  }
+}
+
+template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX, int TQ>
 __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
                                                           const FusedView* __restrict__ views,
                                                           const float* __restrict__ c2_all,
                                                           int nviews, ModeParams mode, int nbx,
                                                           int nby, int cull_enabled) {
-  __shared__ float4 tile_all[4][kTileQuads];
+  __shared__ float4 tile_all[4][TQ];
+  constexpr bool kPrefetch = TQ <= 128;  // two quads per lane fit in registers
   __shared__ TileInfo tinfo_all[4][kMaxFusedViews];
   // A view can be dropped for a whole wave brick when no voxel of the brick can change:
   //   - use_truncation and every sample is provably < -1 (voxel_carver.cc:478), or
@@ -218,7 +242,7 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
       ti.pitchf = 0.0f;
       ti.base = 0;
       ti.tx0 = ti.ty0 = ti.tw = ti.nq = 0;
-      ti.magic = 0;
+      ti.inv_tw = 1.0f;
       ti.ub = INFINITY;  // never dropped
       if (!bad) {
         // one pixel of slack on each side covers the rounding of the corner projections
@@ -227,12 +251,12 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
         const int tx1 = min((int)floorf(umax) + 1, v.roi_max_xi);
         const int ty1 = min((int)floorf(wmax) + 1, v.roi_max_yi);
         const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
-        if (tw > 0 && th > 0 && tw <= kTileQuads && th <= kTileQuads && tw * th <= kTileQuads) {
+        if (tw > 0 && th > 0 && tw <= TQ && th <= TQ && tw * th <= TQ) {
           ti.tx0 = tx0;
           ti.ty0 = ty0;
           ti.tw = tw;
           ti.nq = tw * th;
-          ti.magic = (65536u + (unsigned)tw - 1u) / (unsigned)tw;
+          ti.inv_tw = 1.0f / (float)tw;
           ti.pitchf = (float)tw;
           ti.base = -(ty0 * tw + tx0);
           ti.lo_x = (float)tx0;
@@ -246,13 +270,13 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
             // maximum over every pixel a tap of this tile can read
             const int pw = min(tx1 + 1, v.roi_max_xi) - tx0 + 1;
             const int ph = min(ty1 + 1, v.roi_max_yi) - ty0 + 1;
-            const int npx = pw * ph;  // <= 258
-            const unsigned pmagic = (65536u + (unsigned)pw - 1u) / (unsigned)pw;
+            const int npx = pw * ph;
+            const float inv_pw = 1.0f / (float)pw;
             gfloat_ptr img = (gfloat_ptr)v.sdf;
             float m = -INFINITY;
             int has_nan = 0;
             for (int p = corner; p < npx; p += 8) {
-              const int j = (int)(((unsigned)p * pmagic) >> 16), i = p - j * pw;
+              const int j = div_small(p, inv_pw), i = p - j * pw;
               const float t = img[(int64_t)v.width * (ty0 + j) + (tx0 + i)];
               has_nan |= (t != t);
               m = fmaxf(m, t);
@@ -319,7 +343,8 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
   unsigned long long live = live_views();
   int vi = live ? (__ffsll((long long)live) - 1) : nviews;
   QuadRegs pre;
-  if (vi < nviews) tile_prefetch(views[vi].v, tinfo[vi], lane, &pre);
+  pre.q0 = pre.q1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (kPrefetch && vi < nviews) tile_prefetch(views[vi].v, tinfo[vi], lane, &pre);
 
   // ---- views ------------------------------------------------------------------------------
   while (vi < nviews) {
@@ -327,12 +352,16 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
     cfloat_ptr c2 = (cfloat_ptr)(c2_all + (size_t)vi * 3 * g.nz_local);
     // stage this view's tile (wave-private: program order is enough)
     wave_lds_fence();
-    tile[lane] = pre.q0;
-    tile[lane + 64] = pre.q1;
+    if (kPrefetch) {
+      tile[lane] = pre.q0;
+      tile[lane + 64] = pre.q1;
+    } else {
+      tile_fill(v, tinfo[vi], lane, tile);
+    }
     wave_lds_fence();
     // the next live view's tile is fetched while this one is computed
     int vnext = next_view(live, vi);
-    if (vnext < nviews) tile_prefetch(views[vnext].v, tinfo[vnext], lane, &pre);
+    if (kPrefetch && vnext < nviews) tile_prefetch(views[vnext].v, tinfo[vnext], lane, &pre);
 
     const float lo_x = tinfo[vi].lo_x, hi_x = tinfo[vi].hi_x;
     const float lo_y = tinfo[vi].lo_y, hi_y = tinfo[vi].hi_y;
@@ -364,7 +393,7 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
       const float lu = u - fu, lv = w - fw;
       // any index is harmless when !in_tile (the sample is discarded); keep it inside the tile
       const unsigned idx = min((unsigned)((int)__builtin_fmaf(fw, pitchf, fu) + base),
-                               (unsigned)(kTileQuads - 1));
+                               (unsigned)(TQ - 1));
       const float4 q = tile[idx];
       const float a = (1.0f - lu) * (1.0f - lv) * q.x;
       const float bb = lu * (1.0f - lv) * q.y;
@@ -395,7 +424,7 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
       const int v2 = next_view(live, vi);
       if (v2 != vnext) {
         vnext = v2;
-        if (vnext < nviews) tile_prefetch(views[vnext].v, tinfo[vnext], lane, &pre);
+        if (kPrefetch && vnext < nviews) tile_prefetch(views[vnext].v, tinfo[vnext], lane, &pre);
       }
     }
     vi = vnext;
@@ -417,35 +446,38 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
 }
 
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF>
-void launch_fused_4(bool checkmax, dim3 grid, hipStream_t s, const GridParams& g, const FusedView* dv,
+void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const GridParams& g, const FusedView* dv,
                     const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull) {
-  if (checkmax)
-    hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, true>), grid, dim3(256), 0, s, g,
-                       dv, c2, nv, m, nbx, nby, cull);
-  else
-    hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, false>), grid, dim3(256), 0, s, g,
-                       dv, c2, nv, m, nbx, nby, cull);
+#define VCY_FUSED(CM, TQ_)                                                                                  \
+  hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, CM, TQ_>), grid, dim3(256), 0, s, g, dv, \
+                     c2, nv, m, nbx, nby, cull)
+  if (big) {
+    if (checkmax) VCY_FUSED(true, kTileBig); else VCY_FUSED(false, kTileBig);
+  } else {
+    if (checkmax) VCY_FUSED(true, kTileSmall); else VCY_FUSED(false, kTileSmall);
+  }
+#undef VCY_FUSED
 }
 
 template <typename CountT, int UPDATE>
-void launch_fused_2(bool trunc, bool samef, bool checkmax, dim3 grid, hipStream_t s, const GridParams& g,
+void launch_fused_2(bool big, bool trunc, bool samef, bool checkmax, dim3 grid, hipStream_t s, const GridParams& g,
                     const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull) {
   if (trunc) {
-    if (samef) launch_fused_4<CountT, UPDATE, true, true>(checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
-    else launch_fused_4<CountT, UPDATE, true, false>(checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
+    if (samef) launch_fused_4<CountT, UPDATE, true, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
+    else launch_fused_4<CountT, UPDATE, true, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
   } else {
-    if (samef) launch_fused_4<CountT, UPDATE, false, true>(checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
-    else launch_fused_4<CountT, UPDATE, false, false>(checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
+    if (samef) launch_fused_4<CountT, UPDATE, false, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
+    else launch_fused_4<CountT, UPDATE, false, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
   }
 }
 
 template <typename CountT>
-void launch_fused_1(int update, bool trunc, bool samef, bool checkmax, dim3 grid, hipStream_t s,
+void launch_fused_1(bool big, int update, bool trunc, bool samef, bool checkmax, dim3 grid, hipStream_t s,
                     const GridParams& g, const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull) {
   if (update == VCY_UPDATE_MAX)
-    launch_fused_2<CountT, VCY_UPDATE_MAX>(trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
+    launch_fused_2<CountT, VCY_UPDATE_MAX>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
   else
-    launch_fused_2<CountT, VCY_UPDATE_WEIGHTED_AVERAGE>(trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
+    launch_fused_2<CountT, VCY_UPDATE_WEIGHTED_AVERAGE>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
 }
 
 bool sane(float f) { return f >= 0x1p-40f && f <= 0x1p40f; }
@@ -524,11 +556,32 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   // update_num can only exceed voxel_max_update_num after more than that many views
   const bool checkmax = c->views_carved + n_views > (int64_t)u.voxel_max_update_num;
   const dim3 grid((unsigned)nblocks);
+  // Tile size: footprint of an 8x8x8 wave brick in pixels ~ (8*sqrt(3)*pixels_per_voxel + 3)^2.  The
+  // small tile (register prefetch) covers sub-pixel voxels; the big one up to ~1.4 px per voxel; wider
+  // footprints take the generic path inside the kernel either way.
+  bool big = false;
+  {
+    const float res = c->opt.resolution;
+    float worst = 0.0f;
+    for (int vi = 0; vi < n_views; ++vi) {
+      // pixels per voxel at the centre of the slab (bricks much closer to the camera than that
+      // overflow the tile and take the generic path on their own)
+      const float X = 0.5f * (c->h_px_min + c->h_px_max), Y = 0.5f * (c->h_py_min + c->h_py_max);
+      const float Z = 0.5f * (c->h_pz[c->z0] + c->h_pz[c->z1 - 1]);
+      const float pz = vp[vi].t[2] + (vp[vi].r[2][0] * X + (vp[vi].r[2][1] * Y + vp[vi].r[2][2] * Z));
+      const float f = std::max(vp[vi].fx, vp[vi].fy);
+      worst = std::max(worst, pz > 0.0f ? f * res / pz : INFINITY);
+    }
+    const float side = 8.0f * 1.7320508f * worst + 3.0f;
+    big = side * side > (float)kTileSmall;
+    if (c->tile_mode == 1) big = false;
+    if (c->tile_mode == 2) big = true;
+  }
   if (c->cnt_bytes == 1)
-    launch_fused_1<uint8_t>(u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, g, d_views,
+    launch_fused_1<uint8_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, g, d_views,
                             d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0);
   else
-    launch_fused_1<uint16_t>(u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, g, d_views,
+    launch_fused_1<uint16_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, g, d_views,
                              d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0);
   VCY_HIP_CHECK(hipGetLastError());
   return VCY_OK;

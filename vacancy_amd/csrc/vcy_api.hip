@@ -188,6 +188,13 @@ int vcy_create(const vcy_carver_option* o, int device_id, int z_begin, int z_end
     for (int i = 0; i < n[a]; ++i)
       p[i] = diff * (static_cast<float>(i) / static_cast<float>(n[a])) + o->bb_min[a] + offset;
     VCY_TRY(hipMemcpy(d_axis[a], p.data(), sizeof(float) * n[a], hipMemcpyHostToDevice));
+    if (a == 0) {
+      c->h_px_min = p.front();
+      c->h_px_max = p.back();
+    } else if (a == 1) {
+      c->h_py_min = p.front();
+      c->h_py_max = p.back();
+    }
     if (a == 2) {
       c->h_pz = new float[n[2]];
       std::memcpy(c->h_pz, p.data(), sizeof(float) * n[2]);
@@ -251,6 +258,11 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
   if (!c || !name) return VCY_ERR_INVALID_ARG;
   if (std::strcmp(name, "fused") == 0) {
     c->use_fused = value != 0;
+    return VCY_OK;
+  }
+  if (std::strcmp(name, "tile") == 0) {
+    if (value < 0 || value > 2) return VCY_ERR_INVALID_ARG;
+    c->tile_mode = value;
     return VCY_OK;
   }
   if (std::strcmp(name, "cull") == 0) {

@@ -60,8 +60,10 @@ struct vcy_ctx {
   float* d_py = nullptr;
   float* d_pz = nullptr;
 
+  int tile_mode = 0;                  // 0 auto, 1 small LDS tile, 2 big LDS tile (vcy_set_param "tile")
   bool use_cull = true;               // vcy_set_param("cull", 0): never drop provably idle views
   bool use_fused = true;              // vcy_set_option("fused", 0) forces the per-view kernel
+  float h_px_min = 0, h_px_max = 0, h_py_min = 0, h_py_max = 0;  // extreme voxel centres
   float* h_pz = nullptr;              // host copy of d_pz (per-view z tables of the fused carve)
   void* d_fused_scratch = nullptr;    // view blocks + z tables of the fused carve kernel
   size_t fused_scratch_bytes = 0;
