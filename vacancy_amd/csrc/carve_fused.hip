@@ -146,11 +146,22 @@ __device__ __forceinline__ void tile_prefetch(const ViewParams& v, const TileInf
   }
 }
 
-// min over the wave (NaN operands are ignored, like the `dist > s` test ignores them)
+// min over the wave (NaN operands are ignored, like the `dist > s` test ignores them); DPP row
+// reduction + one readlane per row, no LDS traffic
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) v = fminf(v, __shfl_xor(v, d, 64));
-  return v;
+#define VCY_DPP_MIN(CTRL)                                                                              \
+  v = fminf(v, __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, \
+                                                                     0xF, false)))
+  VCY_DPP_MIN(0xB1);   // quad_perm [1,0,3,2]
+  VCY_DPP_MIN(0x4E);   // quad_perm [2,3,0,1]
+  VCY_DPP_MIN(0x141);  // row_half_mirror
+  VCY_DPP_MIN(0x140);  // row_mirror: every lane of a 16-lane row now holds the row minimum
+#undef VCY_DPP_MIN
+  const float r0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 0));
+  const float r1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 16));
+  const float r2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 32));
+  const float r3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 48));
+  return fminf(fminf(r0, r1), fminf(r2, r3));
 }
 
 // Fills a whole (big) tile in place: lane q, q+64, ... (no register prefetch).
@@ -225,17 +236,26 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
         pc[i] = v.t[i] + (v.r[i][0] * cpx + (v.r[i][1] * cpy + v.r[i][2] * cpz));
       const float u = v.fx / pc[2] * pc[0] + v.cx;
       const float w = v.fy / pc[2] * pc[1] + v.cy;
-      // the whole (convex) brick is in front of the camera iff all 8 corners are
-      int bad = !(pc[2] > 0.0f) || !(fabsf(u) < 1.0e8f) || !(fabsf(w) < 1.0e8f);
-      float umin = u, umax = u, wmin = w, wmax = w;
+      // The whole (convex) brick is in front of the camera iff all 8 corners are.  The footprint
+      // rectangle below is only trusted when the computed image coordinates are accurate to a small
+      // fraction of a pixel: depth spread of the brick below 4x and no catastrophic cancellation in
+      // pc.z (then every voxel of the brick projects within `margin` of the corner hull: the exact
+      // projections are inside it by convexity, computed ones differ by a few ulps).
+      const float zmag = fabsf(v.t[2]) + fabsf(v.r[2][0] * cpx) + fabsf(v.r[2][1] * cpy) + fabsf(v.r[2][2] * cpz);
+      int bad = !(pc[2] > 0.0f) || !(fabsf(u) < 1.0e6f) || !(fabsf(w) < 1.0e6f) || !(pc[2] >= zmag * 0x1p-12f);
+      float umin = u, umax = u, wmin = w, wmax = w, zmin = pc[2], zmax = pc[2];
 #pragma unroll
       for (int d = 1; d < 8; d <<= 1) {
         umin = fminf(umin, __shfl_xor(umin, d, 64));
         umax = fmaxf(umax, __shfl_xor(umax, d, 64));
         wmin = fminf(wmin, __shfl_xor(wmin, d, 64));
         wmax = fmaxf(wmax, __shfl_xor(wmax, d, 64));
+        zmin = fminf(zmin, __shfl_xor(zmin, d, 64));
+        zmax = fmaxf(zmax, __shfl_xor(zmax, d, 64));
         bad |= __shfl_xor(bad, d, 64);
       }
+      bad |= !(zmin * 4.0f >= zmax);
+      const float margin = 0.125f + 0x1p-16f * fmaxf(fmaxf(fabsf(umin), fabsf(umax)), fmaxf(fabsf(wmin), fabsf(wmax)));
       TileInfo ti;
       ti.lo_x = ti.lo_y = INFINITY;  // nothing passes the tile test
       ti.hi_x = ti.hi_y = -INFINITY;
@@ -245,11 +265,10 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
       ti.inv_tw = 1.0f;
       ti.ub = INFINITY;  // never dropped
       if (!bad) {
-        // one pixel of slack on each side covers the rounding of the corner projections
-        const int tx0 = max((int)floorf(umin) - 1, v.roi_min_xi);
-        const int ty0 = max((int)floorf(wmin) - 1, v.roi_min_yi);
-        const int tx1 = min((int)floorf(umax) + 1, v.roi_max_xi);
-        const int ty1 = min((int)floorf(wmax) + 1, v.roi_max_yi);
+        const int tx0 = max((int)floorf(umin - margin), v.roi_min_xi);
+        const int ty0 = max((int)floorf(wmin - margin), v.roi_min_yi);
+        const int tx1 = min((int)floorf(umax + margin), v.roi_max_xi);
+        const int ty1 = min((int)floorf(wmax + margin), v.roi_max_yi);
         const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
         if (tw > 0 && th > 0 && tw <= TQ && th <= TQ && tw * th <= TQ) {
           ti.tx0 = tx0;
@@ -270,16 +289,16 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
             // maximum over every pixel a tap of this tile can read
             const int pw = min(tx1 + 1, v.roi_max_xi) - tx0 + 1;
             const int ph = min(ty1 + 1, v.roi_max_yi) - ty0 + 1;
-            const int npx = pw * ph;
-            const float inv_pw = 1.0f / (float)pw;
             gfloat_ptr img = (gfloat_ptr)v.sdf;
             float m = -INFINITY;
             int has_nan = 0;
-            for (int p = corner; p < npx; p += 8) {
-              const int j = div_small(p, inv_pw), i = p - j * pw;
-              const float t = img[(int64_t)v.width * (ty0 + j) + (tx0 + i)];
-              has_nan |= (t != t);
-              m = fmaxf(m, t);
+            for (int j = 0; j < ph; ++j) {
+              gfloat_ptr row = img + ((unsigned)v.width * (unsigned)(ty0 + j) + (unsigned)tx0);
+              for (int i = corner; i < pw; i += 8) {
+                const float t = row[i];
+                has_nan |= (t != t);
+                m = fmaxf(m, t);
+              }
             }
 #pragma unroll
             for (int d = 1; d < 8; d <<= 1) {
