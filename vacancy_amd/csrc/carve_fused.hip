@@ -65,6 +65,21 @@ __device__ __forceinline__ float div_fast(float n, float d) {
   return __builtin_fmaf(e3, r, q);
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// div_fast on two values at once (v_pk_fma_f32 / v_pk_mul_f32; v_rcp_f32 has no packed form)
+__device__ __forceinline__ f2 div_fast2(float n, f2 d) {
+  const f2 nn = {n, n}, one = {1.0f, 1.0f};
+  f2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const f2 e = __builtin_elementwise_fma(-d, r, one);
+  r = __builtin_elementwise_fma(e, r, r);
+  f2 q = nn * r;
+  const f2 e2 = __builtin_elementwise_fma(-d, q, nn);
+  q = __builtin_elementwise_fma(e2, r, q);
+  const f2 e3 = __builtin_elementwise_fma(-d, q, nn);
+  return __builtin_elementwise_fma(e3, r, q);
+}
+
 // 2^-60 <= z <= 2^60 (also false for negative z, NaN, inf, 0)
 __device__ __forceinline__ bool in_fast_div_range(float z) {
   const unsigned lo = 0x21800000u;  // 2^-60
@@ -394,35 +409,42 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
     // only recorded here and handled below.
     bool slow[BZ];
     bool any_slow = false;
+    // Two voxels (k, k+1) share the packed-FP32 instructions of the depth and of the divide;
+    // within a voxel the (x, y) pair and the (1-l, l) weight pairs are packed.  Every single
+    // operation is still the reference's, in its order (v_pk_* are two independent fp32 ops).
 #pragma unroll
-    for (int k = 0; k < BZ; ++k) {
-      const int zl = min(zl0 + k, g.nz_local - 1);
-      const float pcx = v.t[0] + (c0x + (c1x + c2[zl]));
-      const float pcy = v.t[1] + (c0y + (c1y + c2[g.nz_local + zl]));
-      const float pcz = v.t[2] + (c0z + (c1z + c2[2 * g.nz_local + zl]));
-      const bool zfast = in_fast_div_range(pcz);
-      const float qx = div_fast(v.fx, pcz);
-      const float qy = SAMEF ? qx : div_fast(v.fy, pcz);
-      const float u = qx * pcx + v.cx;
-      const float w = qy * pcy + v.cy;
-      const bool in_tile = zfast && u >= lo_x && u <= hi_x && w >= lo_y && w <= hi_y;
-      slow[k] = !in_tile;
-      any_slow = any_slow || !in_tile;
-      const float fu = floorf(u), fw = floorf(w);
-      const float lu = u - fu, lv = w - fw;
-      // any index is harmless when !in_tile (the sample is discarded); keep it inside the tile
-      const unsigned idx = min((unsigned)((int)__builtin_fmaf(fw, pitchf, fu) + base),
-                               (unsigned)(TQ - 1));
-      const float4 q = tile[idx];
-      const float a = (1.0f - lu) * (1.0f - lv) * q.x;
-      const float bb = lu * (1.0f - lv) * q.y;
-      const float cc = (1.0f - lu) * lv * q.z;
-      const float dd = lu * lv * q.w;
-      const float dist = ((a + bb) + cc) + dd;
-      bool ok = in_tile;
-      if (TRUNC) ok = ok && !(dist < -1.0f);
-      if (CHECKMAX) ok = ok && !(n[k] > g.max_update_num);
-      apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]);
+    for (int kp = 0; kp < BZ; kp += 2) {
+      const int zla = min(zl0 + kp, g.nz_local - 1), zlb = min(zl0 + kp + 1, g.nz_local - 1);
+      const f2 c2z = {c2[2 * g.nz_local + zla], c2[2 * g.nz_local + zlb]};
+      const f2 pcz2 = v.t[2] + (c0z + (c1z + c2z));
+      const f2 qx2 = div_fast2(v.fx, pcz2);
+      const f2 qy2 = SAMEF ? qx2 : div_fast2(v.fy, pcz2);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = kp + h;
+        const int zl = h ? zlb : zla;
+        const float pcz = h ? pcz2.y : pcz2.x;
+        const bool zfast = in_fast_div_range(pcz);
+        const f2 pcxy = (f2){v.t[0], v.t[1]} + ((f2){c0x, c0y} + ((f2){c1x, c1y} + (f2){c2[zl], c2[g.nz_local + zl]}));
+        const f2 uw = (f2){h ? qx2.y : qx2.x, h ? qy2.y : qy2.x} * pcxy + (f2){v.cx, v.cy};
+        const float u = uw.x, w = uw.y;
+        const bool in_tile = zfast && u >= lo_x && u <= hi_x && w >= lo_y && w <= hi_y;
+        slow[k] = !in_tile;
+        any_slow = any_slow || !in_tile;
+        const float fu = floorf(u), fw = floorf(w);
+        const float lu = u - fu, lv = w - fw;
+        const f2 P = {1.0f - lu, lu}, Q = {1.0f - lv, lv};
+        // any index is harmless when !in_tile (the sample is discarded); keep it inside the tile
+        const unsigned idx = min((unsigned)((int)__builtin_fmaf(fw, pitchf, fu) + base), (unsigned)(TQ - 1));
+        const float4 q = tile[idx];
+        const f2 ab = (P * Q.x) * (f2){q.x, q.y};   // ((1-lu)(1-lv)) s00 , (lu (1-lv)) s10
+        const f2 cd = (P * Q.y) * (f2){q.z, q.w};   // ((1-lu) lv) s01   , (lu lv) s11
+        const float dist = ((ab.x + ab.y) + cd.x) + cd.y;
+        bool ok = in_tile;
+        if (TRUNC) ok = ok && !(dist < -1.0f);
+        if (CHECKMAX) ok = ok && !(n[k] > g.max_update_num);
+        apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]);
+      }
     }
     if (any_slow) {
 #pragma unroll
