@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
                                                           const FusedView* __restrict__ views,
                                                           const float* __restrict__ c2_all,
                                                           int nviews, ModeParams mode, int nbx,
-                                                          int nby, int cull_enabled) {
+                                                          int nby, int cull_enabled, int fresh) {
   __shared__ float4 tile_all[4][TQ];
   constexpr bool kPrefetch = TQ <= 128;  // two quads per lane fit in registers
   __shared__ TileInfo tinfo_all[4][kMaxFusedViews];
@@ -345,8 +345,9 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
 #pragma unroll
   for (int k = 0; k < BZ; ++k) {
     const int zl = min(zl0 + k, g.nz_local - 1);
-    s[k] = g.sdf[(int64_t)zl * slice + col];
-    n[k] = (int)cnt[(int64_t)zl * slice + col];
+    // a fresh slab is known to be untouched everywhere: nothing to read
+    s[k] = fresh ? kInvalidSdf : g.sdf[(int64_t)zl * slice + col];
+    n[k] = fresh ? 0 : (int)cnt[(int64_t)zl * slice + col];
   }
 
   // views that may still change something, as a wave-uniform bit mask
@@ -477,7 +478,8 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
     for (int k = 0; k < BZ; ++k) {
       if (zl0 + k < g.nz_local) {
         const int64_t idx = (int64_t)(zl0 + k) * slice + col;
-        if (n[k] != (int)cnt[idx]) {
+        // (a fresh slab has never been written: every voxel is stored)
+        if (fresh || n[k] != (int)cnt[idx]) {
           g.sdf[idx] = s[k];
           cnt[idx] = (CountT)n[k];
         }
@@ -488,10 +490,10 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
 
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF>
 void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const GridParams& g, const FusedView* dv,
-                    const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull) {
+                    const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh) {
 #define VCY_FUSED(CM, TQ_)                                                                                  \
   hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, CM, TQ_>), grid, dim3(256), 0, s, g, dv, \
-                     c2, nv, m, nbx, nby, cull)
+                     c2, nv, m, nbx, nby, cull, fresh)
   if (big) {
     if (checkmax) VCY_FUSED(true, kTileBig); else VCY_FUSED(false, kTileBig);
   } else {
@@ -502,23 +504,23 @@ void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const Gri
 
 template <typename CountT, int UPDATE>
 void launch_fused_2(bool big, bool trunc, bool samef, bool checkmax, dim3 grid, hipStream_t s, const GridParams& g,
-                    const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull) {
+                    const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh) {
   if (trunc) {
-    if (samef) launch_fused_4<CountT, UPDATE, true, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
-    else launch_fused_4<CountT, UPDATE, true, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
+    if (samef) launch_fused_4<CountT, UPDATE, true, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
+    else launch_fused_4<CountT, UPDATE, true, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
   } else {
-    if (samef) launch_fused_4<CountT, UPDATE, false, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
-    else launch_fused_4<CountT, UPDATE, false, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
+    if (samef) launch_fused_4<CountT, UPDATE, false, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
+    else launch_fused_4<CountT, UPDATE, false, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
   }
 }
 
 template <typename CountT>
 void launch_fused_1(bool big, int update, bool trunc, bool samef, bool checkmax, dim3 grid, hipStream_t s,
-                    const GridParams& g, const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull) {
+                    const GridParams& g, const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh) {
   if (update == VCY_UPDATE_MAX)
-    launch_fused_2<CountT, VCY_UPDATE_MAX>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
+    launch_fused_2<CountT, VCY_UPDATE_MAX>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
   else
-    launch_fused_2<CountT, VCY_UPDATE_WEIGHTED_AVERAGE>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull);
+    launch_fused_2<CountT, VCY_UPDATE_WEIGHTED_AVERAGE>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
 }
 
 bool sane(float f) { return f >= 0x1p-40f && f <= 0x1p40f; }
@@ -620,11 +622,12 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   }
   if (c->cnt_bytes == 1)
     launch_fused_1<uint8_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, g, d_views,
-                            d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0);
+                            d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, c->fresh ? 1 : 0);
   else
     launch_fused_1<uint16_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, g, d_views,
-                             d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0);
+                             d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, c->fresh ? 1 : 0);
   VCY_HIP_CHECK(hipGetLastError());
+  c->fresh = false;  // the launch stores every voxel of a fresh slab
   return VCY_OK;
 }
 

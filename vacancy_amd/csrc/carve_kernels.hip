@@ -148,7 +148,12 @@ int launch_carve(vcy_ctx* c, int n_views, const vcy_view* views, const float* co
   std::vector<ViewParams> vp((size_t)n_views);
   for (int i = 0; i < n_views; ++i) fill_view(views[i], sdf_dev[i], max_sdf[i], &vp[i]);
 
-  if (c->use_fused && fused_eligible(c, n_views, views)) {
+  const bool fused = c->use_fused && fused_eligible(c, n_views, views);
+  if (!fused) {
+    int rcm = materialize(c);
+    if (rcm != VCY_OK) return rcm;
+  }
+  if (fused) {
     const int chunk = fused_max_views();
     for (int i = 0; i < n_views; i += chunk) {
       const int m = std::min(chunk, n_views - i);

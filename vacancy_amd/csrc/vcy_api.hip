@@ -28,13 +28,21 @@ __global__ void fill_f32_kernel(float* __restrict__ p, float v, int64_t n) {
 }
 
 int fill_state(vcy_ctx* c) {
-  const int64_t n = c->slice * (int64_t)(c->halo_lo + c->nz_local());
-  const int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 32);
-  hipLaunchKernelGGL(fill_f32_kernel, dim3(grid), dim3(256), 0, c->stream, c->d_sdf, kInvalidSdf, n);
-  VCY_HIP_CHECK(hipGetLastError());
-  VCY_HIP_CHECK(hipMemsetAsync(c->d_cnt, 0, (size_t)n * c->cnt_bytes, c->stream));
+  c->fresh = true;  // written lazily, see vcy_ctx::fresh
   c->views_carved = 0;
   c->halo_valid = false;
+  return VCY_OK;
+}
+
+int materialize(vcy_ctx* c) {
+  if (!c->fresh) return VCY_OK;
+  // only the owned slab: halo slices are written by vcy_halo_install / _unpack
+  const int64_t n = c->slab_voxels();
+  const int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(grid), dim3(256), 0, c->stream, c->owned_slab_sdf(), kInvalidSdf, n);
+  VCY_HIP_CHECK(hipGetLastError());
+  VCY_HIP_CHECK(hipMemsetAsync(c->owned_slab_cnt(), 0, (size_t)n * c->cnt_bytes, c->stream));
+  c->fresh = false;
   return VCY_OK;
 }
 
@@ -360,6 +368,7 @@ int vcy_device_free(vcy_ctx* c, void* p) {
 int vcy_download(vcy_ctx* c, float* sdf, int32_t* update_num) {
   if (!c) return VCY_ERR_NOT_INITIALIZED;
   VCY_HIP_CHECK(hipSetDevice(c->device));
+  { int rcm = materialize(c); if (rcm != VCY_OK) return rcm; }
   VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
   const int64_t n = c->slab_voxels();
   if (sdf)
@@ -382,6 +391,7 @@ int vcy_download(vcy_ctx* c, float* sdf, int32_t* update_num) {
 int vcy_upload(vcy_ctx* c, const float* sdf, const int32_t* update_num) {
   if (!c) return VCY_ERR_NOT_INITIALIZED;
   VCY_HIP_CHECK(hipSetDevice(c->device));
+  { int rcm = materialize(c); if (rcm != VCY_OK) return rcm; }
   VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
   const int64_t n = c->slab_voxels();
   if (sdf)
@@ -445,6 +455,7 @@ int vcy_halo_pack(vcy_ctx* c, void* send) {
     return VCY_ERR_INVALID_ARG;
   }
   VCY_HIP_CHECK(hipSetDevice(c->device));
+  { int rcm = materialize(c); if (rcm != VCY_OK) return rcm; }
   const int64_t s = c->slice;
   const float* sdf_src = c->owned_slab_sdf() + (int64_t)(c->nz_local() - 2) * s;
   const char* cnt_src = (const char*)c->owned_slab_cnt() + (int64_t)(c->nz_local() - 2) * s * c->cnt_bytes;
@@ -743,6 +754,7 @@ int vcy_download_voxels(vcy_ctx* c, int64_t n, const int64_t* voxel_ids, float* 
       return VCY_ERR_INVALID_ARG;
     }
   VCY_HIP_CHECK(hipSetDevice(c->device));
+  { int rcm = materialize(c); if (rcm != VCY_OK) return rcm; }
   char* d = nullptr;
   VCY_HIP_CHECK(hipMalloc(&d, (size_t)n * 16));
   long long* d_ids = (long long*)d;
@@ -792,6 +804,7 @@ int vcy_extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   if (!out) return VCY_ERR_INVALID_ARG;
   std::memset(out, 0, sizeof(*out));
   VCY_HIP_CHECK(hipSetDevice(c->device));
+  { int rcm = materialize(c); if (rcm != VCY_OK) return rcm; }
   return extract_iso(c, iso, linear_interp, out);
 }
 

@@ -51,6 +51,10 @@ struct vcy_ctx {
   int z0 = 0, z1 = 0;          // owned slab [z0, z1)
   int halo_lo = 0;             // slices stored below z0
   bool halo_valid = false;
+  // Lazy initialisation: after vcy_create / vcy_reset the slab is KNOWN to be sdf = lowest(),
+  // update_num = 0 without having been written.  The fused carve starts from that knowledge
+  // (no state read, no fill pass); everything else calls materialize() first.
+  bool fresh = false;
   int64_t slice = 0;           // nx*ny
   int cnt_bytes = 1;
 
@@ -110,6 +114,7 @@ int device_make_sdf(hipStream_t stream, const uint8_t* mask_dev, int w, int h, c
                     float* sdf_dev);
 size_t device_make_sdf_scratch_bytes(int w, int h);
 // utility kernels (vcy_api.hip)
-int fill_state(vcy_ctx* ctx);
+int fill_state(vcy_ctx* ctx);   // marks the slab fresh (lazy)
+int materialize(vcy_ctx* ctx);  // writes the fresh state to HBM if it is still pending
 
 }  // namespace vcy
