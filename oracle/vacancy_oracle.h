@@ -72,6 +72,7 @@ void orc_affine_to_float(const double m[12], float out[12]);
 float orc_focal_from_fov_y(int height, float fov_y_deg);
 
 int orc_omp_max_threads(void);
+void orc_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -137,10 +137,16 @@ class VoxelCarver:
         return self._lib.vcy_carve_device(self._ctx, C.byref(view), sdf_dev) == 0
 
     # -- Carve(vector<Camera>, vector<...>) loop (voxel_carver.cc:516-528), fused on device
-    def CarveBatchDevice(self, views, sdf_devs):
+    @staticmethod
+    def prepare_batch(views, sdf_devs):
+        """ctypes arrays for CarveBatchDevice, built once when the same batch is carved repeatedly."""
         n = len(views)
         arr = (View * n)(*views)
         ptrs = (C.c_void_p * n)(*[p.value if isinstance(p, C.c_void_p) else p for p in sdf_devs])
+        return n, arr, ptrs
+
+    def CarveBatchDevice(self, views, sdf_devs=None):
+        n, arr, ptrs = views if sdf_devs is None else self.prepare_batch(views, sdf_devs)
         return self._lib.vcy_carve_batch_device(self._ctx, n, arr, ptrs) == 0
 
     # -- ExtractIsoSurface(mesh, iso_level, linear_interp)  (voxel_carver.cc:540-543)
