@@ -123,3 +123,45 @@ def test_cpp_facade_host_utilities():
     assert np.array_equal(got[:, 3], np.array(ref["t"], np.float32))
     focal = [np.float32(x) for x in [l for l in out if l.startswith("FOCAL")][0].split()[1:]]
     assert focal[0] == synth.focal_from_fov_y(720, 60.0) and focal[1] == np.float32(639.5)
+
+
+def test_c_abi_argument_validation_without_a_gpu():
+    """Errors the reference reports as `return false` + LOGE come back as negative status codes with
+    the same message, before any device is touched."""
+    import ctypes as C
+    lib = capi.load()
+    ctx = C.c_void_p()
+
+    def create(opt):
+        rc = lib.vcy_create(C.byref(opt), 0, 0, -1, C.byref(ctx))
+        return rc, lib.vcy_last_error().decode()
+
+    rc, msg = create(B.bunny_option(10.0, capi.UpdateOption(voxel_max_update_num=0)))
+    assert rc == -1 and "voxel_max_update_num must be positive" in msg      # voxel_carver.cc:376-379
+    rc, msg = create(B.bunny_option(10.0, capi.UpdateOption(voxel_update_weight=0.0)))
+    assert rc == -1 and "voxel_update_weight must be positive" in msg        # :380-384
+    rc, msg = create(B.bunny_option(10.0, capi.UpdateOption(truncation_band=-1.0)))
+    assert rc == -1 and "truncation_band must be positive" in msg            # :385-389
+    rc, msg = create(B.bunny_option(0.0))
+    assert rc == -1 and "resolution must be positive" in msg                 # :278-281
+    bad = B.bunny_option(10.0)
+    bad.bb_max[1] = bad.bb_min[1]
+    rc, msg = create(bad)
+    assert rc == -1 and "input bounding box is invalid" in msg               # :282-286
+    rc, msg = create(B.bunny_option(10.0, capi.UpdateOption(voxel_update=7)))
+    assert rc == -1
+    # grid sizing without a context: n = (int)((bb_max - bb_min) / resolution)  (:292-296)
+    mn, mx = B.bunny_bb()
+    dims = (C.c_int32 * 3)()
+    assert lib.vcy_compute_dims((C.c_float * 3)(*mn), (C.c_float * 3)(*mx), 10.0, dims) == 0
+    assert list(dims) == GOLD["dims"]["10"]
+    assert lib.vcy_compute_dims((C.c_float * 3)(*mn), (C.c_float * 3)(*mx), 2.5, dims) == 0
+    assert list(dims) == GOLD["dims"]["2.5"]
+    # host SDF entry points validate the ROI
+    mask = np.zeros((8, 8), np.uint8)
+    out = np.zeros((8, 8), np.float32)
+    rmin, rmax = (C.c_int32 * 2)(0, 0), (C.c_int32 * 2)(8, 7)
+    assert lib.vcy_make_sdf(mask.ctypes.data, 8, 8, rmin, rmax, 1, 0, 0.1, out.ctypes.data) == -1
+    # null context
+    assert lib.vcy_sync(None) == -2 and lib.vcy_reset(None) == -2
+    assert lib.vcy_halo_bytes(None) == 0
