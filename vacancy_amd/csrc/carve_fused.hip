@@ -2,19 +2,22 @@
 //
 // Replaces the loop `for each view: Carve(camera, roi, sdf)` (reference voxel_carver.cc:516-528
 // around :415-496).  Voxels are independent and every voxel sees its views in sequence order,
-// so fusing views changes nothing but where the state lives: each workgroup owns a brick of
-// 32x8x8 voxels (x fastest: a wave reads two 128-byte row segments per slice), loads
-// sdf/update_num ONCE, applies all views, writes back only what changed.
+// so fusing views changes nothing but where the state lives.  A workgroup is four independent
+// waves; each WAVE owns an 8x8x8 brick (lane = (x & 7) | (y << 3), 8 voxels along z per lane),
+// loads sdf/update_num ONCE (not at all for a fresh grid), applies all views and writes back only
+// what changed.  The four wave bricks of a workgroup are adjacent in x, so together they read
+// 128-byte row segments.
 //
-// Per view every WAVE stages the footprint of its own 8x8x8 sub-brick in LDS as *quads*
+// Per view the wave stages the image footprint of its brick in a wave-private LDS tile of *quads*
 //   tile[j][i] = { s(x,y), s(x1,y), s(x,y1), s(x1,y1) },  x1 = min(x+1, roi_max.x) ...
 // i.e. the four bilinear taps of pixel (x,y) with the reference's ROI clamps already applied
-// (voxel_carver.cc:51-66), so a sample is ONE ds_read_b128 and no clamp arithmetic.  Tiles
-// are wave-private and double buffered: no workgroup barrier at all, and the global loads of
-// view i+1's tile are in flight while view i is computed.  A voxel whose projection falls outside the
-// staged tile (brick near the camera plane, footprint larger than the LDS budget, outside the
-// ROI) takes the generic global-memory path of carve_common.h, so correctness never depends
-// on the footprint estimate.
+// (voxel_carver.cc:51-66), so a sample is ONE ds_read_b128 and no clamp arithmetic.  No
+// workgroup barrier anywhere; with the small tile the global loads of the next live view's quads
+// fly while the current view is computed.  A voxel whose projection falls outside the staged
+// tile (brick near the camera plane, footprint larger than the tile, outside the ROI) takes the
+// generic global-memory path of carve_common.h, so SAMPLING never depends on the footprint
+// estimate.  DROPPING a view for a brick does (see the kernel): it is only done when the
+// footprint rectangle is provably a superset of every sample, with an explicit error margin.
 //
 // The arithmetic of a sample is the reference's, operation for operation (carve_common.h);
 // the two divides fx/z, fy/z (camera.cc:133-136) use the same Newton sequence the compiler
