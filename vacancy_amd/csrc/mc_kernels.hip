@@ -142,35 +142,55 @@ __global__ __launch_bounds__(256) void mc_bits_kernel(const float* __restrict__ 
   const int lane = threadIdx.x & 63;
   const int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kBitsWordsPerWave;
   if (first >= nwords) return;
-  // (row, word-in-row) of the first word by one division, the rest by stepping
-  int64_t row = first / Wr;
-  int w = (int)(first - row * Wr);
-  float s[kBitsWordsPerWave];
-  int n[kBitsWordsPerWave];
-  bool live[kBitsWordsPerWave];
-#pragma unroll
-  for (int k = 0; k < kBitsWordsPerWave; ++k) {
-    const int x = w * 64 + lane;
-    live[k] = first + k < nwords && x < nx;
-    s[k] = live[k] ? sdf[row * nx + x] : kInvalidSdf;
-    n[k] = live[k] ? (int)cnt[row * nx + x] : 0;
-    if (++w == Wr) {
-      w = 0;
-      ++row;
-    }
-  }
   u64 m_in = 0, m_ok = 0, m_tc = 0;
+  if (nx == Wr * 64 && first + kBitsWordsPerWave <= nwords) {
+    // rows are whole words: voxel index == word * 64 + lane, plain streaming
+    const float* __restrict__ ps = sdf + first * 64 + lane;
+    const CountT* __restrict__ pc = cnt + first * 64 + lane;
+    float s[kBitsWordsPerWave];
+    int n[kBitsWordsPerWave];
 #pragma unroll
-  for (int k = 0; k < kBitsWordsPerWave; ++k) {
-    // `sdf < iso_level` promotes the float to double (marching_cubes.cc:121-128); when iso_level is
-    // itself a float value the comparison is the same in single precision
-    const u64 a = __ballot(live[k] && (ISO_F32 ? s[k] < (float)iso : (double)s[k] < iso));
-    const u64 b = __ballot(live[k] && s[k] != kInvalidSdf);
-    const u64 c = __ballot(live[k] && n[k] >= 1);
-    if (lane == k) {
-      m_in = a;
-      m_ok = b;
-      m_tc = c;
+    for (int k = 0; k < kBitsWordsPerWave; ++k) {
+      s[k] = ps[k * 64];
+      n[k] = (int)pc[k * 64];
+    }
+#pragma unroll
+    for (int k = 0; k < kBitsWordsPerWave; ++k) {
+      // `sdf < iso_level` promotes the float to double (marching_cubes.cc:121-128); when iso_level
+      // is itself a float value the comparison is the same in single precision
+      const u64 a = __ballot(ISO_F32 ? s[k] < (float)iso : (double)s[k] < iso);
+      const u64 b = __ballot(s[k] != kInvalidSdf);
+      const u64 c = __ballot(n[k] >= 1);
+      const bool mine = lane == k;
+      m_in = mine ? a : m_in;
+      m_ok = mine ? b : m_ok;
+      m_tc = mine ? c : m_tc;
+    }
+  } else {
+    // general rows (nx not a multiple of 64, or the tail of the array)
+    int64_t row = first / Wr;
+    int w = (int)(first - row * Wr);
+    for (int k = 0; k < kBitsWordsPerWave; ++k) {
+      const int x = w * 64 + lane;
+      const bool live = first + k < nwords && x < nx;
+      float sv = kInvalidSdf;
+      int nv = 0;
+      if (live) {
+        sv = sdf[row * nx + x];
+        nv = (int)cnt[row * nx + x];
+      }
+      const u64 a = __ballot(live && (ISO_F32 ? sv < (float)iso : (double)sv < iso));
+      const u64 b = __ballot(live && sv != kInvalidSdf);
+      const u64 c = __ballot(live && nv >= 1);
+      if (lane == k) {
+        m_in = a;
+        m_ok = b;
+        m_tc = c;
+      }
+      if (++w == Wr) {
+        w = 0;
+        ++row;
+      }
     }
   }
   if (lane < kBitsWordsPerWave && first + lane < nwords) {
