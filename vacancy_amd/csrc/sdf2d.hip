@@ -160,23 +160,36 @@ __device__ __forceinline__ int wave_excl_scan_min_from_right(int v, int identity
 }
 
 constexpr int kFar = 1 << 28;
+constexpr int kMaxSdfJobs = 32;
 // a distance measured against the 'no seed' sentinel -> kInf
 __device__ __forceinline__ int far_to_inf(int d) { return d >= (1 << 24) ? kInf : d; }
 
-// g_in[y][x]  = distance along the row to the nearest pixel != 255 (kInf if none)
-// g_out[y][x] = distance along the row to the nearest pixel == 255
-__global__ __launch_bounds__(256) void sdf_rows_kernel(const uint8_t* __restrict__ mask, int W, int rx0,
-                                                       int rx1, int ry0, int ry1, int* __restrict__ g_in,
-                                                       int* __restrict__ g_out) {
-  const int row = ry0 + blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row > ry1) return;
+// One job per silhouette; up to kMaxSdfJobs jobs run side by side (blockIdx.y = job) because each
+// of these small kernels is latency-bound on its own.
+struct SdfJob {
+  const uint8_t* mask;
+  float* out;
+  int* g_in;     // distance along the row to the nearest pixel != 255 (kInf if none), then full L1
+  int* g_out;    // same for the nearest pixel == 255
+  unsigned* absmax;
+  int W, H, rx0, rx1, ry0, ry1;
+};
+struct SdfJobs {
+  SdfJob j[kMaxSdfJobs];
+};
+
+__global__ __launch_bounds__(256) void sdf_rows_kernel(SdfJobs jobs) {
+  const SdfJob& jb = jobs.j[blockIdx.y];
+  const int row = jb.ry0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row > jb.ry1) return;
   const int lane = threadIdx.x & 63;
+  const int rx0 = jb.rx0, rx1 = jb.rx1;
   const int rw = rx1 - rx0 + 1;
   const int seg = (rw + 63) / 64;
   const int xs = min(rx0 + lane * seg, rx1 + 1), xe = min(xs + seg, rx1 + 1);
-  const uint8_t* m = mask + (int64_t)row * W;
-  int* gi = g_in + (int64_t)row * W;
-  int* go = g_out + (int64_t)row * W;
+  const uint8_t* m = jb.mask + (int64_t)row * jb.W;
+  int* gi = jb.g_in + (int64_t)row * jb.W;
+  int* go = jb.g_out + (int64_t)row * jb.W;
   // nearest seed to the left
   int last_n = -kFar, last_s = -kFar;  // last non-255 / last 255 inside my segment
   for (int x = xs; x < xe; ++x) {
@@ -201,10 +214,13 @@ __global__ __launch_bounds__(256) void sdf_rows_kernel(const uint8_t* __restrict
   }
 }
 
-__global__ __launch_bounds__(64) void sdf_cols_kernel(int W, int rx0, int rx1, int ry0, int ry1,
-                                                      int* __restrict__ g_in, int* __restrict__ g_out) {
-  const int x = rx0 + blockIdx.x * 64 + threadIdx.x;
-  if (x > rx1) return;
+__global__ __launch_bounds__(64) void sdf_cols_kernel(SdfJobs jobs) {
+  const SdfJob& jb = jobs.j[blockIdx.y];
+  const int x = jb.rx0 + blockIdx.x * 64 + threadIdx.x;
+  if (x > jb.rx1) return;
+  const int W = jb.W, ry0 = jb.ry0, ry1 = jb.ry1;
+  int* __restrict__ g_in = jb.g_in;
+  int* __restrict__ g_out = jb.g_out;
   int ri = kInf, ro = kInf;
   for (int y = ry0; y <= ry1; ++y) {
     const int64_t i = (int64_t)y * W + x;
@@ -233,18 +249,17 @@ __device__ __forceinline__ float signed_dist(uint8_t m, int din, int dout) {
 }
 
 // pass 1: raw signed distance into `out` (0 outside the ROI) + max |v| over the ROI
-__global__ __launch_bounds__(256) void sdf_sign_kernel(const uint8_t* __restrict__ mask, int W, int H, int rx0,
-                                                       int rx1, int ry0, int ry1, const int* __restrict__ g_in,
-                                                       const int* __restrict__ g_out, float* __restrict__ out,
-                                                       unsigned* __restrict__ absmax_bits) {
+__global__ __launch_bounds__(256) void sdf_sign_kernel(SdfJobs jobs) {
   __shared__ unsigned sm[256];
+  const SdfJob& jb = jobs.j[blockIdx.y];
   unsigned local = 0;
-  const int64_t n = (int64_t)W * H;
+  const int W = jb.W;
+  const int64_t n = (int64_t)W * jb.H;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
     float v = 0.0f;
-    if (x >= rx0 && x <= rx1 && y >= ry0 && y <= ry1) v = signed_dist(mask[i], g_in[i], g_out[i]);
-    out[i] = v;
+    if (x >= jb.rx0 && x <= jb.rx1 && y >= jb.ry0 && y <= jb.ry1) v = signed_dist(jb.mask[i], jb.g_in[i], jb.g_out[i]);
+    jb.out[i] = v;
     local = max(local, __float_as_uint(fabsf(v)));  // non-negative floats order like their bits
   }
   sm[threadIdx.x] = local;
@@ -253,49 +268,87 @@ __global__ __launch_bounds__(256) void sdf_sign_kernel(const uint8_t* __restrict
     if (threadIdx.x < s) sm[threadIdx.x] = max(sm[threadIdx.x], sm[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicMax(absmax_bits, sm[0]);
+  if (threadIdx.x == 0) atomicMax(jb.absmax, sm[0]);
 }
 
 // pass 2: min-max normalisation (:205-222) and truncation (:225-236) inside the ROI
-__global__ __launch_bounds__(256) void sdf_finish_kernel(int W, int H, int rx0, int rx1, int ry0, int ry1,
-                                                         const unsigned* __restrict__ absmax_bits, int normalize,
-                                                         int truncate, float band, float* __restrict__ out) {
-  const float abs_max = __uint_as_float(*absmax_bits);
+__global__ __launch_bounds__(256) void sdf_finish_kernel(SdfJobs jobs, int normalize, int truncate, float band) {
+  const SdfJob& jb = jobs.j[blockIdx.y];
+  const float abs_max = __uint_as_float(*jb.absmax);
   const bool do_norm = normalize && abs_max > 1.17549435e-38f;
   const float norm = do_norm ? 1.0f / abs_max : 1.0f;
-  const int64_t n = (int64_t)W * H;
+  const int W = jb.W;
+  const int64_t n = (int64_t)W * jb.H;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
-    if (x < rx0 || x > rx1 || y < ry0 || y > ry1) continue;
-    float d = out[i];
+    if (x < jb.rx0 || x > jb.rx1 || y < jb.ry0 || y > jb.ry1) continue;
+    float d = jb.out[i];
     if (do_norm) d *= norm;
     if (truncate) d = (-band >= d) ? kInvalidSdf : fminf(1.0f, d / band);
-    out[i] = d;
+    jb.out[i] = d;
   }
 }
 
 }  // namespace
 
-// mask_dev: uint8 [h][w] on the device.  sdf_dev: float [h][w] output.  scratch: 2*w*h ints + 1 word.
+// n (<= kMaxSdfJobs) silhouettes at once.  masks_dev[i]: uint8 [h][w] on the device, sdf_dev[i]: float
+// [h][w] output, scratch: device_make_sdf_scratch_bytes(w, h) bytes PER job, laid out back to back
+// with `scratch_stride` bytes between jobs.
+int device_make_sdf_batch(hipStream_t stream, int n, const uint8_t* const* masks_dev, const vcy_view* views,
+                          bool normalize, bool truncate, float band, char* scratch, size_t scratch_stride,
+                          float* const* sdf_dev) {
+  if (n <= 0 || n > kMaxSdfJobs) {
+    set_error("device_make_sdf_batch: %d jobs", n);
+    return VCY_ERR_INVALID_ARG;
+  }
+  SdfJobs jobs;
+  std::memset(&jobs, 0, sizeof(jobs));
+  int max_rh = 1, max_rw = 1;
+  int64_t max_px = 1;
+  for (int i = 0; i < n; ++i) {
+    const vcy_view& v = views[i];
+    SdfJob& jb = jobs.j[i];
+    const size_t npx = (size_t)v.width * v.height;
+    char* base = scratch + (size_t)i * scratch_stride;
+    jb.mask = masks_dev[i];
+    jb.out = sdf_dev[i];
+    jb.g_in = (int*)base;
+    jb.g_out = jb.g_in + npx;
+    jb.absmax = (unsigned*)(jb.g_out + npx);
+    jb.W = v.width;
+    jb.H = v.height;
+    jb.rx0 = v.roi_min[0];
+    jb.rx1 = v.roi_max[0];
+    jb.ry0 = v.roi_min[1];
+    jb.ry1 = v.roi_max[1];
+    max_rh = std::max(max_rh, jb.ry1 - jb.ry0 + 1);
+    max_rw = std::max(max_rw, jb.rx1 - jb.rx0 + 1);
+    max_px = std::max<int64_t>(max_px, (int64_t)npx);
+    VCY_HIP_CHECK(hipMemsetAsync(jb.absmax, 0, sizeof(unsigned), stream));
+  }
+  hipLaunchKernelGGL(sdf_rows_kernel, dim3((max_rh + 3) / 4, n), dim3(256), 0, stream, jobs);
+  hipLaunchKernelGGL(sdf_cols_kernel, dim3((max_rw + 63) / 64, n), dim3(64), 0, stream, jobs);
+  const int grid = (int)std::min<int64_t>((max_px + 255) / 256, 1024);
+  hipLaunchKernelGGL(sdf_sign_kernel, dim3(grid, n), dim3(256), 0, stream, jobs);
+  hipLaunchKernelGGL(sdf_finish_kernel, dim3(grid, n), dim3(256), 0, stream, jobs, normalize ? 1 : 0,
+                     truncate ? 1 : 0, band);
+  VCY_HIP_CHECK(hipGetLastError());
+  return VCY_OK;
+}
+
+// single silhouette (see device_make_sdf_batch)
 int device_make_sdf(hipStream_t stream, const uint8_t* mask_dev, int w, int h, const int32_t* rmin,
                     const int32_t* rmax, bool normalize, bool truncate, float band, void* scratch,
                     float* sdf_dev) {
-  int* g_in = (int*)scratch;
-  int* g_out = g_in + (size_t)w * h;
-  unsigned* absmax = (unsigned*)(g_out + (size_t)w * h);
-  const int rh = rmax[1] - rmin[1] + 1, rw = rmax[0] - rmin[0] + 1;
-  VCY_HIP_CHECK(hipMemsetAsync(absmax, 0, sizeof(unsigned), stream));
-  hipLaunchKernelGGL(sdf_rows_kernel, dim3((rh + 3) / 4), dim3(256), 0, stream, mask_dev, w, rmin[0], rmax[0],
-                     rmin[1], rmax[1], g_in, g_out);
-  hipLaunchKernelGGL(sdf_cols_kernel, dim3((rw + 63) / 64), dim3(64), 0, stream, w, rmin[0], rmax[0], rmin[1],
-                     rmax[1], g_in, g_out);
-  const int grid = (int)std::min<int64_t>(((int64_t)w * h + 255) / 256, 2048);
-  hipLaunchKernelGGL(sdf_sign_kernel, dim3(grid), dim3(256), 0, stream, mask_dev, w, h, rmin[0], rmax[0], rmin[1],
-                     rmax[1], g_in, g_out, sdf_dev, absmax);
-  hipLaunchKernelGGL(sdf_finish_kernel, dim3(grid), dim3(256), 0, stream, w, h, rmin[0], rmax[0], rmin[1],
-                     rmax[1], absmax, normalize ? 1 : 0, truncate ? 1 : 0, band, sdf_dev);
-  VCY_HIP_CHECK(hipGetLastError());
-  return VCY_OK;
+  vcy_view v;
+  std::memset(&v, 0, sizeof(v));
+  v.width = w;
+  v.height = h;
+  v.roi_min[0] = rmin[0];
+  v.roi_min[1] = rmin[1];
+  v.roi_max[0] = rmax[0];
+  v.roi_max[1] = rmax[1];
+  return device_make_sdf_batch(stream, 1, &mask_dev, &v, normalize, truncate, band, (char*)scratch, 0, &sdf_dev);
 }
 
 size_t device_make_sdf_scratch_bytes(int w, int h) { return sizeof(int) * 2 * (size_t)w * h + 256; }

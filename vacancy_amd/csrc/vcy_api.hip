@@ -227,6 +227,7 @@ void vcy_destroy(vcy_ctx* c) {
   (void)hipFree(c->d_pz);
   (void)hipFree(c->d_mc_tables);
   (void)hipFree(c->d_mc_scratch);
+  (void)hipFree(c->d_stream_pool);
   (void)hipFree(c->d_mc_out);
   (void)hipFree(c->d_mc_cells);
   (void)hipFree(c->d_fused_scratch);
@@ -662,10 +663,11 @@ int vcy_carve_batch_silhouettes(vcy_ctx* c, int n_views, const vcy_view* views,
   const int chunk = fused_max_views();
   const int per_set = std::min(chunk, n_views);
   const size_t px_al = (max_px + 255) / 256 * 256;
-  // [2 sets][per_set] SDF images + [2 sets][per_set] masks + one transform scratch
+  // [2 sets][per_set] SDF images + [2 sets][per_set] masks + [per_set] transform scratch; cached in
+  // the context and grown on demand
   const size_t sz_sdf = px_al * sizeof(float), sz_mask = px_al;
-  const size_t total = 2 * per_set * (sz_sdf + sz_mask) + device_make_sdf_scratch_bytes(1, (int)max_px) + 256;
-  char* pool = nullptr;
+  const size_t sz_scr = (device_make_sdf_scratch_bytes(1, (int)max_px) + 255) / 256 * 256;
+  const size_t total = 2 * per_set * (sz_sdf + sz_mask) + per_set * sz_scr + 256;
   hipStream_t aux = nullptr;
   hipEvent_t ready[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
   int rc = VCY_OK;
@@ -676,7 +678,15 @@ int vcy_carve_batch_silhouettes(vcy_ctx* c, int n_views, const vcy_view* views,
     }
     return e != hipSuccess;
   };
-  if (fail_hip(hipMalloc(&pool, total), "hipMalloc")) return rc;
+  if (c->stream_pool_bytes < total) {
+    VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->d_stream_pool) VCY_HIP_CHECK(hipFree(c->d_stream_pool));
+    c->d_stream_pool = nullptr;
+    c->stream_pool_bytes = 0;
+    VCY_HIP_CHECK(hipMalloc(&c->d_stream_pool, total));
+    c->stream_pool_bytes = total;
+  }
+  char* pool = (char*)c->d_stream_pool;
   fail_hip(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking), "hipStreamCreate");
   for (int k = 0; k < 2 && rc == VCY_OK; ++k) {
     fail_hip(hipEventCreateWithFlags(&ready[k], hipEventDisableTiming), "hipEventCreate");
@@ -692,17 +702,21 @@ int vcy_carve_batch_silhouettes(vcy_ctx* c, int n_views, const vcy_view* views,
   auto produce = [&](int ci) {
     const int set = ci & 1, first = ci * chunk, m = std::min(chunk, n_views - first);
     if (ci >= 2) fail_hip(hipStreamWaitEvent(aux, consumed[set], 0), "hipStreamWaitEvent");
+    std::vector<const uint8_t*> mptr(m);
+    std::vector<float*> optr(m);
     for (int j = 0; j < m && rc == VCY_OK; ++j) {
       const vcy_view& v = views[first + j];
       const size_t npx = (size_t)v.width * v.height;
-      if (fail_hip(hipMemcpyAsync(mask_buf(set, j), masks_host[first + j], npx, hipMemcpyHostToDevice, aux),
-                   "mask upload"))
-        break;
-      // MakeSignedDistanceField(...), reference voxel_carver.cc:405-408
-      int r2 = device_make_sdf(aux, mask_buf(set, j), v.width, v.height, v.roi_min, v.roi_max,
-                               c->opt.sdf_minmax_normalize != 0, u.use_truncation != 0, u.truncation_band, scratch,
-                               sdf_buf(set, j));
-      if (r2 != VCY_OK && rc == VCY_OK) rc = r2;
+      mptr[j] = mask_buf(set, j);
+      optr[j] = sdf_buf(set, j);
+      fail_hip(hipMemcpyAsync(mask_buf(set, j), masks_host[first + j], npx, hipMemcpyHostToDevice, aux),
+               "mask upload");
+    }
+    if (rc == VCY_OK) {
+      // MakeSignedDistanceField(...) for the whole chunk at once, reference voxel_carver.cc:405-408
+      int r2 = device_make_sdf_batch(aux, m, mptr.data(), views + first, c->opt.sdf_minmax_normalize != 0,
+                                     u.use_truncation != 0, u.truncation_band, scratch, sz_scr, optr.data());
+      if (r2 != VCY_OK) rc = r2;
     }
     fail_hip(hipEventRecord(ready[set], aux), "hipEventRecord");
   };
@@ -725,7 +739,6 @@ int vcy_carve_batch_silhouettes(vcy_ctx* c, int n_views, const vcy_view* views,
     if (consumed[k]) (void)hipEventDestroy(consumed[k]);
   }
   if (aux) (void)hipStreamDestroy(aux);
-  (void)hipFree(pool);
   return rc;
 }
 

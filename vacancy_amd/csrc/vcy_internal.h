@@ -74,6 +74,8 @@ struct vcy_ctx {
   bool fused_cache_valid = false;     // host mirror of what d_fused_scratch holds
   std::vector<char> fused_cache_views;
   std::vector<float> fused_cache_c2;
+  void* d_stream_pool = nullptr;      // staging of vcy_carve_batch_silhouettes (masks, SDFs, scratch)
+  size_t stream_pool_bytes = 0;
   void* d_mc_tables = nullptr;        // marching-cubes case tables (mc_kernels.hip)
   void* d_mc_scratch = nullptr;       // bit planes, active words, offsets, per-cell info
   size_t mc_scratch_bytes = 0;
@@ -113,6 +115,9 @@ int device_make_sdf(hipStream_t stream, const uint8_t* mask_dev, int w, int h, c
                     const int32_t* rmax, bool normalize, bool truncate, float band, void* scratch,
                     float* sdf_dev);
 size_t device_make_sdf_scratch_bytes(int w, int h);
+int device_make_sdf_batch(hipStream_t stream, int n, const uint8_t* const* masks_dev, const vcy_view* views,
+                          bool normalize, bool truncate, float band, char* scratch, size_t scratch_stride,
+                          float* const* sdf_dev);
 // utility kernels (vcy_api.hip)
 int fill_state(vcy_ctx* ctx);   // marks the slab fresh (lazy)
 int materialize(vcy_ctx* ctx);  // writes the fresh state to HBM if it is still pending
