@@ -288,10 +288,20 @@ def test_cpp_bunny_example(tmp_path):
     assert int(rows[5][16]) == 683400  # ExtractVoxel, SURVEY Appendix C
     vsum = [float(x) for x in rows[5][12:15]]
     assert np.allclose(vsum, gold["final_vertex_sums"], rtol=0, atol=1e-4)
-    # ASCII PLY in the reference's format
-    ply = open(os.path.join(str(tmp_path), "surface_00005.ply")).read().splitlines()
-    assert ply[0] == "ply" and ply[2] == "element vertex 8672" and "element face 17270" in ply
-    assert ply[ply.index("end_header") + 1].endswith(" ") and ply[-1].startswith("3 ")
+    # ASCII PLY byte for byte what the reference's Mesh::WritePly (mesh.cc:583-631) writes for the
+    # oracle's mesh: ostream default float formatting == "%g", "x y z \n", "3 a b c \n"
+    views = B.bunny_views(lambda t, q: O.affine_inverse(O.pose_from_tum(t, q)))
+    orc = O.OracleGrid(B.bunny_option(10.0))
+    for i, m in enumerate(B.load_masks()):
+        orc.carve(views[i], O.make_sdf(m))
+    om = orc.marching_cubes(0.0, True)
+    lines = ["ply", "format ascii 1.0", "element vertex %d" % len(om["vertices"]), "property float x",
+             "property float y", "property float z", "element face %d" % len(om["faces"]),
+             "property list uchar int vertex_indices", "end_header"]
+    lines += ["%g %g %g " % (float(v[0]), float(v[1]), float(v[2])) for v in om["vertices"]]
+    lines += ["3 %d %d %d " % (f[0], f[1], f[2]) for f in om["faces"]]
+    expected = "\n".join(lines) + "\n"
+    assert open(os.path.join(str(tmp_path), "surface_00005.ply")).read() == expected
 
 
 @pytest.mark.parametrize("world", [2, 3])
