@@ -1,6 +1,8 @@
 // The reference's demo (examples.cc:75-152) on the MI355X path: 6 masks + TUM poses of data/
 // bunny, 10 mm voxels; per view carve -> marching cubes (interpolated and not), PLY out.
-// Usage: bunny <data_dir> <out_dir> [resolution]
+// Usage: bunny <data_dir> <out_dir> [resolution] [n_slabs]
+//   n_slabs > 0 additionally runs the same views through ShardedVoxelCarver (that many z-slabs on
+//   device 0) and checks that its stitched mesh is identical to the single-context one.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -10,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "vacancy/sharded_voxel_carver.h"
 #include "vacancy/voxel_carver.h"
 
 // TUM trajectory line: id tx ty tz qx qy qz qw -> pose = Translation * Quaternion (examples.cc:36-50)
@@ -42,6 +45,7 @@ int main(int argc, char* argv[]) {
   const std::string data_dir = argc > 1 ? argv[1] : "../data/";
   const std::string out_dir = argc > 2 ? argv[2] : data_dir;
   const float resolution = argc > 3 ? (float)std::atof(argv[3]) : 10.0f;
+  const int n_slabs = argc > 4 ? std::atoi(argv[4]) : 0;
   std::vector<Eigen::Affine3d> poses;
   if (!LoadTumPoses(data_dir + "/tumpose.txt", &poses)) return 1;
 
@@ -56,6 +60,12 @@ int main(int argc, char* argv[]) {
   option.resolution = resolution;
   vacancy::VoxelCarver carver(option);
   if (!carver.Init()) return 2;
+
+  std::unique_ptr<vacancy::ShardedVoxelCarver> sharded;
+  if (n_slabs > 0) {
+    sharded.reset(new vacancy::ShardedVoxelCarver(option, {0}, n_slabs));
+    if (!sharded->Init()) return 5;
+  }
 
   const int width = 320, height = 240;
   std::shared_ptr<vacancy::Camera> camera = std::make_shared<vacancy::PinholeCamera>(
@@ -72,6 +82,8 @@ int main(int argc, char* argv[]) {
     vacancy::SignedDistance2Color(sdf, &vis, -1.0f, 1.0f);
     vis.WritePng(out_dir + "/sdf_" + num + ".png");
 
+    if (sharded && !sharded->Carve(*camera, silhouette)) return 6;
+
     vacancy::Mesh mesh;
     carver.ExtractVoxel(&mesh);  // cube per voxel: large and slow to write, like the reference says
     mesh.WritePlyBinary(out_dir + "/voxel_" + num + ".ply");
@@ -82,6 +94,17 @@ int main(int argc, char* argv[]) {
     double sum[3] = {0, 0, 0};
     for (const auto& v : mesh.vertices())
       for (int k = 0; k < 3; ++k) sum[k] += v[k];
+    if (sharded) {
+      vacancy::Mesh sm;
+      sharded->ExtractIsoSurface(&sm, 0.0);
+      bool same = sm.vertices().size() == mesh.vertices().size() &&
+                  sm.vertex_indices().size() == mesh.vertex_indices().size();
+      for (size_t k = 0; same && k < sm.vertices().size(); ++k)
+        for (int a = 0; a < 3; ++a) same = sm.vertices()[k][a] == mesh.vertices()[k][a];
+      for (size_t k = 0; same && k < sm.vertex_indices().size(); ++k)
+        for (int a = 0; a < 3; ++a) same = sm.vertex_indices()[k][a] == mesh.vertex_indices()[k][a];
+      std::printf("SHARDED view %zu slabs %d identical %d\n", i, sharded->slab_count(), same ? 1 : 0);
+    }
     carver.ExtractIsoSurface(&mesh, 0.0, false);
     mesh.WritePly(out_dir + "/surface_nointerp_" + num + ".ply");
     std::printf("RESULT view %zu verts %zu faces %zu nointerp_verts %zu nointerp_faces %zu vsum %.6f %.6f %.6f "

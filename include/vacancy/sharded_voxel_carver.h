@@ -1,0 +1,36 @@
+// ShardedVoxelCarver: the VoxelCarver API over several GPUs of one node from ONE process.
+//
+// The grid is cut into z-slabs (k per device, dealt cyclically so that slabs near the object and
+// empty ones mix on every device); carving needs no exchange, extraction needs the two slices below
+// each slab, copied peer-to-peer (vcy_halo_copy_from), and the per-slab meshes are stitched by edge
+// key into exactly the mesh a single VoxelCarver returns.  (The one-process-per-GPU form of the same
+// scheme, with a single RCCL all-gather for the halos, is vacancy_amd/dist.py + bench.py.)
+#pragma once
+
+#include <memory>
+#include <vector>
+
+#include "vacancy/voxel_carver.h"
+
+namespace vacancy {
+
+class ShardedVoxelCarver {
+ public:
+  ShardedVoxelCarver(VoxelCarverOption option, std::vector<int> device_ids, int slabs_per_device = 2);
+  ~ShardedVoxelCarver();
+  ShardedVoxelCarver(const ShardedVoxelCarver&) = delete;
+  ShardedVoxelCarver& operator=(const ShardedVoxelCarver&) = delete;
+
+  bool Init();
+  int slab_count() const;
+  // one view / a batch of views into every slab (slabs of different devices run concurrently)
+  bool Carve(const Camera& camera, const Image1b& silhouette);
+  bool Carve(const std::vector<const Camera*>& cameras, const std::vector<Image1b>& silhouettes);
+  void ExtractIsoSurface(Mesh* mesh, double iso_level = 0.0, bool linear_interp = true);
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> impl_;
+};
+
+}  // namespace vacancy

@@ -205,6 +205,9 @@ int vcy_halo_unpack(vcy_ctx* ctx, const void* gathered_device, int rank, int wor
 /* Same, given directly the pack (vcy_halo_bytes bytes, device) of the slab that ends at this
  * context's z_begin -- for layouts where slabs are not ordered by rank (several slabs per GPU). */
 int vcy_halo_install(vcy_ctx* ctx, const void* prev_slab_pack_device);
+/* Single-process multi-GPU: copies the last two slices of `below` (the slab that ends at ctx's
+ * z_begin, on any device of this process) straight into ctx's halo (peer-to-peer over xGMI). */
+int vcy_halo_copy_from(vcy_ctx* ctx, vcy_ctx* below);
 
 /* ---- device memory / stream / timing helpers ----------------------------- */
 

@@ -276,8 +276,11 @@ def test_cpp_bunny_example(tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.run(["make", "-C", os.path.join(root, "vacancy_amd", "host"), "-s"], check=True)
-    out = subprocess.run([os.path.join(root, "vacancy_amd", "host", "bunny"), B.BUNNY, str(tmp_path)],
+    out = subprocess.run([os.path.join(root, "vacancy_amd", "host", "bunny"), B.BUNNY, str(tmp_path), "10", "3"],
                          check=True, capture_output=True, text=True).stdout
+    # ShardedVoxelCarver (3 z-slabs, peer-copied halos, C++ merge) == single context, every view
+    sh = [l.split() for l in out.splitlines() if l.startswith("SHARDED")]
+    assert len(sh) == 6 and all(r[4] == "3" and r[6] == "1" for r in sh), sh
     gold = json.load(open(os.path.join(root, "tests", "golden", "appendix_c.json")))
     rows = [l.split() for l in out.splitlines() if l.startswith("RESULT")]
     assert len(rows) == 6

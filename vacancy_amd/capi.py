@@ -134,6 +134,7 @@ def load():
         "vcy_halo_pack": (C.c_int, [vp, vp]),
         "vcy_halo_unpack": (C.c_int, [vp, vp, C.c_int, C.c_int]),
         "vcy_halo_install": (C.c_int, [vp, vp]),
+        "vcy_halo_copy_from": (C.c_int, [vp, vp]),
         "vcy_device_count": (C.c_int, [P(C.c_int)]),
         "vcy_sdf_upload": (C.c_int, [vp, vp, C.c_int, C.c_int, P(vp)]),
         "vcy_device_free": (C.c_int, [vp, vp]),

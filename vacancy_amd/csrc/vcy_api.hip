@@ -483,6 +483,30 @@ int vcy_halo_install(vcy_ctx* c, const void* prev_pack) {
   return VCY_OK;
 }
 
+int vcy_halo_copy_from(vcy_ctx* c, vcy_ctx* below) {
+  if (!c) return VCY_ERR_INVALID_ARG;
+  if (c->halo_lo == 0) {
+    c->halo_valid = true;
+    return VCY_OK;
+  }
+  if (!below || below->z1 != c->z0 || below->nx != c->nx || below->ny != c->ny ||
+      below->cnt_bytes != c->cnt_bytes || below->nz_local() < 2) {
+    set_error("vcy_halo_copy_from: `below` is not the slab that ends at z_begin (with >= 2 slices)");
+    return VCY_ERR_INVALID_ARG;
+  }
+  VCY_HIP_CHECK(hipSetDevice(below->device));
+  { int rcm = materialize(below); if (rcm != VCY_OK) return rcm; }
+  VCY_HIP_CHECK(hipStreamSynchronize(below->stream));  // its carve must have finished
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  const int64_t s = c->slice;
+  const float* sdf_src = below->owned_slab_sdf() + (int64_t)(below->nz_local() - 2) * s;
+  const char* cnt_src = (const char*)below->owned_slab_cnt() + (int64_t)(below->nz_local() - 2) * s * c->cnt_bytes;
+  VCY_HIP_CHECK(hipMemcpyPeerAsync(c->d_sdf, c->device, sdf_src, below->device, 2 * s * sizeof(float), c->stream));
+  VCY_HIP_CHECK(hipMemcpyPeerAsync(c->d_cnt, c->device, cnt_src, below->device, 2 * s * c->cnt_bytes, c->stream));
+  c->halo_valid = true;
+  return VCY_OK;
+}
+
 int vcy_halo_unpack(vcy_ctx* c, const void* gathered, int rank, int world) {
   if (!c || !gathered || rank < 0 || rank >= world) return VCY_ERR_INVALID_ARG;
   VCY_HIP_CHECK(hipSetDevice(c->device));

@@ -1,0 +1,187 @@
+// ShardedVoxelCarver: z-slab sharding over the C-ABI contexts of include/vacancy_hip.h.
+#include "vacancy/sharded_voxel_carver.h"
+
+#include <cstring>
+#include <future>
+#include <limits>
+#include <unordered_map>
+
+#include "vacancy_hip.h"
+
+namespace vacancy {
+
+namespace {
+
+vcy_view MakeView(const Camera& camera, int width, int height) {
+  vcy_view v;
+  std::memset(&v, 0, sizeof(v));
+  const Eigen::Affine3f w2c = camera.w2c().cast<float>();
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) v.w2c[4 * i + j] = w2c.linear()(i, j);
+    v.w2c[4 * i + 3] = w2c.translation()[i];
+  }
+  if (const PinholeCamera* p = dynamic_cast<const PinholeCamera*>(&camera)) {
+    v.fx = p->focal_length()[0];
+    v.fy = p->focal_length()[1];
+    v.cx = p->principal_point()[0];
+    v.cy = p->principal_point()[1];
+  }
+  v.is_ortho = camera.is_orthographic() ? 1 : 0;
+  v.roi_max[0] = width - 1;
+  v.roi_max[1] = height - 1;
+  v.width = width;
+  v.height = height;
+  return v;
+}
+
+struct KeyHash {
+  size_t operator()(const std::pair<int64_t, int64_t>& k) const {
+    return std::hash<int64_t>()(k.first * 1000003 + (k.second - k.first));
+  }
+};
+
+}  // namespace
+
+struct ShardedVoxelCarver::Impl {
+  VoxelCarverOption option;
+  std::vector<int> devices;
+  int per_device = 2;
+  std::vector<vcy_ctx*> slabs;  // in z order
+  ~Impl() {
+    for (vcy_ctx* c : slabs) vcy_destroy(c);
+  }
+};
+
+ShardedVoxelCarver::ShardedVoxelCarver(VoxelCarverOption option, std::vector<int> device_ids, int slabs_per_device)
+    : impl_(new Impl) {
+  impl_->option = option;
+  impl_->devices = device_ids.empty() ? std::vector<int>{0} : device_ids;
+  impl_->per_device = slabs_per_device < 1 ? 1 : slabs_per_device;
+}
+ShardedVoxelCarver::~ShardedVoxelCarver() {}
+
+int ShardedVoxelCarver::slab_count() const { return static_cast<int>(impl_->slabs.size()); }
+
+bool ShardedVoxelCarver::Init() {
+  for (vcy_ctx* c : impl_->slabs) vcy_destroy(c);
+  impl_->slabs.clear();
+  const VoxelCarverOption& o = impl_->option;
+  vcy_carver_option c;
+  std::memset(&c, 0, sizeof(c));
+  for (int i = 0; i < 3; ++i) {
+    c.bb_max[i] = o.bb_max[i];
+    c.bb_min[i] = o.bb_min[i];
+  }
+  c.resolution = o.resolution;
+  c.sdf_minmax_normalize = o.sdf_minmax_normalize ? 1 : 0;
+  c.update_option.voxel_update = static_cast<int>(o.update_option.voxel_update);
+  c.update_option.sdf_interp = static_cast<int>(o.update_option.sdf_interp);
+  c.update_option.update_outside = static_cast<int>(o.update_option.update_outside);
+  c.update_option.voxel_max_update_num = o.update_option.voxel_max_update_num;
+  c.update_option.voxel_update_weight = o.update_option.voxel_update_weight;
+  c.update_option.use_truncation = o.update_option.use_truncation ? 1 : 0;
+  c.update_option.truncation_band = o.update_option.truncation_band;
+  int32_t dims[3];
+  if (vcy_compute_dims(c.bb_min, c.bb_max, c.resolution, dims) != VCY_OK) {
+    LOGE("%s\n", vcy_last_error());
+    return false;
+  }
+  const int ndev = static_cast<int>(impl_->devices.size());
+  int count = ndev * impl_->per_device;
+  while (count > 1 && dims[2] / count < 2) --count;  // every slab needs >= 2 slices
+  const int base = dims[2] / count, rem = dims[2] % count;
+  for (int s = 0; s < count; ++s) {
+    const int z0 = s * base + (s < rem ? s : rem), z1 = z0 + base + (s < rem ? 1 : 0);
+    vcy_ctx* ctx = nullptr;
+    if (vcy_create(&c, impl_->devices[s % ndev], z0, z1, &ctx) != VCY_OK) {  // cyclic deal
+      LOGE("%s\n", vcy_last_error());
+      return false;
+    }
+    impl_->slabs.push_back(ctx);
+  }
+  return true;
+}
+
+bool ShardedVoxelCarver::Carve(const Camera& camera, const Image1b& silhouette) {
+  return Carve(std::vector<const Camera*>{&camera}, std::vector<Image1b>{silhouette});
+}
+
+bool ShardedVoxelCarver::Carve(const std::vector<const Camera*>& cameras, const std::vector<Image1b>& silhouettes) {
+  if (impl_->slabs.empty() || cameras.size() != silhouettes.size() || cameras.empty()) return false;
+  const int n = static_cast<int>(cameras.size());
+  std::vector<vcy_view> views(n);
+  std::vector<const uint8_t*> masks(n);
+  for (int i = 0; i < n; ++i) {
+    views[i] = MakeView(*cameras[i], silhouettes[i].width(), silhouettes[i].height());
+    masks[i] = silhouettes[i].data().data();
+  }
+  // one host thread per slab: a context is single-threaded, different contexts are independent
+  std::vector<std::future<int>> jobs;
+  for (vcy_ctx* ctx : impl_->slabs)
+    jobs.push_back(std::async(std::launch::async, [ctx, n, &views, &masks]() {
+      return vcy_carve_batch_silhouettes(ctx, n, views.data(), masks.data());
+    }));
+  bool ok = true;
+  for (auto& j : jobs) ok = (j.get() == VCY_OK) && ok;
+  if (!ok) LOGE("sharded carve failed\n");
+  return ok;
+}
+
+void ShardedVoxelCarver::ExtractIsoSurface(Mesh* mesh, double iso_level, bool linear_interp) {
+  mesh->Clear();
+  const size_t ns = impl_->slabs.size();
+  if (ns == 0) return;
+  for (size_t s = 1; s < ns; ++s)
+    if (vcy_halo_copy_from(impl_->slabs[s], impl_->slabs[s - 1]) != VCY_OK) {
+      LOGE("%s\n", vcy_last_error());
+      return;
+    }
+  std::vector<vcy_mesh> parts(ns);
+  std::vector<std::future<int>> jobs;
+  for (size_t s = 0; s < ns; ++s)
+    jobs.push_back(std::async(std::launch::async, [this, s, iso_level, linear_interp, &parts]() {
+      return vcy_extract_iso(impl_->slabs[s], iso_level, linear_interp ? 1 : 0, &parts[s]);
+    }));
+  bool ok = true;
+  for (auto& j : jobs) ok = (j.get() == VCY_OK) && ok;
+  if (ok) {
+    // stitch: a slab's first n_foreign vertices are owned by the slab below -> look them up by edge key
+    std::vector<Eigen::Vector3f>* V = mesh->mutable_vertices();
+    std::vector<Eigen::Vector3i>* F = mesh->mutable_vertex_indices();
+    std::unordered_map<std::pair<int64_t, int64_t>, int, KeyHash> prev;
+    int64_t offset = 0;
+    for (size_t s = 0; s < ns && ok; ++s) {
+      const vcy_mesh& m = parts[s];
+      const int64_t nfo = m.n_foreign_vertices, nown = m.n_vertices - nfo;
+      std::vector<int> remap(static_cast<size_t>(m.n_vertices));
+      for (int64_t i = 0; i < nfo; ++i) {
+        auto it = prev.find({m.edge_keys[2 * i], m.edge_keys[2 * i + 1]});
+        if (it == prev.end()) {
+          LOGE("sharded merge: shared-plane vertex without an owner\n");
+          ok = false;
+          break;
+        }
+        remap[i] = it->second;
+      }
+      for (int64_t i = 0; i < nown; ++i) remap[nfo + i] = static_cast<int>(offset + i);
+      const size_t v0 = V->size(), f0 = F->size();
+      V->resize(v0 + nown);
+      if (nown) std::memcpy(static_cast<void*>(V->data() + v0), m.vertices + 3 * nfo, sizeof(float) * 3 * nown);
+      F->resize(f0 + m.n_faces);
+      for (int64_t i = 0; i < m.n_faces; ++i)
+        (*F)[f0 + i] = Eigen::Vector3i(remap[m.faces[3 * i]], remap[m.faces[3 * i + 1]], remap[m.faces[3 * i + 2]]);
+      prev.clear();
+      if (s + 1 < ns)  // only vertices on this slab's top plane can be referenced from above
+        for (int64_t i = 0; i < nown; ++i)
+          prev[{m.edge_keys[2 * (nfo + i)], m.edge_keys[2 * (nfo + i) + 1]}] = static_cast<int>(offset + i);
+      offset += nown;
+    }
+  }
+  if (!ok) {
+    mesh->Clear();
+    LOGE("%s\n", vcy_last_error());
+  }
+  for (vcy_mesh& m : parts) vcy_mesh_free(&m);
+}
+
+}  // namespace vacancy
