@@ -213,9 +213,11 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
   //   - use_truncation and every sample is provably < -1 (voxel_carver.cc:478), or
   //   - kMax, every voxel already touched, and every sample is provably <= min(sdf) of the
   //     brick (UpdateVoxelMax only writes when dist > sdf, voxel_carver.cc:82).
-  // "Provably": a bilinear sample is a convex combination of taps of the staged footprint, so
-  // it is bounded by the footprint's maximum M times the rounding slack of the four products
-  // and three sums (|error| < 2^-20 |M|).  ub below is that bound.
+  // "Provably": with every tap <= M and weights >= 0, monotonicity of IEEE rounding gives
+  //   dist = fl(fl(fl(w00 s00 + w10 s10) + w01 s01) + w11 s11) <= the same expression with all taps = M,
+  // and the four weights sum to 1 within 2^-23 (each is a product of u-floor(u), 1-(u-floor(u)) ...),
+  // so dist <= M + 2^-22 |M| for either sign of M.  ub = M + 2^-20 |M| is that bound with slack.
+  // Footprints holding a NaN or an infinity give no bound (0 * inf = NaN samples).
   constexpr bool kNeedBound = TRUNC || UPDATE == VCY_UPDATE_MAX;
 
   const int tid = threadIdx.x;
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
               gfloat_ptr row = img + ((unsigned)v.width * (unsigned)(ty0 + j) + (unsigned)tx0);
               for (int i = corner; i < pw; i += 8) {
                 const float t = row[i];
-                has_nan |= (t != t);
+                has_nan |= !(fabsf(t) <= 3.402823466e+38f);  // NaN or +-inf: 0 * inf = NaN samples
                 m = fmaxf(m, t);
               }
             }
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
             }
             // voxels projecting outside the ROI sample max_sdf instead (voxel_carver.cc:469-471)
             if (mode.outside == VCY_OUTSIDE_MAX) {
-              has_nan |= (v.max_sdf != v.max_sdf);
+              has_nan |= !(fabsf(v.max_sdf) <= 3.402823466e+38f);
               m = fmaxf(m, v.max_sdf);
             }
             ti.ub = has_nan ? INFINITY : (__builtin_fmaf(fabsf(m), 0x1p-20f, m) + 1.0e-30f);
