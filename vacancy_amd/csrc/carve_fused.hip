@@ -200,7 +200,9 @@ __device__ __forceinline__ void tile_fill(const ViewParams& v, const TileInfo& t
   }
 }
 
-template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX, int TQ>
+// GEN: nearest-neighbour sampling and/or an orthographic camera, selected at run time from `mode`
+// (compiled out of the default bilinear + pinhole kernels, where the extra branches cost 16 %).
+template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX, int TQ, bool GEN>
 __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
                                                           const FusedView* __restrict__ views,
                                                           const float* __restrict__ c2_all,
@@ -254,15 +256,17 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
 #pragma unroll
       for (int i = 0; i < 3; ++i)
         pc[i] = v.t[i] + (v.r[i][0] * cpx + (v.r[i][1] * cpy + v.r[i][2] * cpz));
-      const float u = v.fx / pc[2] * pc[0] + v.cx;
-      const float w = v.fy / pc[2] * pc[1] + v.cy;
+      const bool ortho = GEN && mode.ortho != 0;
+      const float u = ortho ? pc[0] : v.fx / pc[2] * pc[0] + v.cx;
+      const float w = ortho ? pc[1] : v.fy / pc[2] * pc[1] + v.cy;
       // The whole (convex) brick is in front of the camera iff all 8 corners are.  The footprint
       // rectangle below is only trusted when the computed image coordinates are accurate to a small
       // fraction of a pixel: depth spread of the brick below 4x and no catastrophic cancellation in
       // pc.z (then every voxel of the brick projects within `margin` of the corner hull: the exact
       // projections are inside it by convexity, computed ones differ by a few ulps).
       const float zmag = fabsf(v.t[2]) + fabsf(v.r[2][0] * cpx) + fabsf(v.r[2][1] * cpy) + fabsf(v.r[2][2] * cpz);
-      int bad = !(pc[2] > 0.0f) || !(fabsf(u) < 1.0e6f) || !(fabsf(w) < 1.0e6f) || !(pc[2] >= zmag * 0x1p-12f);
+      int bad = !(fabsf(u) < 1.0e6f) || !(fabsf(w) < 1.0e6f);
+      if (!ortho) bad |= !(pc[2] > 0.0f) || !(pc[2] >= zmag * 0x1p-12f);
       float umin = u, umax = u, wmin = w, wmax = w, zmin = pc[2], zmax = pc[2];
 #pragma unroll
       for (int d = 1; d < 8; d <<= 1) {
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
         zmax = fmaxf(zmax, __shfl_xor(zmax, d, 64));
         bad |= __shfl_xor(bad, d, 64);
       }
-      bad |= !(zmin * 4.0f >= zmax);
+      if (!ortho) bad |= !(zmin * 4.0f >= zmax);
       const float margin = 0.125f + 0x1p-16f * fmaxf(fmaxf(fabsf(umin), fabsf(umax)), fmaxf(fabsf(wmin), fabsf(wmax)));
       TileInfo ti;
       ti.lo_x = ti.lo_y = INFINITY;  // nothing passes the tile test
@@ -407,6 +411,7 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
     const float lo_y = tinfo[vi].lo_y, hi_y = tinfo[vi].hi_y;
     const float pitchf = tinfo[vi].pitchf;
     const int base = tinfo[vi].base;
+    const bool is_ortho = GEN && mode.ortho != 0, is_nn = GEN && mode.interp == VCY_INTERP_NN;
     const float c0x = v.r[0][0] * px, c0y = v.r[1][0] * px, c0z = v.r[2][0] * px;
     const float c1x = v.r[0][1] * py, c1y = v.r[1][1] * py, c1z = v.r[2][1] * py;
 
@@ -423,16 +428,21 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
       const int zla = min(zl0 + kp, g.nz_local - 1), zlb = min(zl0 + kp + 1, g.nz_local - 1);
       const f2 c2z = {c2[2 * g.nz_local + zla], c2[2 * g.nz_local + zlb]};
       const f2 pcz2 = v.t[2] + (c0z + (c1z + c2z));
-      const f2 qx2 = div_fast2(v.fx, pcz2);
-      const f2 qy2 = SAMEF ? qx2 : div_fast2(v.fy, pcz2);
+      // pinhole: u = fx / z * x + cx (camera.cc:133-136); orthographic: u = x (camera.cc:201-205)
+      f2 qx2 = {1.0f, 1.0f}, qy2 = {1.0f, 1.0f};
+      if (!is_ortho) {
+        qx2 = div_fast2(v.fx, pcz2);
+        qy2 = SAMEF ? qx2 : div_fast2(v.fy, pcz2);
+      }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int k = kp + h;
         const int zl = h ? zlb : zla;
         const float pcz = h ? pcz2.y : pcz2.x;
-        const bool zfast = in_fast_div_range(pcz);
+        // orthographic: only `pc.z < 0` is skipped (voxel_carver.cc:456)
+        const bool zfast = is_ortho ? !(pcz < 0.0f) : in_fast_div_range(pcz);
         const f2 pcxy = (f2){v.t[0], v.t[1]} + ((f2){c0x, c0y} + ((f2){c1x, c1y} + (f2){c2[zl], c2[g.nz_local + zl]}));
-        const f2 uw = (f2){h ? qx2.y : qx2.x, h ? qy2.y : qy2.x} * pcxy + (f2){v.cx, v.cy};
+        const f2 uw = is_ortho ? pcxy : (f2){h ? qx2.y : qx2.x, h ? qy2.y : qy2.x} * pcxy + (f2){v.cx, v.cy};
         const float u = uw.x, w = uw.y;
         const bool in_tile = zfast && u >= lo_x && u <= hi_x && w >= lo_y && w <= hi_y;
         slow[k] = !in_tile;
@@ -445,7 +455,13 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
         const float4 q = tile[idx];
         const f2 ab = (P * Q.x) * (f2){q.x, q.y};   // ((1-lu)(1-lv)) s00 , (lu (1-lv)) s10
         const f2 cd = (P * Q.y) * (f2){q.z, q.w};   // ((1-lu) lv) s01   , (lu lv) s11
-        const float dist = ((ab.x + ab.y) + cd.x) + cd.y;
+        float dist = ((ab.x + ab.y) + cd.x) + cd.y;
+        if (is_nn) {
+          // SdfInterpolationNn (voxel_carver.cc:16-38): round half away from zero == floor + (frac >= .5)
+          // for the non-negative in-ROI coordinates; the quad already holds the ROI-clamped neighbours
+          const float top = lu >= 0.5f ? q.y : q.x, bot = lu >= 0.5f ? q.w : q.z;
+          dist = lv >= 0.5f ? bot : top;
+        }
         bool ok = in_tile;
         if (TRUNC) ok = ok && !(dist < -1.0f);
         if (CHECKMAX) ok = ok && !(n[k] > g.max_update_num);
@@ -496,14 +512,20 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF>
 void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const GridParams& g, const FusedView* dv,
                     const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh) {
-#define VCY_FUSED(CM, TQ_)                                                                                  \
-  hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, CM, TQ_>), grid, dim3(256), 0, s, g, dv, \
-                     c2, nv, m, nbx, nby, cull, fresh)
+  const bool gen = m.ortho != 0 || m.interp == VCY_INTERP_NN;
+#define VCY_FUSED(CM, TQ_, GEN_)                                                                            \
+  hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, CM, TQ_, GEN_>), grid, dim3(256), 0, s, \
+                     g, dv, c2, nv, m, nbx, nby, cull, fresh)
+#define VCY_FUSED_G(CM, TQ_)                                                                                \
+  do {                                                                                                      \
+    if (gen) VCY_FUSED(CM, TQ_, true); else VCY_FUSED(CM, TQ_, false);                                    \
+  } while (0)
   if (big) {
-    if (checkmax) VCY_FUSED(true, kTileBig); else VCY_FUSED(false, kTileBig);
+    if (checkmax) VCY_FUSED_G(true, kTileBig); else VCY_FUSED_G(false, kTileBig);
   } else {
-    if (checkmax) VCY_FUSED(true, kTileSmall); else VCY_FUSED(false, kTileSmall);
+    if (checkmax) VCY_FUSED_G(true, kTileSmall); else VCY_FUSED_G(false, kTileSmall);
   }
+#undef VCY_FUSED_G
 #undef VCY_FUSED
 }
 
@@ -535,13 +557,12 @@ bool sane(float f) { return f >= 0x1p-40f && f <= 0x1p40f; }
 // True when the fused kernel can take these views (otherwise the per-view kernel does).
 bool fused_eligible(const vcy_ctx* c, int n_views, const vcy_view* views) {
   const vcy_update_option& u = c->opt.update_option;
-  if (u.sdf_interp != VCY_INTERP_BILINEAR) return false;
   if (c->cnt_bytes > 2) return false;
   if (u.voxel_update == VCY_UPDATE_WEIGHTED_AVERAGE && !sane(u.voxel_update_weight)) return false;
   for (int i = 0; i < n_views; ++i) {
     const vcy_view& v = views[i];
-    if (v.is_ortho) return false;
-    if (!sane(v.fx) || !sane(v.fy)) return false;
+    if (v.is_ortho != views[0].is_ortho) return false;  // one projection model per launch
+    if (!v.is_ortho && (!sane(v.fx) || !sane(v.fy))) return false;
     if (v.width > 8192 || v.height > 8192) return false;
   }
   return true;
@@ -600,7 +621,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     set_error("slab too large for one launch");
     return VCY_ERR_TOO_MANY_VOXELS;
   }
-  ModeParams m{u.voxel_update, u.sdf_interp, u.update_outside, u.use_truncation ? 1 : 0, 0};
+  ModeParams m{u.voxel_update, u.sdf_interp, u.update_outside, u.use_truncation ? 1 : 0, c->fused_ortho ? 1 : 0};
   // update_num can only exceed voxel_max_update_num after more than that many views
   const bool checkmax = c->views_carved + n_views > (int64_t)u.voxel_max_update_num;
   const dim3 grid((unsigned)nblocks);
@@ -618,7 +639,8 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
       const float Z = 0.5f * (c->h_pz[c->z0] + c->h_pz[c->z1 - 1]);
       const float pz = vp[vi].t[2] + (vp[vi].r[2][0] * X + (vp[vi].r[2][1] * Y + vp[vi].r[2][2] * Z));
       const float f = std::max(vp[vi].fx, vp[vi].fy);
-      worst = std::max(worst, pz > 0.0f ? f * res / pz : INFINITY);
+      // orthographic: one pixel per world unit
+      worst = std::max(worst, c->fused_ortho ? res : (pz > 0.0f ? f * res / pz : INFINITY));
     }
     const float side = 8.0f * 1.7320508f * worst + 3.0f;
     big = side * side > (float)kTileSmall;

@@ -154,6 +154,7 @@ int launch_carve(vcy_ctx* c, int n_views, const vcy_view* views, const float* co
     if (rcm != VCY_OK) return rcm;
   }
   if (fused) {
+    c->fused_ortho = views[0].is_ortho != 0;
     const int chunk = fused_max_views();
     for (int i = 0; i < n_views; i += chunk) {
       const int m = std::min(chunk, n_views - i);
