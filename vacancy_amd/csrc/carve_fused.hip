@@ -240,10 +240,14 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
   const float px = g.px[x], py = g.py[y];
   const bool want_bound = kNeedBound && cull_enabled;
 
-  // ---- prologue: per view, 8 lanes project the 8 corners of the wave brick -> footprint
-  // rectangle, then scan the rectangle for its maximum ---------------------------------------
-  for (int vbase = 0; vbase < nviews; vbase += 8) {
-    const int vi = vbase + (lane >> 3), corner = lane & 7;
+  // ---- prologue: per view, a group of lanes projects the 8 corners of the wave brick -> footprint
+  // rectangle, then scans the rectangle for its maximum.  8 lanes per view (8 views per pass); with
+  // few views per launch the group grows to 16/32/64 lanes, which only shortens the scan -----------
+  const int lpv_shift = nviews >= 8 ? 3 : (nviews >= 4 ? 4 : (nviews >= 2 ? 5 : 6));
+  const int lpv = 1 << lpv_shift, views_per_pass = 64 >> lpv_shift;
+  for (int vbase = 0; vbase < nviews; vbase += views_per_pass) {
+    const int vi = vbase + (lane >> lpv_shift), corner = lane & 7;
+    const int sub = (lane & (lpv - 1)) >> 3, nsub = lpv >> 3;  // row group inside the view's lanes
     if (vi < nviews) {
       const ViewParams& v = views[vi].v;
       const int x_lo = min(x_first, g.nx - 1), x_hi = min(x_first + WX - 1, g.nx - 1);
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
             gfloat_ptr img = (gfloat_ptr)v.sdf;
             float m = -INFINITY;
             int has_nan = 0;
-            for (int j = 0; j < ph; ++j) {
+            for (int j = sub; j < ph; j += nsub) {
               gfloat_ptr row = img + ((unsigned)v.width * (unsigned)(ty0 + j) + (unsigned)tx0);
               for (int i = corner; i < pw; i += 8) {
                 const float t = row[i];
@@ -324,8 +328,7 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
                 m = fmaxf(m, t);
               }
             }
-#pragma unroll
-            for (int d = 1; d < 8; d <<= 1) {
+            for (int d = 1; d < lpv; d <<= 1) {
               m = fmaxf(m, __shfl_xor(m, d, 64));
               has_nan |= __shfl_xor(has_nan, d, 64);
             }
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
           }
         }
       }
-      if (corner == 0) tinfo[vi] = ti;
+      if ((lane & (lpv - 1)) == 0) tinfo[vi] = ti;
     }
   }
   wave_lds_fence();
