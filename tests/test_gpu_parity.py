@@ -443,3 +443,39 @@ def test_bunny_scale_big_tiles(res):
         assert dev.CarveBatchDevice(views, devs), vc.last_error()
         ds, du = dev.download()
         assert np.array_equal(du, ou) and np.array_equal(ds.view(np.uint32), os_.view(np.uint32)), (res, tile)
+
+
+@pytest.mark.parametrize("dims", [(1, 1, 5), (2, 3, 1), (9, 1, 1), (1, 7, 2), (3, 3, 3), (65, 2, 9), (8, 8, 8), (33, 9, 17)])
+def test_odd_grid_shapes(dims):
+    """Grids thinner than a wave brick, single-voxel axes, dims straddling brick / word boundaries;
+    a 1x1 and a 2x1 image; one camera looking away from the grid (nothing is carved)."""
+    nx, ny, nz = dims
+    opt = vc.CarverOption(bb_min=(-nx / 2.0, -ny / 2.0, -nz / 2.0), bb_max=(nx / 2.0, ny / 2.0, nz / 2.0),
+                          resolution=1.0, update_option=UpdateOption(update_outside=int(nx % 2)))
+    rng = np.random.RandomState(nx * 100 + ny * 10 + nz)
+    views, sdfs = [], []
+    for (w, h, away) in ((40, 30, False), (1, 1, False), (2, 1, False), (64, 48, True), (31, 17, False)):
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        pos = d * (max(dims) * 2.0 + 3.0)
+        target = pos * 2.0 if away else np.zeros(3)
+        w2c = synth.affine_inverse(synth.lookat_c2w(pos, target, (0.0, 1.0, 0.0) if abs(d[1]) < 0.9 else (1.0, 0.0, 0.0)))
+        f = np.float32(max(w, h) * 1.2)
+        views.append(vc.make_view(w2c.astype(np.float32), f, f, np.float32(w / 2 - 0.5), np.float32(h / 2 - 0.5), w, h))
+        sdfs.append(rng.uniform(-1, 1, (h, w)).astype(np.float32))
+    orc = O.OracleGrid(opt)
+    assert orc.dims == dims
+    for v, s_ in zip(views, sdfs):
+        orc.carve(v, s_)
+    os_, ou = orc.download()
+    for fused in (1, 0):
+        dev = vc.VoxelCarver(opt)
+        assert dev.Init(), vc.last_error()
+        assert dev.dims == dims
+        dev.set_param("fused", fused)
+        assert dev.CarveBatchDevice(views, [dev.upload_sdf(s_) for s_ in sdfs]), vc.last_error()
+        ds, du = dev.download()
+        assert np.array_equal(du, ou) and np.array_equal(ds.view(np.uint32), os_.view(np.uint32)), (dims, fused)
+        assert_mesh_equal(dev.ExtractIsoSurface(0.0, True), orc.marching_cubes(0.0, True), str(dims))
+        dv, ov = dev.ExtractVoxel(True), orc.extract_voxel(True)
+        assert np.array_equal(dv["faces"], ov["faces"]) and np.array_equal(dv["vertices"].view(np.uint32), ov["vertices"].view(np.uint32))
