@@ -33,6 +33,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--mode", default="default", choices=["default", "tsdf"])
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="shortcut for BASELINE.json configs[i]: 1 = 512^3 x16 @640x480 TSDF, 2/3 = 1024^3 x32 "
+                         "@1280x720 (the default; 3 is the same with --gpus N), 4 = 2048^3 x64 @1920x1080")
     ap.add_argument("--batch", type=int, default=1, help="1: fused multi-view carve; 0: one launch per view")
     ap.add_argument("--cull", type=int, default=1,
                     help="1: drop (brick, view) pairs that provably cannot change the brick (results identical)")
@@ -42,7 +45,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.config == 1:
+        a.grid, a.views, a.width, a.height, a.mode = 512, 16, 640, 480, "tsdf"
+    elif a.config in (2, 3):
+        a.grid, a.views, a.width, a.height, a.mode = 1024, 32, 1280, 720, "default"
+    elif a.config == 4:
+        a.grid, a.views, a.width, a.height, a.mode = 2048, 64, 1920, 1080, "default"
+    return a
 
 
 def cpu_baseline(args, views, sdfs, budget_s):
@@ -191,8 +201,9 @@ def main():
     # launch duration from HIP events on the launch stream.
     bytes_per_vv = 4.0 if args.mode == "default" else 4.0 + (1 if uo.voxel_max_update_num <= 254 else 2)
     slab_vox = sum(c.slab_voxels for c in devs) / float(len(devs))  # per launch
-    launches_per_step = (1 if args.batch else nv) * len(devs)
-    views_per_launch = nv if args.batch else 1
+    FUSED_MAX = 32  # views per fused launch (carve_fused.hip)
+    views_per_launch = min(nv, FUSED_MAX) if args.batch else 1
+    launches_per_step = ((nv + views_per_launch - 1) // views_per_launch) * len(devs)
     avg_launch_ms = sum(kernel_ms) / len(kernel_ms) / launches_per_step
     achieved = slab_vox * views_per_launch * bytes_per_vv / (avg_launch_ms * 1e-3) / 1e9
     traffic = None
