@@ -101,3 +101,58 @@ def test_random_scene(seed):
         assert np.array_equal(dm["keys"], om["keys"]) and np.array_equal(dm["faces"], om["faces"])
         assert np.array_equal(dm["vertices"].view(np.uint32), om["vertices"].view(np.uint32))
         dev.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_silhouettes_device_sdf_and_batches(seed):
+    """Random masks (blobs, noise, values other than 0/255, empty, full) with random ROIs: the device
+    SDF builder (single and batched/streamed) equals the oracle's MakeSignedDistanceField bit for bit,
+    and carving them through vcy_carve_batch_silhouettes equals the oracle's per-view loop."""
+    rng = np.random.RandomState(500 + seed)
+    n = int(rng.randint(12, 30))
+    uo = UpdateOption(voxel_update=int(rng.randint(0, 2)), use_truncation=bool(rng.randint(0, 2)),
+                      truncation_band=float(rng.choice([0.1, 0.4])))
+    opt = synth.sphere_option(n, uo)
+    opt.sdf_minmax_normalize = int(rng.randint(0, 2))
+    nv = int(rng.randint(2, 40))
+    w, h = int(rng.randint(8, 150)), int(rng.randint(8, 110))
+    views, _ = synth.sphere_views(n, nv, w, h)
+    masks = []
+    yy, xx = np.mgrid[0:h, 0:w]
+    for i in range(nv):
+        kind = rng.randint(0, 6)
+        if kind == 0:
+            m = np.zeros((h, w), np.uint8)
+        elif kind == 1:
+            m = np.full((h, w), 255, np.uint8)
+        elif kind == 2:
+            m = ((rng.rand(h, w) < rng.uniform(0.05, 0.95)) * 255).astype(np.uint8)
+        else:
+            cx, cy, r = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(2, max(w, h) / 2)
+            m = ((np.hypot(xx - cx, yy - cy) < r) * 255).astype(np.uint8)
+            if kind == 5:
+                m[rng.rand(h, w) < 0.05] = rng.randint(1, 255)
+        masks.append(m)
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init(), vc.last_error()
+    for m in masks[:4]:
+        x0, y0 = int(rng.randint(0, w // 2)), int(rng.randint(0, h // 2))
+        x1, y1 = int(rng.randint(x0, w)), int(rng.randint(y0, h))
+        for rmin, rmax in ((None, None), ((x0, y0), (x1, y1))):
+            d = dev.make_sdf_device(m, rmin, rmax, bool(opt.sdf_minmax_normalize), bool(uo.use_truncation),
+                                    uo.truncation_band)
+            got = dev.download_image(d, m.shape)
+            dev.free_device(d)
+            ref = O.make_sdf(m, rmin, rmax, bool(opt.sdf_minmax_normalize), bool(uo.use_truncation),
+                             uo.truncation_band)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (seed, rmin, rmax)
+    assert dev.CarveBatchSilhouettes(views, masks), vc.last_error()
+    orc = O.OracleGrid(opt)
+    for v, m in zip(views, masks):
+        orc.carve(v, O.make_sdf(m, None, None, bool(opt.sdf_minmax_normalize), bool(uo.use_truncation),
+                                uo.truncation_band))
+    ds, du = dev.download()
+    os_, ou = orc.download()
+    nan_d, nan_o = np.isnan(ds), np.isnan(os_)
+    assert np.array_equal(du, ou) and np.array_equal(nan_d, nan_o)
+    assert np.array_equal(np.where(nan_d, 0, ds.view(np.uint32)), np.where(nan_o, 0, os_.view(np.uint32)))
