@@ -128,7 +128,18 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)  # fail here, on every rank alike, rather than mid-benchmark
+                torch.cuda.synchronize()
+            except Exception as e:  # RCCL unusable in this environment: the carve path needs no collective,
+                # so keep measuring it; timing reductions and the halo exchange go through gloo instead
+                sys.stderr.write("bench: nccl backend failed (%s); falling back to gloo\n" % e)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(backend)
     red_dev = "cuda" if backend == "nccl" else "cpu"
