@@ -227,7 +227,15 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
   float4* tile = tile_all[wave];
   TileInfo* tinfo = tinfo_all[wave];
   const int lx = lane & (WX - 1), ly = lane >> 3;
+  // XCD-aware order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, so
+  // workgroup b runs on XCD b % 8.  Give every XCD one contiguous eighth of the brick list: bricks
+  // that follow each other on an XCD are neighbours in x and share SDF footprint pixels and
+  // z-table entries in that XCD's private L2.
   int b = blockIdx.x;
+  {
+    const int nb = gridDim.x, per = nb >> 3;
+    if (b < per * 8) b = (b & 7) * per + (b >> 3);
+  }
   const int bx = b % nbx;
   b /= nbx;
   const int by = b % nby;
