@@ -342,7 +342,14 @@ __global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restr
                                                         uint32_t* __restrict__ word_cell_off,
                                                         u64* __restrict__ block_cells) {
   __shared__ int sm[4];
-  const int64_t cw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // XCD-aware order (workgroup b runs on XCD b % 8): consecutive word blocks -- which share their
+  // boundary rows and, one layer later, the rows of slice z-1 -- stay on one XCD's L2
+  int64_t lb = blockIdx.x;
+  {
+    const int64_t per = gridDim.x >> 3;
+    if (lb < per * 8) lb = (lb & 7) * per + (lb >> 3);
+  }
+  const int64_t cw = lb * 256 + threadIdx.x;
   u64 a = 0;
   if (cw < p.nwords) {
     int li, cy, w;
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restr
   int total;
   const int off = block_exclusive_scan(__popcll(a), &total, sm);
   if (cw < p.nwords) word_cell_off[cw] = (uint32_t)off;
-  if (threadIdx.x == 0) block_cells[blockIdx.x] = (u64)(unsigned)total;
+  if (threadIdx.x == 0) block_cells[lb] = (u64)(unsigned)total;
 }
 
 // ---- pass 2: compact the active cells into a list (raster order is preserved) ------------------
