@@ -231,6 +231,15 @@ def main():
                 "kernel": "carve_batch" if args.batch else "carve_view",
                 "avg_launch_ms": round(avg_launch_ms, 4),
                 "algorithmic_bytes_per_launch": slab_vox * views_per_launch * bytes_per_vv}
+    # measured streaming bandwidth of this box next to the vendor figure (after the timed region)
+    try:
+        rd, cp = vc.measure_bandwidth(local_rank, 1 << 31, 3)
+        roofline["measured_read_gbs"] = round(rd, 1)
+        roofline["measured_copy_gbs"] = round(cp, 1)
+        roofline["frac_of_measured_read"] = round(achieved / rd, 4) if rd > 0 else None
+    except Exception as e:
+        roofline["measured_read_gbs"] = None
+        roofline["measured_error"] = "%s: %s" % (type(e).__name__, e)
 
     # marching cubes (second half of the metric), outside the timed region
     mc = None

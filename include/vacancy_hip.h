@@ -235,6 +235,12 @@ int vcy_sync(vcy_ctx* ctx);
 int vcy_timer_begin(vcy_ctx* ctx);
 int vcy_timer_end(vcy_ctx* ctx, float* elapsed_ms);
 
+/* Measured device-memory bandwidth of this GPU, for the roofline next to the vendor peak
+ * ("print a measured device-memcpy/triad GB/s on the box"): a streaming read of
+ * `bytes` (dword loads, eight in flight per lane, the access shape of the grid sweeps here) and a
+ * device-to-device copy of `bytes` (counted as read + write).  Best of `reps`; GB/s = 1e9 B/s. */
+int vcy_measure_bandwidth(int device_id, uint64_t bytes, int reps, double* read_gbs, double* copy_gbs);
+
 const char* vcy_last_error(void);
 const char* vcy_version(void);
 

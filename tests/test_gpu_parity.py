@@ -479,3 +479,12 @@ def test_odd_grid_shapes(dims):
         assert_mesh_equal(dev.ExtractIsoSurface(0.0, True), orc.marching_cubes(0.0, True), str(dims))
         dv, ov = dev.ExtractVoxel(True), orc.extract_voxel(True)
         assert np.array_equal(dv["faces"], ov["faces"]) and np.array_equal(dv["vertices"].view(np.uint32), ov["vertices"].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_measured_bandwidth_probe():
+    """vcy_measure_bandwidth: the measured denominator bench.py prints next to the 8 TB/s figure."""
+    rd, cp = vc.measure_bandwidth(0, 1 << 28, 2)
+    assert 500.0 < rd < 16000.0 and 500.0 < cp < 16000.0
+    lib = vc.capi.load()
+    assert lib.vcy_measure_bandwidth(0, 16, 1, None, None) != 0  # too small / no outputs: rejected

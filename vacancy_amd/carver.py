@@ -264,6 +264,16 @@ class VoxelCarver:
         return ms.value
 
 
+def measure_bandwidth(device_id=0, nbytes=1 << 31, reps=3):
+    """(read GB/s, device-to-device copy GB/s) measured on this GPU (vcy_measure_bandwidth)."""
+    lib = capi.load()
+    rd, cp = C.c_double(), C.c_double()
+    rc = lib.vcy_measure_bandwidth(int(device_id), int(nbytes), int(reps), C.byref(rd), C.byref(cp))
+    if rc != 0:
+        raise RuntimeError("vcy_measure_bandwidth: " + last_error())
+    return rd.value, cp.value
+
+
 def make_sdf(mask, roi_min=None, roi_max=None, normalize=True, use_truncation=False, band=0.1):
     """MakeSignedDistanceField (voxel_carver.cc:169-237) through the C-ABI."""
     lib = capi.load()
