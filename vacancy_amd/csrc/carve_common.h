@@ -13,7 +13,7 @@ struct ViewParams {
   float fx, fy, cx, cy;
   float roi_min_x, roi_min_y, roi_max_x, roi_max_y;  // (float)int, as the reference's int->float compare
   int roi_min_xi, roi_min_yi, roi_max_xi, roi_max_yi;
-  int width;
+  int width, height;
   float max_sdf;
   const float* sdf;
 };

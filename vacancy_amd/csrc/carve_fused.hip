@@ -41,8 +41,18 @@ constexpr int kMaxFusedViews = 32;
 constexpr int kTileSmall = 128;          // quads per wave tile (2 KB): <= 2 per lane, prefetched in registers
 constexpr int kTileBig = 512;            // 8 KB per wave: footprints up to ~1.4 px per voxel, filled in place
 
+constexpr int kWmaxLevels = 5;           // window sizes 1, 2, 4, 8, 16
+
 struct FusedView {
   ViewParams v;
+  // Window maxima of the SDF image (built per launch by wmax_* below), or null:
+  //   wmax[L * plane + y * width + x] = max of g over [x, x + 2^L) x [y, y + 2^L) clipped to the image,
+  //   g = the SDF value, or +inf where it is NaN / infinite.
+  // The maximum over any pw x ph rectangle is then the maximum of ceil(pw/k) * ceil(ph/k) entries
+  // of the level k = 2^L <= min(pw, ph) (windows placed inside the rectangle, overlapping at the far
+  // edges): the prologue bounds a footprint with a handful of loads instead of scanning it.
+  const float* wmax;
+  int wmax_plane;
 };
 // c2_all[view][3][nz_local] = R[i][2] * pz[z]  (one fp32 multiply per entry, done on the host)
 
@@ -200,6 +210,178 @@ __device__ __forceinline__ void tile_fill(const ViewParams& v, const TileInfo& t
   }
 }
 
+// Level 0 of the window maxima: the image with non-finite values replaced by +inf (a footprint
+// holding one gives no bound: 0 * inf = NaN samples).  blockIdx.y = view.
+__global__ __launch_bounds__(256) void wmax_level0_kernel(const FusedView* __restrict__ views) {
+  const FusedView& fv = views[blockIdx.y];
+  const int npx = fv.v.width * fv.v.height;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (fv.wmax == nullptr || i >= npx) return;
+  const float t = fv.v.sdf[i];
+  float* out = const_cast<float*>(fv.wmax);
+  out[i] = (fabsf(t) <= 3.402823466e+38f) ? t : INFINITY;
+}
+
+// Level L+1 from level L (k = 2^L): the 2k window is the union of four k windows; windows are clipped
+// at the image border, where the neighbour k window degenerates to one inside the clipped 2k window.
+__global__ __launch_bounds__(256) void wmax_next_kernel(const FusedView* __restrict__ views, int level) {
+  const FusedView& fv = views[blockIdx.y];
+  const int w = fv.v.width, h = fv.v.height;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (fv.wmax == nullptr || i >= w * h) return;
+  const int y = i / w, x = i - y * w;
+  const int k = 1 << level;
+  const int x1 = min(x + k, w - 1), y1 = min(y + k, h - 1);
+  const float* in = fv.wmax + (size_t)level * fv.wmax_plane;
+  float* out = const_cast<float*>(fv.wmax) + (size_t)(level + 1) * fv.wmax_plane;
+  const float a = in[y * w + x], b = in[y * w + x1], c = in[y1 * w + x], d = in[y1 * w + x1];
+  out[i] = fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+// Prologue of the fused kernel, out of line so that its registers do not add to the main loop's:
+// The brick is convex, so the exact projections of its voxels lie in the hull of the exact
+// projections of its 8 corners.  Corners and voxels are both COMPUTED with a few float operations;
+// the rectangle is only trusted when an explicit first-order bound of those errors (err_u, err_w
+// below) is well inside the margin added around the corner hull.  Nothing here needs the exact
+// arithmetic of the samples: corners come from the linear form p000 + {0,ax} + {0,ay} + {0,az} and
+// an approximate reciprocal.
+template <bool SAMEF, int TQ, bool GEN>
+__device__ __attribute__((noinline)) float brick_footprints(const FusedView* __restrict__ views, int nviews, int lane,
+                                                            float xl, float xh, float yl, float yh, float zl_, float zh,
+                                                            bool is_ortho, bool outside_max, bool want_bound,
+                                                            TileInfo* tinfo) {
+  float ub_lane = INFINITY;
+  if (lane < nviews) {
+    const int vi = lane;
+    const ViewParams& v = views[vi].v;
+    const float xa = fmaxf(fabsf(xl), fabsf(xh)), ya = fmaxf(fabsf(yl), fabsf(yh)), za = fmaxf(fabsf(zl_), fabsf(zh));
+    const bool ortho = GEN && is_ortho;
+    float p0[3], ax[3], ay[3], az[3], mag[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      p0[i] = v.t[i] + (v.r[i][0] * xl + (v.r[i][1] * yl + v.r[i][2] * zl_));
+      ax[i] = v.r[i][0] * (xh - xl);
+      ay[i] = v.r[i][1] * (yh - yl);
+      az[i] = v.r[i][2] * (zh - zl_);
+      // magnitude of the terms of pc[i]: its computed value is within ~2^-21 * mag[i] of the exact one
+      mag[i] = fabsf(v.t[i]) + (fabsf(v.r[i][0]) * xa + (fabsf(v.r[i][1]) * ya + fabsf(v.r[i][2]) * za));
+    }
+    float umin = INFINITY, umax = -INFINITY, wmin = INFINITY, wmax_ = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+    int bad = 0;
+    const float fx = v.fx, fy = SAMEF ? v.fx : v.fy;
+#pragma unroll 1
+    for (int corner = 0; corner < 8; ++corner) {
+      const float sx = (corner & 1) ? 1.0f : 0.0f, sy = (corner & 2) ? 1.0f : 0.0f, sz = (corner & 4) ? 1.0f : 0.0f;
+      float pc[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        pc[i] = __builtin_fmaf(sz, az[i], __builtin_fmaf(sy, ay[i], __builtin_fmaf(sx, ax[i], p0[i])));
+      float u = pc[0], w = pc[1];
+      if (!ortho) {
+        bad |= !in_fast_div_range(pc[2]);  // in front of the camera, reciprocal finite and normal
+        const float rz = __builtin_amdgcn_rcpf(pc[2]);
+        u = __builtin_fmaf(fx * rz, pc[0], v.cx);
+        w = __builtin_fmaf(fy * rz, pc[1], v.cy);
+      }
+      umin = fminf(umin, u);
+      umax = fmaxf(umax, u);
+      wmin = fminf(wmin, w);
+      wmax_ = fmaxf(wmax_, w);
+      zmin = fminf(zmin, pc[2]);
+      zmax = fmaxf(zmax, pc[2]);
+    }
+    // finite inputs (NaN / huge values anywhere end up in mag), image coordinates of sane size
+    bad |= !(mag[0] < 0x1p60f) || !(mag[1] < 0x1p60f) || !(mag[2] < 0x1p60f);
+    bad |= !(umin > -1.0e6f) || !(umax < 1.0e6f) || !(wmin > -1.0e6f) || !(wmax_ < 1.0e6f);
+    const float uabs = fmaxf(fabsf(umin), fabsf(umax)), wabs = fmaxf(fabsf(wmin), fabsf(wmax_));
+    // |computed - exact| of an image coordinate, corner or voxel (first order, constants rounded up):
+    //   pinhole  u = fx * X / Z + cx:  fx * dX / Z + |u - cx| * dZ / Z + rounding of the last operations,
+    //            with dX <= 2^-21 mag_x, dZ <= 2^-21 mag_z and Z >= zmin;
+    //   ortho    u = X:                dX.
+    float err_u, err_w;
+    if (ortho) {
+      err_u = 0x1p-21f * mag[0];
+      err_w = 0x1p-21f * mag[1];
+    } else {
+      bad |= !(zmin * 4.0f >= zmax);
+      const float iz = 0x1p-21f * __builtin_amdgcn_rcpf(zmin) * 1.0001f;
+      err_u = iz * (fx * mag[0] + (uabs + fabsf(v.cx)) * mag[2]) + 0x1p-21f * (uabs + fabsf(v.cx));
+      err_w = iz * (fy * mag[1] + (wabs + fabsf(v.cy)) * mag[2]) + 0x1p-21f * (wabs + fabsf(v.cy));
+    }
+    const float margin = 0.125f;
+    bad |= !(err_u <= 0.03125f) || !(err_w <= 0.03125f);  // corner error + voxel error <= margin / 2
+    TileInfo ti;
+    ti.lo_x = ti.lo_y = INFINITY;  // nothing passes the tile test
+    ti.hi_x = ti.hi_y = -INFINITY;
+    ti.pitchf = 0.0f;
+    ti.base = 0;
+    ti.tx0 = ti.ty0 = ti.tw = ti.nq = 0;
+    ti.inv_tw = 1.0f;
+    ti.ub = INFINITY;  // never dropped
+    if (!bad) {
+      const int tx0 = max((int)floorf(umin - margin), v.roi_min_xi);
+      const int ty0 = max((int)floorf(wmin - margin), v.roi_min_yi);
+      const int tx1 = min((int)floorf(umax + margin), v.roi_max_xi);
+      const int ty1 = min((int)floorf(wmax_ + margin), v.roi_max_yi);
+      const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
+      if (tw > 0 && th > 0 && tw <= TQ && th <= TQ && tw * th <= TQ) {
+        ti.tx0 = tx0;
+        ti.ty0 = ty0;
+        ti.tw = tw;
+        ti.nq = tw * th;
+        ti.inv_tw = 1.0f / (float)tw;
+        ti.pitchf = (float)tw;
+        ti.base = -(ty0 * tw + tx0);
+        ti.lo_x = (float)tx0;
+        ti.lo_y = (float)ty0;
+        // taps exist for floor(u) in [tx0, tx1]; at the ROI edge u == roi_max is still inside
+        ti.hi_x = (tx1 == v.roi_max_xi) ? v.roi_max_x
+                                        : __uint_as_float(__float_as_uint((float)(tx1 + 1)) - 1u);
+        ti.hi_y = (ty1 == v.roi_max_yi) ? v.roi_max_y
+                                        : __uint_as_float(__float_as_uint((float)(ty1 + 1)) - 1u);
+        if (want_bound) {
+          // maximum over every pixel a tap of this tile can read
+          const int pw = min(tx1 + 1, v.roi_max_xi) - tx0 + 1;
+          const int ph = min(ty1 + 1, v.roi_max_yi) - ty0 + 1;
+          float m = -INFINITY;
+          int has_nan = 0;
+          gfloat_ptr wm = (gfloat_ptr)views[vi].wmax;
+          if (wm != nullptr) {
+            // window maxima: level k = 2^L <= min(pw, ph), nxw x nyw windows inside the rectangle
+            const int L = min(kWmaxLevels - 1, 31 - __clz(min(pw, ph)));
+            const int k = 1 << L;
+            const int nxw = (pw + k - 1) >> L, nyw = (ph + k - 1) >> L;
+            gfloat_ptr lvl = wm + (size_t)L * (size_t)views[vi].wmax_plane;
+            for (int bq = 0; bq < nyw; ++bq) {
+              gfloat_ptr row = lvl + (unsigned)v.width * (unsigned)(ty0 + min(bq << L, ph - k));
+              for (int aq = 0; aq < nxw; ++aq) m = fmaxf(m, row[tx0 + min(aq << L, pw - k)]);
+            }
+          } else {  // no planes (out of memory for them): scan the rectangle
+            gfloat_ptr img = (gfloat_ptr)v.sdf;
+            for (int j = 0; j < ph; ++j) {
+              gfloat_ptr row = img + ((unsigned)v.width * (unsigned)(ty0 + j) + (unsigned)tx0);
+              for (int i = 0; i < pw; ++i) {
+                const float t = row[i];
+                has_nan |= !(fabsf(t) <= 3.402823466e+38f);  // NaN or +-inf: 0 * inf = NaN samples
+                m = fmaxf(m, t);
+              }
+            }
+          }
+          // voxels projecting outside the ROI sample max_sdf instead (voxel_carver.cc:469-471)
+          if (outside_max) {
+            has_nan |= !(fabsf(v.max_sdf) <= 3.402823466e+38f);
+            m = fmaxf(m, v.max_sdf);
+          }
+          ti.ub = has_nan ? INFINITY : (__builtin_fmaf(fabsf(m), 0x1p-20f, m) + 1.0e-30f);
+        }
+      }
+    }
+    tinfo[vi] = ti;
+    ub_lane = ti.ub;
+  }
+  return ub_lane;
+}
+
 // GEN: nearest-neighbour sampling and/or an orthographic camera, selected at run time from `mode`
 // (compiled out of the default bilinear + pinhole kernels, where the extra branches cost 16 %).
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX, int TQ, bool GEN>
@@ -248,112 +430,17 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
   const float px = g.px[x], py = g.py[y];
   const bool want_bound = kNeedBound && cull_enabled;
 
-  // ---- prologue: per view, a group of lanes projects the 8 corners of the wave brick -> footprint
-  // rectangle, then scans the rectangle for its maximum.  8 lanes per view (8 views per pass); with
-  // few views per launch the group grows to 16/32/64 lanes, which only shortens the scan -----------
-  const int lpv_shift = nviews >= 8 ? 3 : (nviews >= 4 ? 4 : (nviews >= 2 ? 5 : 6));
-  const int lpv = 1 << lpv_shift, views_per_pass = 64 >> lpv_shift;
-  for (int vbase = 0; vbase < nviews; vbase += views_per_pass) {
-    const int vi = vbase + (lane >> lpv_shift), corner = lane & 7;
-    const int sub = (lane & (lpv - 1)) >> 3, nsub = lpv >> 3;  // row group inside the view's lanes
-    if (vi < nviews) {
-      const ViewParams& v = views[vi].v;
-      const int x_lo = min(x_first, g.nx - 1), x_hi = min(x_first + WX - 1, g.nx - 1);
-      const int y_hi = min(by * BY + BY - 1, g.ny - 1);
-      const int z_hi = min(zl0 + BZ - 1, g.nz_local - 1);
-      const float cpx = g.px[(corner & 1) ? x_hi : x_lo];
-      const float cpy = g.py[(corner & 2) ? y_hi : by * BY];
-      const float cpz = g.pz[g.z0 + ((corner & 4) ? z_hi : zl0)];
-      float pc[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-        pc[i] = v.t[i] + (v.r[i][0] * cpx + (v.r[i][1] * cpy + v.r[i][2] * cpz));
-      const bool ortho = GEN && mode.ortho != 0;
-      const float u = ortho ? pc[0] : v.fx / pc[2] * pc[0] + v.cx;
-      const float w = ortho ? pc[1] : v.fy / pc[2] * pc[1] + v.cy;
-      // The whole (convex) brick is in front of the camera iff all 8 corners are.  The footprint
-      // rectangle below is only trusted when the computed image coordinates are accurate to a small
-      // fraction of a pixel: depth spread of the brick below 4x and no catastrophic cancellation in
-      // pc.z (then every voxel of the brick projects within `margin` of the corner hull: the exact
-      // projections are inside it by convexity, computed ones differ by a few ulps).
-      const float zmag = fabsf(v.t[2]) + fabsf(v.r[2][0] * cpx) + fabsf(v.r[2][1] * cpy) + fabsf(v.r[2][2] * cpz);
-      int bad = !(fabsf(u) < 1.0e6f) || !(fabsf(w) < 1.0e6f);
-      if (!ortho) bad |= !(pc[2] > 0.0f) || !(pc[2] >= zmag * 0x1p-12f);
-      float umin = u, umax = u, wmin = w, wmax = w, zmin = pc[2], zmax = pc[2];
-#pragma unroll
-      for (int d = 1; d < 8; d <<= 1) {
-        umin = fminf(umin, __shfl_xor(umin, d, 64));
-        umax = fmaxf(umax, __shfl_xor(umax, d, 64));
-        wmin = fminf(wmin, __shfl_xor(wmin, d, 64));
-        wmax = fmaxf(wmax, __shfl_xor(wmax, d, 64));
-        zmin = fminf(zmin, __shfl_xor(zmin, d, 64));
-        zmax = fmaxf(zmax, __shfl_xor(zmax, d, 64));
-        bad |= __shfl_xor(bad, d, 64);
-      }
-      if (!ortho) bad |= !(zmin * 4.0f >= zmax);
-      const float margin = 0.125f + 0x1p-16f * fmaxf(fmaxf(fabsf(umin), fabsf(umax)), fmaxf(fabsf(wmin), fabsf(wmax)));
-      TileInfo ti;
-      ti.lo_x = ti.lo_y = INFINITY;  // nothing passes the tile test
-      ti.hi_x = ti.hi_y = -INFINITY;
-      ti.pitchf = 0.0f;
-      ti.base = 0;
-      ti.tx0 = ti.ty0 = ti.tw = ti.nq = 0;
-      ti.inv_tw = 1.0f;
-      ti.ub = INFINITY;  // never dropped
-      if (!bad) {
-        const int tx0 = max((int)floorf(umin - margin), v.roi_min_xi);
-        const int ty0 = max((int)floorf(wmin - margin), v.roi_min_yi);
-        const int tx1 = min((int)floorf(umax + margin), v.roi_max_xi);
-        const int ty1 = min((int)floorf(wmax + margin), v.roi_max_yi);
-        const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
-        if (tw > 0 && th > 0 && tw <= TQ && th <= TQ && tw * th <= TQ) {
-          ti.tx0 = tx0;
-          ti.ty0 = ty0;
-          ti.tw = tw;
-          ti.nq = tw * th;
-          ti.inv_tw = 1.0f / (float)tw;
-          ti.pitchf = (float)tw;
-          ti.base = -(ty0 * tw + tx0);
-          ti.lo_x = (float)tx0;
-          ti.lo_y = (float)ty0;
-          // taps exist for floor(u) in [tx0, tx1]; at the ROI edge u == roi_max is still inside
-          ti.hi_x = (tx1 == v.roi_max_xi) ? v.roi_max_x
-                                          : __uint_as_float(__float_as_uint((float)(tx1 + 1)) - 1u);
-          ti.hi_y = (ty1 == v.roi_max_yi) ? v.roi_max_y
-                                          : __uint_as_float(__float_as_uint((float)(ty1 + 1)) - 1u);
-          if (want_bound) {
-            // maximum over every pixel a tap of this tile can read
-            const int pw = min(tx1 + 1, v.roi_max_xi) - tx0 + 1;
-            const int ph = min(ty1 + 1, v.roi_max_yi) - ty0 + 1;
-            gfloat_ptr img = (gfloat_ptr)v.sdf;
-            float m = -INFINITY;
-            int has_nan = 0;
-            for (int j = sub; j < ph; j += nsub) {
-              gfloat_ptr row = img + ((unsigned)v.width * (unsigned)(ty0 + j) + (unsigned)tx0);
-              for (int i = corner; i < pw; i += 8) {
-                const float t = row[i];
-                has_nan |= !(fabsf(t) <= 3.402823466e+38f);  // NaN or +-inf: 0 * inf = NaN samples
-                m = fmaxf(m, t);
-              }
-            }
-            for (int d = 1; d < lpv; d <<= 1) {
-              m = fmaxf(m, __shfl_xor(m, d, 64));
-              has_nan |= __shfl_xor(has_nan, d, 64);
-            }
-            // voxels projecting outside the ROI sample max_sdf instead (voxel_carver.cc:469-471)
-            if (mode.outside == VCY_OUTSIDE_MAX) {
-              has_nan |= !(fabsf(v.max_sdf) <= 3.402823466e+38f);
-              m = fmaxf(m, v.max_sdf);
-            }
-            ti.ub = has_nan ? INFINITY : (__builtin_fmaf(fabsf(m), 0x1p-20f, m) + 1.0e-30f);
-          }
-        }
-      }
-      if ((lane & (lpv - 1)) == 0) tinfo[vi] = ti;
-    }
+  // ---- prologue: lane vi bounds the footprint of the wave brick in view vi (brick_footprints) -------
+  float ub_lane;
+  {
+    const int x_lo = min(x_first, g.nx - 1), x_hi = min(x_first + WX - 1, g.nx - 1);
+    const int y_hi = min(by * BY + BY - 1, g.ny - 1);
+    const int z_hi = min(zl0 + BZ - 1, g.nz_local - 1);
+    ub_lane = brick_footprints<SAMEF, TQ, GEN>(views, nviews, lane, g.px[x_lo], g.px[x_hi], g.py[by * BY], g.py[y_hi],
+                                               g.pz[g.z0 + zl0], g.pz[g.z0 + z_hi], mode.ortho != 0,
+                                               mode.outside == VCY_OUTSIDE_MAX, want_bound, tinfo);
   }
   wave_lds_fence();
-  const float ub_lane = (lane < nviews) ? tinfo[min(lane, kMaxFusedViews - 1)].ub : INFINITY;
   const unsigned long long view_mask = (nviews >= 64) ? ~0ull : ((1ull << nviews) - 1ull);
 
   // ---- load the wave brick's state ----------------------------------------------------------
@@ -609,6 +696,32 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     fv[vi].v = vp[vi];
     samef = samef && (vp[vi].fx == vp[vi].fy);
   }
+  // Window-maximum planes for the view-dropping bounds (kMax or truncation, see the kernel).  Without
+  // the memory for them the kernel scans the footprints instead; results are the same either way.
+  const bool need_bound = c->use_cull && (u.voxel_update == VCY_UPDATE_MAX || u.use_truncation);
+  int max_px = 0;
+  if (need_bound) {
+    size_t total = 0;
+    for (int vi = 0; vi < n_views; ++vi) total += (size_t)kWmaxLevels * vp[vi].width * vp[vi].height;
+    if (c->wmax_bytes < total * sizeof(float)) {
+      VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+      if (c->d_wmax) (void)hipFree(c->d_wmax);
+      c->d_wmax = nullptr;
+      c->wmax_bytes = 0;
+      if (hipMalloc(&c->d_wmax, total * sizeof(float)) == hipSuccess) c->wmax_bytes = total * sizeof(float);
+      else { c->d_wmax = nullptr; (void)hipGetLastError(); }
+    }
+    if (c->d_wmax) {
+      size_t off = 0;
+      for (int vi = 0; vi < n_views; ++vi) {
+        const int npx = vp[vi].width * vp[vi].height;
+        fv[vi].wmax = c->d_wmax + off;
+        fv[vi].wmax_plane = npx;
+        off += (size_t)kWmaxLevels * npx;
+        max_px = std::max(max_px, npx);
+      }
+    }
+  }
   // Upload the view blocks and z tables unless the device copy already holds exactly these
   // (repeated carves of the same views, e.g. after vcy_reset).
   const bool cached = c->fused_cache_valid && c->fused_cache_views.size() == fv_bytes &&
@@ -626,6 +739,12 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     c->fused_cache_valid = true;
   }
 
+  if (max_px > 0) {  // the images may have changed since the last call: rebuild every time
+    const dim3 wgrid((unsigned)((max_px + 255) / 256), (unsigned)n_views);
+    hipLaunchKernelGGL(wmax_level0_kernel, wgrid, dim3(256), 0, c->stream, d_views);
+    for (int L = 0; L + 1 < kWmaxLevels; ++L)
+      hipLaunchKernelGGL(wmax_next_kernel, wgrid, dim3(256), 0, c->stream, d_views, L);
+  }
   const int nbx = (c->nx + BX - 1) / BX, nby = (c->ny + BY - 1) / BY, nbz = (nzl + BZ - 1) / BZ;
   const int64_t nblocks = (int64_t)nbx * nby * nbz;
   if (nblocks > 0x7fffffffLL) {

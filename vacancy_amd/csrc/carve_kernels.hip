@@ -81,6 +81,7 @@ static void fill_view(const vcy_view& in, const float* sdf_dev, float max_sdf, V
   v->roi_max_x = (float)in.roi_max[0];
   v->roi_max_y = (float)in.roi_max[1];
   v->width = in.width;
+  v->height = in.height;
   v->max_sdf = max_sdf;
   v->sdf = sdf_dev;
 }

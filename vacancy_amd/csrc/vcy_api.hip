@@ -231,6 +231,7 @@ void vcy_destroy(vcy_ctx* c) {
   (void)hipFree(c->d_mc_out);
   (void)hipFree(c->d_mc_cells);
   (void)hipFree(c->d_fused_scratch);
+  (void)hipFree(c->d_wmax);
   delete[] c->h_pz;
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);

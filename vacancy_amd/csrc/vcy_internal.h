@@ -71,6 +71,8 @@ struct vcy_ctx {
   float* h_pz = nullptr;              // host copy of d_pz (per-view z tables of the fused carve)
   void* d_fused_scratch = nullptr;    // view blocks + z tables of the fused carve kernel
   size_t fused_scratch_bytes = 0;
+  float* d_wmax = nullptr;            // window-maximum planes of the views of one fused launch
+  size_t wmax_bytes = 0;
   bool fused_ortho = false;           // projection model of the launch being prepared
   bool fused_cache_valid = false;     // host mirror of what d_fused_scratch holds
   std::vector<char> fused_cache_views;
