@@ -269,13 +269,19 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
     float umin = INFINITY, umax = -INFINITY, wmin = INFINITY, wmax_ = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
     int bad = 0;
     const float fx = v.fx, fy = SAMEF ? v.fx : v.fy;
-#pragma unroll 1
+    float pxy[4][3];  // p0, p0 + ax, p0 + ay, p0 + ax + ay
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      pxy[0][i] = p0[i];
+      pxy[1][i] = p0[i] + ax[i];
+      pxy[2][i] = p0[i] + ay[i];
+      pxy[3][i] = pxy[1][i] + ay[i];
+    }
+#pragma unroll
     for (int corner = 0; corner < 8; ++corner) {
-      const float sx = (corner & 1) ? 1.0f : 0.0f, sy = (corner & 2) ? 1.0f : 0.0f, sz = (corner & 4) ? 1.0f : 0.0f;
       float pc[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
-        pc[i] = __builtin_fmaf(sz, az[i], __builtin_fmaf(sy, ay[i], __builtin_fmaf(sx, ax[i], p0[i])));
+      for (int i = 0; i < 3; ++i) pc[i] = (corner & 4) ? pxy[corner & 3][i] + az[i] : pxy[corner & 3][i];
       float u = pc[0], w = pc[1];
       if (!ortho) {
         bad |= !in_fast_div_range(pc[2]);  // in front of the camera, reciprocal finite and normal
