@@ -174,22 +174,20 @@ __device__ __forceinline__ void tile_prefetch(const ViewParams& v, const TileInf
   }
 }
 
-// min over the wave (NaN operands are ignored, like the `dist > s` test ignores them); DPP row
-// reduction + one readlane per row, no LDS traffic
+// min over the wave (NaN operands are ignored, like the `dist > s` test ignores them): six DPP
+// v_min_f32 (row reduction, then row_bcast 15 / 31) and one readlane.  Written in assembly because
+// the compiler expands a DPP move + canonicalise + min per step; the s_nop covers the VALU-write ->
+// DPP-read hazard the assembler does not see inside an asm block.
 __device__ __forceinline__ float wave_min(float v) {
-#define VCY_DPP_MIN(CTRL)                                                                              \
-  v = fminf(v, __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, \
-                                                                     0xF, false)))
-  VCY_DPP_MIN(0xB1);   // quad_perm [1,0,3,2]
-  VCY_DPP_MIN(0x4E);   // quad_perm [2,3,0,1]
-  VCY_DPP_MIN(0x141);  // row_half_mirror
-  VCY_DPP_MIN(0x140);  // row_mirror: every lane of a 16-lane row now holds the row minimum
+#define VCY_DPP_MIN(CTRL) asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " CTRL : "+v"(v))
+  VCY_DPP_MIN("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+  VCY_DPP_MIN("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+  VCY_DPP_MIN("row_half_mirror row_mask:0xf bank_mask:0xf");
+  VCY_DPP_MIN("row_mirror row_mask:0xf bank_mask:0xf");  // every lane of a 16-lane row holds the row minimum
+  VCY_DPP_MIN("row_bcast:15 row_mask:0xa bank_mask:0xf");  // rows 1, 3 <- min(own, row 0 / 2)
+  VCY_DPP_MIN("row_bcast:31 row_mask:0xc bank_mask:0xf");  // rows 2, 3 <- min(own, row 1): lane 63 = all
 #undef VCY_DPP_MIN
-  const float r0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 0));
-  const float r1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 16));
-  const float r2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 32));
-  const float r3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 48));
-  return fminf(fminf(r0, r1), fminf(r2, r3));
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 63));
 }
 
 // Fills a whole (big) tile in place: lane q, q+64, ... (no register prefetch).
@@ -464,21 +462,23 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
   }
 
   // views that may still change something, as a wave-uniform bit mask
+  bool all_touched = false;  // wave-uniform
   auto live_views = [&]() -> unsigned long long {
     bool drop = false;
     if (want_bound) {
       if (TRUNC) drop = ub_lane < -1.0f;
       if (UPDATE == VCY_UPDATE_MAX) {
         float m = s[0];
-        int nmin = n[0];
 #pragma unroll
-        for (int k = 1; k < BZ; ++k) {
-          m = fminf(m, s[k]);
-          nmin = min(nmin, n[k]);
+        for (int k = 1; k < BZ; ++k) m = fminf(m, s[k]);
+        if (!all_touched) {  // update_num never decreases: once every voxel is touched it stays so
+          int nmin = n[0];
+#pragma unroll
+          for (int k = 1; k < BZ; ++k) nmin = min(nmin, n[k]);
+          all_touched = __all(nmin >= 1);
         }
         const float smin = wave_min(m);
-        const bool touched = __all(nmin >= 1);
-        drop = drop || (touched && ub_lane <= smin);
+        drop = drop || (all_touched && ub_lane <= smin);
       }
     }
     return __ballot(!drop) & view_mask;
