@@ -36,7 +36,8 @@ typedef enum vcy_status {
   VCY_ERR_TOO_MANY_VOXELS = -3,
   VCY_ERR_HIP = -4,           /* a HIP runtime call failed */
   VCY_ERR_NO_DEVICE = -5,
-  VCY_ERR_UNSUPPORTED = -6
+  VCY_ERR_UNSUPPORTED = -6,
+  VCY_ERR_INTERNAL = -7       /* vcy_selftest: a device-side identity a fast path relies on does not hold */
 } vcy_status;
 
 /* vacancy::VoxelUpdate / SdfInterpolation / UpdateOutsideImage
@@ -234,6 +235,12 @@ int vcy_sync(vcy_ctx* ctx);
  * between begin and end; vcy_timer_end synchronises and returns milliseconds. */
 int vcy_timer_begin(vcy_ctx* ctx);
 int vcy_timer_end(vcy_ctx* ctx, float* elapsed_ms);
+
+/* Device-side self test of the identities the fast paths rest on (no reference counterpart): the
+ * two-instruction reciprocal used for update_num + 1 in the unit-weight weighted average equals the
+ * IEEE quotient for every count a u8 / u16 counter can hold.  VCY_OK, or VCY_ERR_INTERNAL with the
+ * mismatch in vcy_last_error(). */
+int vcy_selftest(vcy_ctx* ctx);
 
 /* Measured device-memory bandwidth of this GPU, for the roofline next to the vendor peak
  * ("print a measured device-memcpy/triad GB/s on the box"): a streaming read of

@@ -488,3 +488,25 @@ def test_measured_bandwidth_probe():
     assert 500.0 < rd < 16000.0 and 500.0 < cp < 16000.0
     lib = vc.capi.load()
     assert lib.vcy_measure_bandwidth(0, 16, 1, None, None) != 0  # too small / no outputs: rejected
+
+
+def test_selftest_and_unit_weight_average_many_views():
+    """The unit-weight weighted average uses a two-instruction reciprocal of update_num + 1:
+    vcy_selftest checks it against IEEE division for every count; here 300 views push the counts
+    of a small grid through 1..300 (u16 counter) against the oracle."""
+    n, nv = 20, 300
+    uo = UpdateOption(voxel_update=1, voxel_max_update_num=400)
+    opt = synth.sphere_option(n, uo)
+    views, masks = synth.sphere_views(n, nv, 64, 48)
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init(), vc.last_error()
+    assert dev.selftest(), vc.last_error()
+    orc = O.OracleGrid(opt)
+    sdf = O.make_sdf(masks[0])
+    d = dev.upload_sdf(sdf)
+    assert dev.CarveBatchDevice(vc.VoxelCarver.prepare_batch(views, [d] * nv)), vc.last_error()
+    for i in range(nv):
+        orc.carve(views[i], sdf)
+    assert_state_equal(dev, orc, "unit-weight average, 300 views")
+    assert int(dev.download()[1].max()) == nv
+    dev.free_device(d)

@@ -255,6 +255,10 @@ class VoxelCarver:
     def sync(self):
         self._lib.vcy_sync(self._ctx)
 
+    def selftest(self):
+        """vcy_selftest: device-side identities behind the fast paths; True when all hold."""
+        return self._lib.vcy_selftest(self._ctx) == 0
+
     def timer_begin(self):
         self._lib.vcy_timer_begin(self._ctx)
 

@@ -119,6 +119,18 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Internal update mode: kWeightedAverage with voxel_update_weight == 1.0f (the default weight).
+constexpr int kUpdateWaUnitWeight = 2;
+
+// Correctly rounded 1.0f / m for the integers m = 1 .. 65536 (update_num + 1 of a u8 / u16 counter):
+// v_rcp_f32 and ONE Newton step.  Unlike div_fast this is not correct for every float; that it is for
+// every m in the range is checked exhaustively on the device by vcy_selftest (and by the GPU tests).
+__device__ __forceinline__ float rcp_count(float m) {
+  const float r = __builtin_amdgcn_rcpf(m);
+  const float e = __builtin_fmaf(-m, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
+}
+
 // Branch-free voxel update (select form of fuse() in carve_common.h): first touch
 // (voxel_carver.cc:482-486), UpdateVoxelMax (:78-86) or UpdateVoxelWeightedAverage (:88-95).
 template <int UPDATE>
@@ -127,6 +139,13 @@ __device__ __forceinline__ void apply_sample(bool ok, float dist, float wgt, flo
     const bool take = ok && (n < 1 || dist > s);
     s = take ? dist : s;
     n += take ? 1 : 0;
+  } else if (UPDATE == kUpdateWaUnitWeight) {
+    // voxel_update_weight == 1: w * x == x exactly, and the denominator is the integer n + 1
+    const float inv_denom = rcp_count((float)(n + 1));
+    const float avg = ((float)n * s + dist) * inv_denom;
+    const float ns = (n < 1) ? dist : avg;
+    s = ok ? ns : s;
+    n += ok ? 1 : 0;
   } else {
     const float inv_denom = div_fast(1.0f, wgt * (float)(n + 1));
     const float avg = (wgt * (float)n * s + wgt * dist) * inv_denom;
@@ -650,6 +669,8 @@ void launch_fused_1(bool big, int update, bool trunc, bool samef, bool checkmax,
                     const GridParams& g, const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh) {
   if (update == VCY_UPDATE_MAX)
     launch_fused_2<CountT, VCY_UPDATE_MAX>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
+  else if (g.weight == 1.0f)
+    launch_fused_2<CountT, kUpdateWaUnitWeight>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
   else
     launch_fused_2<CountT, VCY_UPDATE_WEIGHTED_AVERAGE>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
 }
@@ -795,5 +816,36 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
 }
 
 int fused_max_views() { return kMaxFusedViews; }
+
+namespace {
+__global__ void selftest_rcp_count_kernel(int* n_bad) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x + 1;  // 1 .. 65536
+  const float x = (float)m;
+  if (rcp_count(x) != 1.0f / x) atomicAdd(n_bad, 1);  // IEEE division (-fhip-fp32-correctly-rounded-divide-sqrt)
+}
+}  // namespace
+
+// Device-side identities the fast paths of the fused kernel rest on; VCY_OK when all hold.
+int selftest_fused(hipStream_t stream) {
+  int* d_bad = nullptr;
+  int h_bad = -1;
+  VCY_HIP_CHECK(hipMalloc(&d_bad, sizeof(int)));
+  hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(int), stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(selftest_rcp_count_kernel, dim3(256), dim3(256), 0, stream, d_bad);
+    e = hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(d_bad);
+  if (e != hipSuccess) {
+    set_error("self test failed to run: %s", hipGetErrorString(e));
+    return VCY_ERR_HIP;
+  }
+  if (h_bad != 0) {
+    set_error("self test: rcp_count differs from IEEE division for %d of 65536 counts", h_bad);
+    return VCY_ERR_INTERNAL;
+  }
+  return VCY_OK;
+}
 
 }  // namespace vcy

@@ -310,6 +310,12 @@ int vcy_timer_end(vcy_ctx* c, float* ms) {
   return VCY_OK;
 }
 
+int vcy_selftest(vcy_ctx* c) {
+  if (!c) return VCY_ERR_NOT_INITIALIZED;
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  return selftest_fused(c->stream);
+}
+
 int vcy_sdf_upload(vcy_ctx* c, const float* host, int w, int h, float** dev_out) {
   if (!c || !host || !dev_out || w <= 0 || h <= 0) {
     set_error("invalid argument");

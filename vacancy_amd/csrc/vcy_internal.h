@@ -107,6 +107,7 @@ struct ViewParams;
 bool fused_eligible(const vcy_ctx* ctx, int n_views, const vcy_view* views);
 int launch_carve_fused(vcy_ctx* ctx, const GridParams& g, int n_views, const ViewParams* vp);
 int fused_max_views();
+int selftest_fused(hipStream_t stream);
 // mc_kernels.hip
 int extract_iso(vcy_ctx* ctx, double iso, int linear_interp, vcy_mesh* out);
 // sdf2d.hip
