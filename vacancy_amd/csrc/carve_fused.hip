@@ -27,6 +27,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "carve_common.h"
@@ -63,6 +64,7 @@ struct TileInfo {
   int tx0, ty0, tw, nq;          // nq = tw*th quads; 0: no tile for this view
   float inv_tw;                  // 1 / tw: q / tw == (int)((q + 0.5f) * inv_tw) for q < 2^12
   float ub;                      // upper bound of any sample taken from this tile (+inf: unknown)
+  int sure;                      // 1: every voxel of the brick provably samples inside this tile
 };
 
 // Correctly rounded n/d for normal operands away from the exponent limits: v_rcp_f32 plus the
@@ -341,6 +343,7 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
     ti.tx0 = ti.ty0 = ti.tw = ti.nq = 0;
     ti.inv_tw = 1.0f;
     ti.ub = INFINITY;  // never dropped
+    ti.sure = 0;
     if (!bad) {
       const int tx0 = max((int)floorf(umin - margin), v.roi_min_xi);
       const int ty0 = max((int)floorf(wmin - margin), v.roi_min_yi);
@@ -348,6 +351,13 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
       const int ty1 = min((int)floorf(wmax_ + margin), v.roi_max_yi);
       const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
       if (tw > 0 && th > 0 && tw <= TQ && th <= TQ && tw * th <= TQ) {
+        // Every computed (u, w) of the brick is within corner error + voxel error < margin of the corner
+        // hull, so when the ROI clipped nothing it lies in [tx0, tx1 + 1) x [ty0, ty1 + 1); the depth
+        // guard keeps every computed pc.z within a factor 2 of the corner range, inside div_fast's.
+        const bool unclipped = (int)floorf(umin - margin) >= v.roi_min_xi && (int)floorf(wmin - margin) >= v.roi_min_yi &&
+                               (int)floorf(umax + margin) < v.roi_max_xi && (int)floorf(wmax_ + margin) < v.roi_max_yi;
+        const bool depth_ok = 0x1p-20f * mag[2] <= 0.25f * zmin && zmin >= 0x1p-58f && zmax <= 0x1p58f;
+        ti.sure = (!ortho && unclipped && depth_ok) ? 1 : 0;
         ti.tx0 = tx0;
         ti.ty0 = ty0;
         ti.tw = tw;
@@ -540,69 +550,79 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
 
     // Straight-line fast path for the 8 voxels of this thread (no divergent control flow, so
     // the eight LDS reads and the arithmetic interleave); voxels the tile does not cover are
-    // only recorded here and handled below.
-    bool slow[BZ];
-    bool any_slow = false;
-    // Two voxels (k, k+1) share the packed-FP32 instructions of the depth and of the divide;
-    // within a voxel the (x, y) pair and the (1-l, l) weight pairs are packed.  Every single
-    // operation is still the reference's, in its order (v_pk_* are two independent fp32 ops).
+    // only recorded here and handled below.  SURE: the prologue has proved that every voxel of the
+    // brick samples inside this tile (TileInfo::sure), so the per-voxel tests are compiled out.
+    auto carve_view = [&](auto sure_tag) {
+      constexpr bool SURE = decltype(sure_tag)::value;
+      bool slow[BZ];
+      bool any_slow = false;
+      // Two voxels (k, k+1) share the packed-FP32 instructions of the depth and of the divide;
+      // within a voxel the (x, y) pair and the (1-l, l) weight pairs are packed.  Every single
+      // operation is still the reference's, in its order (v_pk_* are two independent fp32 ops).
 #pragma unroll
-    for (int kp = 0; kp < BZ; kp += 2) {
-      const int zla = min(zl0 + kp, g.nz_local - 1), zlb = min(zl0 + kp + 1, g.nz_local - 1);
-      const f2 c2z = {c2[2 * g.nz_local + zla], c2[2 * g.nz_local + zlb]};
-      const f2 pcz2 = v.t[2] + (c0z + (c1z + c2z));
-      // pinhole: u = fx / z * x + cx (camera.cc:133-136); orthographic: u = x (camera.cc:201-205)
-      f2 qx2 = {1.0f, 1.0f}, qy2 = {1.0f, 1.0f};
-      if (!is_ortho) {
-        qx2 = div_fast2(v.fx, pcz2);
-        qy2 = SAMEF ? qx2 : div_fast2(v.fy, pcz2);
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int k = kp + h;
-        const int zl = h ? zlb : zla;
-        const float pcz = h ? pcz2.y : pcz2.x;
-        // orthographic: only `pc.z < 0` is skipped (voxel_carver.cc:456)
-        const bool zfast = is_ortho ? !(pcz < 0.0f) : in_fast_div_range(pcz);
-        const f2 pcxy = (f2){v.t[0], v.t[1]} + ((f2){c0x, c0y} + ((f2){c1x, c1y} + (f2){c2[zl], c2[g.nz_local + zl]}));
-        const f2 uw = is_ortho ? pcxy : (f2){h ? qx2.y : qx2.x, h ? qy2.y : qy2.x} * pcxy + (f2){v.cx, v.cy};
-        const float u = uw.x, w = uw.y;
-        const bool in_tile = zfast && u >= lo_x && u <= hi_x && w >= lo_y && w <= hi_y;
-        slow[k] = !in_tile;
-        any_slow = any_slow || !in_tile;
-        const float fu = floorf(u), fw = floorf(w);
-        const float lu = u - fu, lv = w - fw;
-        const f2 P = {1.0f - lu, lu}, Q = {1.0f - lv, lv};
-        // any index is harmless when !in_tile (the sample is discarded); keep it inside the tile
-        const unsigned idx = min((unsigned)((int)__builtin_fmaf(fw, pitchf, fu) + base), (unsigned)(TQ - 1));
-        const float4 q = tile[idx];
-        const f2 ab = (P * Q.x) * (f2){q.x, q.y};   // ((1-lu)(1-lv)) s00 , (lu (1-lv)) s10
-        const f2 cd = (P * Q.y) * (f2){q.z, q.w};   // ((1-lu) lv) s01   , (lu lv) s11
-        float dist = ((ab.x + ab.y) + cd.x) + cd.y;
-        if (is_nn) {
-          // SdfInterpolationNn (voxel_carver.cc:16-38): round half away from zero == floor + (frac >= .5)
-          // for the non-negative in-ROI coordinates; the quad already holds the ROI-clamped neighbours
-          const float top = lu >= 0.5f ? q.y : q.x, bot = lu >= 0.5f ? q.w : q.z;
-          dist = lv >= 0.5f ? bot : top;
+      for (int kp = 0; kp < BZ; kp += 2) {
+        const int zla = min(zl0 + kp, g.nz_local - 1), zlb = min(zl0 + kp + 1, g.nz_local - 1);
+        const f2 c2z = {c2[2 * g.nz_local + zla], c2[2 * g.nz_local + zlb]};
+        const f2 pcz2 = v.t[2] + (c0z + (c1z + c2z));
+        // pinhole: u = fx / z * x + cx (camera.cc:133-136); orthographic: u = x (camera.cc:201-205)
+        f2 qx2 = {1.0f, 1.0f}, qy2 = {1.0f, 1.0f};
+        if (!is_ortho) {
+          qx2 = div_fast2(v.fx, pcz2);
+          qy2 = SAMEF ? qx2 : div_fast2(v.fy, pcz2);
         }
-        bool ok = in_tile;
-        if (TRUNC) ok = ok && !(dist < -1.0f);
-        if (CHECKMAX) ok = ok && !(n[k] > g.max_update_num);
-        apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]);
-      }
-    }
-    if (any_slow) {
 #pragma unroll
-      for (int k = 0; k < BZ; ++k) {
-        if (slow[k]) {
-          const int zl = min(zl0 + k, g.nz_local - 1);
-          float dist = 0.0f;
-          bool ok = sample_generic(&v, mode, px, py, g.pz[g.z0 + zl], &dist);
+        for (int h = 0; h < 2; ++h) {
+          const int k = kp + h;
+          const int zl = h ? zlb : zla;
+          const float pcz = h ? pcz2.y : pcz2.x;
+          const f2 pcxy = (f2){v.t[0], v.t[1]} + ((f2){c0x, c0y} + ((f2){c1x, c1y} + (f2){c2[zl], c2[g.nz_local + zl]}));
+          const f2 uw = is_ortho ? pcxy : (f2){h ? qx2.y : qx2.x, h ? qy2.y : qy2.x} * pcxy + (f2){v.cx, v.cy};
+          const float u = uw.x, w = uw.y;
+          bool in_tile = true;
+          if (!SURE) {
+            // orthographic: only `pc.z < 0` is skipped (voxel_carver.cc:456)
+            const bool zfast = is_ortho ? !(pcz < 0.0f) : in_fast_div_range(pcz);
+            in_tile = zfast && u >= lo_x && u <= hi_x && w >= lo_y && w <= hi_y;
+            slow[k] = !in_tile;
+            any_slow = any_slow || !in_tile;
+          }
+          const float fu = floorf(u), fw = floorf(w);
+          const float lu = u - fu, lv = w - fw;
+          const f2 P = {1.0f - lu, lu}, Q = {1.0f - lv, lv};
+          // any index is harmless when !in_tile (the sample is discarded); keep it inside the tile
+          unsigned idx = (unsigned)((int)__builtin_fmaf(fw, pitchf, fu) + base);
+          if (!SURE) idx = min(idx, (unsigned)(TQ - 1));
+          const float4 q = tile[idx];
+          const f2 ab = (P * Q.x) * (f2){q.x, q.y};   // ((1-lu)(1-lv)) s00 , (lu (1-lv)) s10
+          const f2 cd = (P * Q.y) * (f2){q.z, q.w};   // ((1-lu) lv) s01   , (lu lv) s11
+          float dist = ((ab.x + ab.y) + cd.x) + cd.y;
+          if (is_nn) {
+            // SdfInterpolationNn (voxel_carver.cc:16-38): round half away from zero == floor + (frac >= .5)
+            // for the non-negative in-ROI coordinates; the quad already holds the ROI-clamped neighbours
+            const float top = lu >= 0.5f ? q.y : q.x, bot = lu >= 0.5f ? q.w : q.z;
+            dist = lv >= 0.5f ? bot : top;
+          }
+          bool ok = in_tile;
+          if (TRUNC) ok = ok && !(dist < -1.0f);
           if (CHECKMAX) ok = ok && !(n[k] > g.max_update_num);
           apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]);
         }
       }
-    }
+      if (!SURE && any_slow) {
+#pragma unroll
+        for (int k = 0; k < BZ; ++k) {
+          if (slow[k]) {
+            const int zl = min(zl0 + k, g.nz_local - 1);
+            float dist = 0.0f;
+            bool ok = sample_generic(&v, mode, px, py, g.pz[g.z0 + zl], &dist);
+            if (CHECKMAX) ok = ok && !(n[k] > g.max_update_num);
+            apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]);
+          }
+        }
+      }
+    };
+    if (!GEN && __builtin_amdgcn_readfirstlane(tinfo[vi].sure) != 0) carve_view(std::true_type{});
+    else carve_view(std::false_type{});
 
     // state moved: some of the remaining views may have become droppable (min(sdf) only grows)
     if (want_bound && UPDATE == VCY_UPDATE_MAX) {
