@@ -42,15 +42,15 @@ constexpr int kMaxFusedViews = 32;
 constexpr int kTileSmall = 128;          // quads per wave tile (2 KB): <= 2 per lane, prefetched in registers
 constexpr int kTileBig = 512;            // 8 KB per wave: footprints up to ~1.4 px per voxel, filled in place
 
-constexpr int kWmaxLevels = 5;           // window sizes 1, 2, 4, 8, 16
+constexpr int kWmaxPlanes = 2;           // window sizes 4 and 8
 
 struct FusedView {
   ViewParams v;
-  // Window maxima of the SDF image (built per launch by wmax_* below), or null:
-  //   wmax[L * plane + y * width + x] = max of g over [x, x + 2^L) x [y, y + 2^L) clipped to the image,
-  //   g = the SDF value, or +inf where it is NaN / infinite.
-  // The maximum over any pw x ph rectangle is then the maximum of ceil(pw/k) * ceil(ph/k) entries
-  // of the level k = 2^L <= min(pw, ph) (windows placed inside the rectangle, overlapping at the far
+  // Window maxima of the SDF image (built per launch by wmax_k4 / wmax_k8 below), or null:
+  //   wmax[p * plane + y * width + x] = max of g over [x, x + k) x [y, y + k) clipped to the image,
+  //   k = 4 (p = 0) or 8 (p = 1), g = the SDF value, or +inf where it is NaN / infinite.
+  // The maximum over any pw x ph rectangle with min(pw, ph) >= k is then the maximum of
+  // ceil(pw/k) * ceil(ph/k) entries (windows placed inside the rectangle, overlapping at the far
   // edges): the prologue bounds a footprint with a handful of loads instead of scanning it.
   const float* wmax;
   int wmax_plane;
@@ -229,32 +229,82 @@ __device__ __forceinline__ void tile_fill(const ViewParams& v, const TileInfo& t
   }
 }
 
-// Level 0 of the window maxima: the image with non-finite values replaced by +inf (a footprint
-// holding one gives no bound: 0 * inf = NaN samples).  blockIdx.y = view.
-__global__ __launch_bounds__(256) void wmax_level0_kernel(const FusedView* __restrict__ views) {
-  const FusedView& fv = views[blockIdx.y];
-  const int npx = fv.v.width * fv.v.height;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (fv.wmax == nullptr || i >= npx) return;
-  const float t = fv.v.sdf[i];
-  float* out = const_cast<float*>(fv.wmax);
-  out[i] = (fabsf(t) <= 3.402823466e+38f) ? t : INFINITY;
+// ---- window maxima (FusedView::wmax) --------------------------------------------------------
+// Each thread produces four consecutive pixels of a row; blockIdx.y = view.  Rows are read as float4
+// when the image allows it (width % 4 == 0, 16-byte aligned base), element-wise otherwise.  Pixels
+// beyond the image border count as -inf, i.e. windows are clipped to the image.
+
+// a[0..7] = row[x0 .. x0 + 7] (x0 % 4 == 0, x0 < w); row == nullptr: a row below the image
+__device__ __forceinline__ void wmax_load8(const float* __restrict__ row, int x0, int w, bool vec, float a[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = -INFINITY;
+  if (row == nullptr) return;
+  if (vec) {
+    const float4 lo = *(const float4*)(row + x0);
+    a[0] = lo.x, a[1] = lo.y, a[2] = lo.z, a[3] = lo.w;
+    if (x0 + 4 < w) {
+      const float4 hi = *(const float4*)(row + x0 + 4);
+      a[4] = hi.x, a[5] = hi.y, a[6] = hi.z, a[7] = hi.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (x0 + j < w) a[j] = row[x0 + j];
+  }
 }
 
-// Level L+1 from level L (k = 2^L): the 2k window is the union of four k windows; windows are clipped
-// at the image border, where the neighbour k window degenerates to one inside the clipped 2k window.
-__global__ __launch_bounds__(256) void wmax_next_kernel(const FusedView* __restrict__ views, int level) {
+__device__ __forceinline__ void wmax_store4(float* __restrict__ row, int x0, int w, bool vec, const float o[4]) {
+  if (vec) {
+    *(float4*)(row + x0) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (x0 + j < w) row[x0 + j] = o[j];
+  }
+}
+
+// Plane 0: maxima of 4 x 4 windows of the image, non-finite pixels counted as +inf (a footprint
+// holding one gives no bound: 0 * inf = NaN samples).
+__global__ __launch_bounds__(256) void wmax_k4_kernel(const FusedView* __restrict__ views) {
   const FusedView& fv = views[blockIdx.y];
-  const int w = fv.v.width, h = fv.v.height;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (fv.wmax == nullptr || i >= w * h) return;
-  const int y = i / w, x = i - y * w;
-  const int k = 1 << level;
-  const int x1 = min(x + k, w - 1), y1 = min(y + k, h - 1);
-  const float* in = fv.wmax + (size_t)level * fv.wmax_plane;
-  float* out = const_cast<float*>(fv.wmax) + (size_t)(level + 1) * fv.wmax_plane;
-  const float a = in[y * w + x], b = in[y * w + x1], c = in[y1 * w + x], d = in[y1 * w + x1];
-  out[i] = fmaxf(fmaxf(a, b), fmaxf(c, d));
+  const int w = fv.v.width, h = fv.v.height, wq = (w + 3) >> 2;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (fv.wmax == nullptr || t >= wq * h) return;
+  const int y = t / wq, x0 = (t - y * wq) << 2;
+  const float* img = fv.v.sdf;
+  const bool vec = (w & 3) == 0 && (((uintptr_t)img | (uintptr_t)fv.wmax) & 15) == 0;
+  float o[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float a[8];
+    wmax_load8(y + r < h ? img + (size_t)(y + r) * w : nullptr, x0, w, vec, a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)  // NaN, +inf, -inf -> +inf; the -inf padding beyond the border stays
+      if (x0 + j < w && y + r < h) a[j] = (fabsf(a[j]) <= 3.402823466e+38f) ? a[j] : INFINITY;
+    float p[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) p[j] = fmaxf(a[j], a[j + 1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], fmaxf(p[j], p[j + 2]));
+  }
+  wmax_store4(const_cast<float*>(fv.wmax) + (size_t)y * w, x0, w, vec, o);
+}
+
+// Plane 1: maxima of 8 x 8 windows = the four 4 x 4 windows at offsets 0 / 4 of plane 0.
+__global__ __launch_bounds__(256) void wmax_k8_kernel(const FusedView* __restrict__ views) {
+  const FusedView& fv = views[blockIdx.y];
+  const int w = fv.v.width, h = fv.v.height, wq = (w + 3) >> 2;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (fv.wmax == nullptr || t >= wq * h) return;
+  const int y = t / wq, x0 = (t - y * wq) << 2;
+  const float* in = fv.wmax;
+  const bool vec = (w & 3) == 0 && ((uintptr_t)in & 15) == 0;
+  float a[8], b[8], o[4];
+  wmax_load8(in + (size_t)y * w, x0, w, vec, a);
+  wmax_load8(y + 4 < h ? in + (size_t)(y + 4) * w : nullptr, x0, w, vec, b);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = fmaxf(fmaxf(a[j], a[j + 4]), fmaxf(b[j], b[j + 4]));
+  wmax_store4(const_cast<float*>(fv.wmax) + (size_t)fv.wmax_plane + (size_t)y * w, x0, w, vec, o);
 }
 
 // Prologue of the fused kernel, out of line so that its registers do not add to the main loop's:
@@ -379,17 +429,17 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
           float m = -INFINITY;
           int has_nan = 0;
           gfloat_ptr wm = (gfloat_ptr)views[vi].wmax;
-          if (wm != nullptr) {
-            // window maxima: level k = 2^L <= min(pw, ph), nxw x nyw windows inside the rectangle
-            const int L = min(kWmaxLevels - 1, 31 - __clz(min(pw, ph)));
+          if (wm != nullptr && min(pw, ph) >= 4) {
+            // window maxima: k = 8 or 4 <= min(pw, ph), nxw x nyw windows inside the rectangle
+            const int L = min(pw, ph) >= 8 ? 3 : 2;
             const int k = 1 << L;
             const int nxw = (pw + k - 1) >> L, nyw = (ph + k - 1) >> L;
-            gfloat_ptr lvl = wm + (size_t)L * (size_t)views[vi].wmax_plane;
+            gfloat_ptr lvl = wm + (L == 3 ? (size_t)views[vi].wmax_plane : (size_t)0);
             for (int bq = 0; bq < nyw; ++bq) {
               gfloat_ptr row = lvl + (unsigned)v.width * (unsigned)(ty0 + min(bq << L, ph - k));
               for (int aq = 0; aq < nxw; ++aq) m = fmaxf(m, row[tx0 + min(aq << L, pw - k)]);
             }
-          } else {  // no planes (out of memory for them): scan the rectangle
+          } else {  // thin rectangle, or no planes (out of memory for them): scan it
             gfloat_ptr img = (gfloat_ptr)v.sdf;
             for (int j = 0; j < ph; ++j) {
               gfloat_ptr row = img + ((unsigned)v.width * (unsigned)(ty0 + j) + (unsigned)tx0);
@@ -746,10 +796,10 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   // Window-maximum planes for the view-dropping bounds (kMax or truncation, see the kernel).  Without
   // the memory for them the kernel scans the footprints instead; results are the same either way.
   const bool need_bound = c->use_cull && (u.voxel_update == VCY_UPDATE_MAX || u.use_truncation);
-  int max_px = 0;
+  int max_px = 0, max_quads = 0;  // per view: pixels, and threads of the window-maximum kernels
   if (need_bound) {
     size_t total = 0;
-    for (int vi = 0; vi < n_views; ++vi) total += (size_t)kWmaxLevels * vp[vi].width * vp[vi].height;
+    for (int vi = 0; vi < n_views; ++vi) total += ((size_t)kWmaxPlanes * vp[vi].width * vp[vi].height + 3) & ~(size_t)3;
     if (c->wmax_bytes < total * sizeof(float)) {
       VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
       if (c->d_wmax) (void)hipFree(c->d_wmax);
@@ -764,8 +814,9 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
         const int npx = vp[vi].width * vp[vi].height;
         fv[vi].wmax = c->d_wmax + off;
         fv[vi].wmax_plane = npx;
-        off += (size_t)kWmaxLevels * npx;
+        off += ((size_t)kWmaxPlanes * npx + 3) & ~(size_t)3;  // every view 16-byte aligned
         max_px = std::max(max_px, npx);
+        max_quads = std::max(max_quads, ((vp[vi].width + 3) / 4) * vp[vi].height);
       }
     }
   }
@@ -787,10 +838,9 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   }
 
   if (max_px > 0) {  // the images may have changed since the last call: rebuild every time
-    const dim3 wgrid((unsigned)((max_px + 255) / 256), (unsigned)n_views);
-    hipLaunchKernelGGL(wmax_level0_kernel, wgrid, dim3(256), 0, c->stream, d_views);
-    for (int L = 0; L + 1 < kWmaxLevels; ++L)
-      hipLaunchKernelGGL(wmax_next_kernel, wgrid, dim3(256), 0, c->stream, d_views, L);
+    const dim3 wgrid((unsigned)((max_quads + 255) / 256), (unsigned)n_views);
+    hipLaunchKernelGGL(wmax_k4_kernel, wgrid, dim3(256), 0, c->stream, d_views);
+    hipLaunchKernelGGL(wmax_k8_kernel, wgrid, dim3(256), 0, c->stream, d_views);
   }
   const int nbx = (c->nx + BX - 1) / BX, nby = (c->ny + BY - 1) / BY, nbz = (nzl + BZ - 1) / BZ;
   const int64_t nblocks = (int64_t)nbx * nby * nbz;
