@@ -165,33 +165,33 @@ struct QuadRegs {
   float4 q0, q1;
 };
 
-// Issues the global loads of this lane's (up to two) quads of view vi's tile.
+// Issues the global loads of this lane's (up to two) quads of view vi's tile.  Lanes without a quad
+// keep whatever the registers held: tile entries >= nq are never read.  Offsets are 32-bit (images
+// are at most 8192 x 8192, fused_eligible) on a wave-uniform base, 24-bit multiplies (full rate).
 __device__ __forceinline__ void tile_prefetch(const ViewParams& v, const TileInfo& ti, int lane,
                                               QuadRegs* r) {
   const int nq = __builtin_amdgcn_readfirstlane(ti.nq);
-  r->q0 = r->q1 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (nq == 0) return;
   const int tw = __builtin_amdgcn_readfirstlane(ti.tw);
   const int tx0 = __builtin_amdgcn_readfirstlane(ti.tx0);
   const int ty0 = __builtin_amdgcn_readfirstlane(ti.ty0);
   const float inv_tw = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ti.inv_tw)));
   gfloat_ptr img = (gfloat_ptr)v.sdf;
+  const unsigned width = (unsigned)v.width;
   if (lane < nq) {
-    const int j = div_small(lane, inv_tw), i = lane - j * tw;
-    const int xx = tx0 + i, yy = ty0 + j;
-    const int xx1 = min(xx + 1, v.roi_max_xi), yy1 = min(yy + 1, v.roi_max_yi);
-    gfloat_ptr r0 = img + (int64_t)v.width * yy;
-    gfloat_ptr r1 = img + (int64_t)v.width * yy1;
-    r->q0 = make_float4(r0[xx], r0[xx1], r1[xx], r1[xx1]);
+    const int j = div_small(lane, inv_tw), i = lane - __mul24(j, tw);
+    const unsigned xx = tx0 + i, yy = ty0 + j;
+    const unsigned xx1 = min((int)xx + 1, v.roi_max_xi), yy1 = min((int)yy + 1, v.roi_max_yi);
+    const unsigned r0 = __umul24(width, yy), r1 = __umul24(width, yy1);
+    r->q0 = make_float4(img[r0 + xx], img[r0 + xx1], img[r1 + xx], img[r1 + xx1]);
   }
   if (nq > 64 && lane + 64 < nq) {
     const int q = lane + 64;
-    const int j = div_small(q, inv_tw), i = q - j * tw;
-    const int xx = tx0 + i, yy = ty0 + j;
-    const int xx1 = min(xx + 1, v.roi_max_xi), yy1 = min(yy + 1, v.roi_max_yi);
-    gfloat_ptr r0 = img + (int64_t)v.width * yy;
-    gfloat_ptr r1 = img + (int64_t)v.width * yy1;
-    r->q1 = make_float4(r0[xx], r0[xx1], r1[xx], r1[xx1]);
+    const int j = div_small(q, inv_tw), i = q - __mul24(j, tw);
+    const unsigned xx = tx0 + i, yy = ty0 + j;
+    const unsigned xx1 = min((int)xx + 1, v.roi_max_xi), yy1 = min((int)yy + 1, v.roi_max_yi);
+    const unsigned r0 = __umul24(width, yy), r1 = __umul24(width, yy1);
+    r->q1 = make_float4(img[r0 + xx], img[r0 + xx1], img[r1 + xx], img[r1 + xx1]);
   }
 }
 
