@@ -54,6 +54,10 @@ struct FusedView {
   // edges): the prologue bounds a footprint with a handful of loads instead of scanning it.
   const float* wmax;
   int wmax_plane;
+  // The planes are only filled inside wrect = {x0, y0, x1, y1} (x0, x1 multiples of 4), the image-space
+  // bounding box of this context's slab plus a border wider than anything a footprint lookup reaches;
+  // a z-slab of a sharded grid often sees a narrow band of the image.
+  int wrect[4];
 };
 // c2_all[view][3][nz_local] = R[i][2] * pz[z]  (one fp32 multiply per entry, done on the host)
 
@@ -267,10 +271,10 @@ __device__ __forceinline__ void wmax_store4(float* __restrict__ row, int x0, int
 // holding one gives no bound: 0 * inf = NaN samples).
 __global__ __launch_bounds__(256) void wmax_k4_kernel(const FusedView* __restrict__ views) {
   const FusedView& fv = views[blockIdx.y];
-  const int w = fv.v.width, h = fv.v.height, wq = (w + 3) >> 2;
+  const int w = fv.v.width, h = fv.v.height, wq = (fv.wrect[2] - fv.wrect[0]) >> 2;
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (fv.wmax == nullptr || t >= wq * h) return;
-  const int y = t / wq, x0 = (t - y * wq) << 2;
+  if (fv.wmax == nullptr || wq <= 0 || t >= wq * (fv.wrect[3] - fv.wrect[1])) return;
+  const int yr = t / wq, y = fv.wrect[1] + yr, x0 = fv.wrect[0] + ((t - yr * wq) << 2);
   const float* img = fv.v.sdf;
   const bool vec = (w & 3) == 0 && (((uintptr_t)img | (uintptr_t)fv.wmax) & 15) == 0;
   float o[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -293,10 +297,10 @@ __global__ __launch_bounds__(256) void wmax_k4_kernel(const FusedView* __restric
 // Plane 1: maxima of 8 x 8 windows = the four 4 x 4 windows at offsets 0 / 4 of plane 0.
 __global__ __launch_bounds__(256) void wmax_k8_kernel(const FusedView* __restrict__ views) {
   const FusedView& fv = views[blockIdx.y];
-  const int w = fv.v.width, h = fv.v.height, wq = (w + 3) >> 2;
+  const int w = fv.v.width, h = fv.v.height, wq = (fv.wrect[2] - fv.wrect[0]) >> 2;
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (fv.wmax == nullptr || t >= wq * h) return;
-  const int y = t / wq, x0 = (t - y * wq) << 2;
+  if (fv.wmax == nullptr || wq <= 0 || t >= wq * (fv.wrect[3] - fv.wrect[1])) return;
+  const int yr = t / wq, y = fv.wrect[1] + yr, x0 = fv.wrect[0] + ((t - yr * wq) << 2);
   const float* in = fv.wmax;
   const bool vec = (w & 3) == 0 && ((uintptr_t)in & 15) == 0;
   float a[8], b[8], o[4];
@@ -816,7 +820,43 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
         fv[vi].wmax_plane = npx;
         off += ((size_t)kWmaxPlanes * npx + 3) & ~(size_t)3;  // every view 16-byte aligned
         max_px = std::max(max_px, npx);
-        max_quads = std::max(max_quads, ((vp[vi].width + 3) / 4) * vp[vi].height);
+        // image-space bounding box of the slab (double precision, 16 px border; the footprints the
+        // kernel looks up lie within a fraction of a pixel of the exact hull, their windows inside them)
+        const int w = vp[vi].width, h = vp[vi].height;
+        int rx0 = 0, ry0 = 0, rx1 = w, ry1 = h;
+        {
+          const double X[2] = {c->h_px_min, c->h_px_max}, Y[2] = {c->h_py_min, c->h_py_max};
+          const double Z[2] = {c->h_pz[c->z0], c->h_pz[c->z1 - 1]};
+          double umin = 1e300, umax = -1e300, wmin = 1e300, wmax = -1e300;
+          bool whole = false;
+          for (int cr = 0; cr < 8; ++cr) {
+            const double x = X[cr & 1], y = Y[(cr >> 1) & 1], z = Z[cr >> 2];
+            double pc[3];
+            for (int i = 0; i < 3; ++i)
+              pc[i] = (double)vp[vi].t[i] + ((double)vp[vi].r[i][0] * x + (double)vp[vi].r[i][1] * y + (double)vp[vi].r[i][2] * z);
+            double u = pc[0], ww = pc[1];
+            if (!c->fused_ortho) {
+              if (!(pc[2] > 1e-30)) { whole = true; break; }
+              u = (double)vp[vi].fx / pc[2] * pc[0] + vp[vi].cx;
+              ww = (double)vp[vi].fy / pc[2] * pc[1] + vp[vi].cy;
+            }
+            if (!(std::fabs(u) < 1e9) || !(std::fabs(ww) < 1e9)) { whole = true; break; }
+            umin = std::min(umin, u), umax = std::max(umax, u);
+            wmin = std::min(wmin, ww), wmax = std::max(wmax, ww);
+          }
+          if (!whole) {
+            rx0 = std::max(0, (int)std::floor(umin) - 16) & ~3;
+            ry0 = std::max(0, (int)std::floor(wmin) - 16);
+            rx1 = std::min((w + 3) & ~3, ((int)std::floor(umax) + 16 + 4) & ~3);
+            ry1 = std::min(h, (int)std::floor(wmax) + 16 + 1);
+            if (rx1 < rx0) rx1 = rx0;
+            if (ry1 < ry0) ry1 = ry0;
+          } else {
+            rx1 = (w + 3) & ~3;
+          }
+        }
+        fv[vi].wrect[0] = rx0, fv[vi].wrect[1] = ry0, fv[vi].wrect[2] = rx1, fv[vi].wrect[3] = ry1;
+        max_quads = std::max(max_quads, ((rx1 - rx0) / 4) * (ry1 - ry0));
       }
     }
   }
@@ -837,7 +877,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     c->fused_cache_valid = true;
   }
 
-  if (max_px > 0) {  // the images may have changed since the last call: rebuild every time
+  if (max_quads > 0) {  // the images may have changed since the last call: rebuild every time
     const dim3 wgrid((unsigned)((max_quads + 255) / 256), (unsigned)n_views);
     hipLaunchKernelGGL(wmax_k4_kernel, wgrid, dim3(256), 0, c->stream, d_views);
     hipLaunchKernelGGL(wmax_k8_kernel, wgrid, dim3(256), 0, c->stream, d_views);
