@@ -91,6 +91,18 @@ def cpu_baseline(args, views, sdfs, budget_s):
         n_done += 1
         if t_total > budget_s:
             break
+    # the same loop on ONE thread (SURVEY 8d asks for both), on a 256^3 version of the scene, one view
+    single = None
+    try:
+        lib.orc_set_num_threads(1)
+        opt1 = synth.sphere_option(args.grid, uo)
+        opt1.resolution = float(args.grid) / min(args.grid, 256)
+        g1 = O.OracleGrid(opt1)
+        ms1 = g1.carve(views[0], sdfs[0])
+        single = round(g1.n / (ms1 / 1e3) / 1e6, 2)
+        del g1
+    finally:
+        lib.orc_set_num_threads(usable)
     t0 = time.time()
     mesh = g.marching_cubes(0.0, True)
     mc_s = mesh["ms"] / 1e3
@@ -101,6 +113,7 @@ def cpu_baseline(args, views, sdfs, budget_s):
         "unit": "Mvoxel*views/s",
         "cores": int(threads),
         "kind": "port",
+        "single_thread_value": single,
         "sample": "oracle (OpenMP over z, %d threads = usable host cores of %d visible), %d^3 grid over the same "
                   "scene, %d of %d views at %dx%d; times the Carve main loop only (reference "
                   "voxel_carver.cc:435,492)"
