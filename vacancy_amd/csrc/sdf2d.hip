@@ -135,30 +135,6 @@ void host_make_sdf(const uint8_t* mask, int w, int h, const int32_t* rmin, const
 
 namespace {
 
-__device__ __forceinline__ int wave_excl_scan_max(int v, int identity) {
-  const int lane = threadIdx.x & 63;
-  int incl = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(incl, d, 64);
-    if (lane >= d) incl = max(incl, t);
-  }
-  const int prev = __shfl_up(incl, 1, 64);
-  return lane == 0 ? identity : prev;
-}
-
-__device__ __forceinline__ int wave_excl_scan_min_from_right(int v, int identity) {
-  const int lane = threadIdx.x & 63;
-  int incl = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_down(incl, d, 64);
-    if (lane + d < 64) incl = min(incl, t);
-  }
-  const int next = __shfl_down(incl, 1, 64);
-  return lane == 63 ? identity : next;
-}
-
 constexpr int kFar = 1 << 28;
 constexpr int kMaxSdfJobs = 32;
 // a distance measured against the 'no seed' sentinel -> kInf
@@ -178,64 +154,114 @@ struct SdfJobs {
   SdfJob j[kMaxSdfJobs];
 };
 
+// Row pass: one wave per row, lane = pixel inside a 64-pixel chunk (coalesced).  The two seed sets of
+// a chunk are two ballots; the nearest seed on one side of a pixel is the highest (lowest) set bit at
+// or below (above) its lane, or else the carry from the chunks already swept (wave-uniform).
 __global__ __launch_bounds__(256) void sdf_rows_kernel(SdfJobs jobs) {
   const SdfJob& jb = jobs.j[blockIdx.y];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *jb.absmax = 0u;  // reduced into by sdf_sign_kernel (a later launch)
   const int row = jb.ry0 + blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row > jb.ry1) return;
   const int lane = threadIdx.x & 63;
   const int rx0 = jb.rx0, rx1 = jb.rx1;
-  const int rw = rx1 - rx0 + 1;
-  const int seg = (rw + 63) / 64;
-  const int xs = min(rx0 + lane * seg, rx1 + 1), xe = min(xs + seg, rx1 + 1);
-  const uint8_t* m = jb.mask + (int64_t)row * jb.W;
-  int* gi = jb.g_in + (int64_t)row * jb.W;
-  int* go = jb.g_out + (int64_t)row * jb.W;
-  // nearest seed to the left
-  int last_n = -kFar, last_s = -kFar;  // last non-255 / last 255 inside my segment
-  for (int x = xs; x < xe; ++x) {
-    if (m[x] != 255) last_n = x; else last_s = x;
-  }
-  int ln = wave_excl_scan_max(last_n, -kFar), ls = wave_excl_scan_max(last_s, -kFar);
-  for (int x = xs; x < xe; ++x) {
-    if (m[x] != 255) ln = x; else ls = x;
-    gi[x] = far_to_inf(x - ln);
-    go[x] = far_to_inf(x - ls);
+  const uint8_t* __restrict__ m = jb.mask + (int64_t)row * jb.W;
+  int* __restrict__ gi = jb.g_in + (int64_t)row * jb.W;
+  int* __restrict__ go = jb.g_out + (int64_t)row * jb.W;
+  const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);  // bits 0..lane
+  const unsigned long long ge = ~0ull << lane;                                   // bits lane..63
+  // nearest seed to the left (itself included)
+  int carry_n = -kFar, carry_s = -kFar;  // last non-255 / last 255 pixel of the chunks swept so far
+  for (int x0 = rx0; x0 <= rx1; x0 += 64) {
+    const int x = x0 + lane;
+    const bool valid = x <= rx1;
+    const int mv = valid ? (int)m[x] : 0;
+    const unsigned long long bn = __ballot(valid && mv != 255), bs = __ballot(valid && mv == 255);
+    const unsigned long long tn = bn & le, ts = bs & le;
+    const int ln = tn ? x0 + 63 - __clzll((long long)tn) : carry_n;
+    const int ls = ts ? x0 + 63 - __clzll((long long)ts) : carry_s;
+    if (valid) {
+      gi[x] = far_to_inf(x - ln);
+      go[x] = far_to_inf(x - ls);
+    }
+    if (bn) carry_n = x0 + 63 - __clzll((long long)bn);
+    if (bs) carry_s = x0 + 63 - __clzll((long long)bs);
   }
   // nearest seed to the right
-  int next_n = kFar, next_s = kFar;
-  for (int x = xe - 1; x >= xs; --x) {
-    if (m[x] != 255) next_n = x; else next_s = x;
-  }
-  int rn = wave_excl_scan_min_from_right(next_n, kFar), rs = wave_excl_scan_min_from_right(next_s, kFar);
-  for (int x = xe - 1; x >= xs; --x) {
-    if (m[x] != 255) rn = x; else rs = x;
-    gi[x] = min(gi[x], far_to_inf(rn - x));
-    go[x] = min(go[x], far_to_inf(rs - x));
+  carry_n = kFar, carry_s = kFar;
+  const int last = rx0 + ((rx1 - rx0) & ~63);
+  for (int x0 = last; x0 >= rx0; x0 -= 64) {
+    const int x = x0 + lane;
+    const bool valid = x <= rx1;
+    const int mv = valid ? (int)m[x] : 0;
+    const unsigned long long bn = __ballot(valid && mv != 255), bs = __ballot(valid && mv == 255);
+    const unsigned long long tn = bn & ge, ts = bs & ge;
+    const int rn = tn ? x0 + __ffsll((long long)tn) - 1 : carry_n;
+    const int rs = ts ? x0 + __ffsll((long long)ts) - 1 : carry_s;
+    if (valid) {
+      gi[x] = min(gi[x], far_to_inf(rn - x));
+      go[x] = min(go[x], far_to_inf(rs - x));
+    }
+    if (bn) carry_n = x0 + __ffsll((long long)bn) - 1;
+    if (bs) carry_s = x0 + __ffsll((long long)bs) - 1;
   }
 }
 
+// Column pass: one thread per column (coalesced across x).  The recurrence r = min(g, r + 1) is cheap;
+// the loads are what takes time, so eight rows are fetched before the chain touches them.
 __global__ __launch_bounds__(64) void sdf_cols_kernel(SdfJobs jobs) {
   const SdfJob& jb = jobs.j[blockIdx.y];
   const int x = jb.rx0 + blockIdx.x * 64 + threadIdx.x;
   if (x > jb.rx1) return;
-  const int W = jb.W, ry0 = jb.ry0, ry1 = jb.ry1;
-  int* __restrict__ g_in = jb.g_in;
-  int* __restrict__ g_out = jb.g_out;
+  const int64_t W = jb.W;
+  const int ry0 = jb.ry0, ry1 = jb.ry1;
+  int* __restrict__ g_in = jb.g_in + x;
+  int* __restrict__ g_out = jb.g_out + x;
+  constexpr int U = 8;
   int ri = kInf, ro = kInf;
-  for (int y = ry0; y <= ry1; ++y) {
-    const int64_t i = (int64_t)y * W + x;
-    ri = min(g_in[i], min(ri + 1, kInf));
-    ro = min(g_out[i], min(ro + 1, kInf));
-    g_in[i] = ri;
-    g_out[i] = ro;
+  int y = ry0;
+  for (; y + U - 1 <= ry1; y += U) {
+    int a[U], b[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      a[k] = g_in[(y + k) * W];
+      b[k] = g_out[(y + k) * W];
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      ri = min(a[k], min(ri + 1, kInf));
+      ro = min(b[k], min(ro + 1, kInf));
+      g_in[(y + k) * W] = ri;
+      g_out[(y + k) * W] = ro;
+    }
+  }
+  for (; y <= ry1; ++y) {
+    ri = min(g_in[y * W], min(ri + 1, kInf));
+    ro = min(g_out[y * W], min(ro + 1, kInf));
+    g_in[y * W] = ri;
+    g_out[y * W] = ro;
   }
   ri = ro = kInf;
-  for (int y = ry1; y >= ry0; --y) {
-    const int64_t i = (int64_t)y * W + x;
-    ri = min(g_in[i], min(ri + 1, kInf));
-    ro = min(g_out[i], min(ro + 1, kInf));
-    g_in[i] = ri;
-    g_out[i] = ro;
+  y = ry1;
+  for (; y - (U - 1) >= ry0; y -= U) {
+    int a[U], b[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      a[k] = g_in[(y - k) * W];
+      b[k] = g_out[(y - k) * W];
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      ri = min(a[k], min(ri + 1, kInf));
+      ro = min(b[k], min(ro + 1, kInf));
+      g_in[(y - k) * W] = ri;
+      g_out[(y - k) * W] = ro;
+    }
+  }
+  for (; y >= ry0; --y) {
+    ri = min(g_in[y * W], min(ri + 1, kInf));
+    ro = min(g_out[y * W], min(ro + 1, kInf));
+    g_in[y * W] = ri;
+    g_out[y * W] = ro;
   }
 }
 
@@ -324,7 +350,6 @@ int device_make_sdf_batch(hipStream_t stream, int n, const uint8_t* const* masks
     max_rh = std::max(max_rh, jb.ry1 - jb.ry0 + 1);
     max_rw = std::max(max_rw, jb.rx1 - jb.rx0 + 1);
     max_px = std::max<int64_t>(max_px, (int64_t)npx);
-    VCY_HIP_CHECK(hipMemsetAsync(jb.absmax, 0, sizeof(unsigned), stream));
   }
   hipLaunchKernelGGL(sdf_rows_kernel, dim3((max_rh + 3) / 4, n), dim3(256), 0, stream, jobs);
   hipLaunchKernelGGL(sdf_cols_kernel, dim3((max_rw + 63) / 64, n), dim3(64), 0, stream, jobs);

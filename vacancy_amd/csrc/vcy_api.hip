@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "vcy_internal.h"
@@ -228,6 +229,13 @@ void vcy_destroy(vcy_ctx* c) {
   (void)hipFree(c->d_mc_tables);
   (void)hipFree(c->d_mc_scratch);
   (void)hipFree(c->d_stream_pool);
+  if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+  for (int k = 0; k < 2; ++k) {
+    if (c->ev_ready[k]) (void)hipEventDestroy(c->ev_ready[k]);
+    if (c->ev_consumed[k]) (void)hipEventDestroy(c->ev_consumed[k]);
+    if (c->ev_uploaded[k]) (void)hipEventDestroy(c->ev_uploaded[k]);
+  }
   (void)hipFree(c->d_mc_out);
   (void)hipFree(c->d_mc_cells);
   (void)hipFree(c->d_fused_scratch);
@@ -699,8 +707,6 @@ int vcy_carve_batch_silhouettes(vcy_ctx* c, int n_views, const vcy_view* views,
   const size_t sz_sdf = px_al * sizeof(float), sz_mask = px_al;
   const size_t sz_scr = (device_make_sdf_scratch_bytes(1, (int)max_px) + 255) / 256 * 256;
   const size_t total = 2 * per_set * (sz_sdf + sz_mask) + per_set * sz_scr + 256;
-  hipStream_t aux = nullptr;
-  hipEvent_t ready[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
   int rc = VCY_OK;
   auto fail_hip = [&](hipError_t e, const char* what) {
     if (e != hipSuccess && rc == VCY_OK) {
@@ -717,59 +723,91 @@ int vcy_carve_batch_silhouettes(vcy_ctx* c, int n_views, const vcy_view* views,
     VCY_HIP_CHECK(hipMalloc(&c->d_stream_pool, total));
     c->stream_pool_bytes = total;
   }
-  char* pool = (char*)c->d_stream_pool;
-  fail_hip(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking), "hipStreamCreate");
-  for (int k = 0; k < 2 && rc == VCY_OK; ++k) {
-    fail_hip(hipEventCreateWithFlags(&ready[k], hipEventDisableTiming), "hipEventCreate");
-    fail_hip(hipEventCreateWithFlags(&consumed[k], hipEventDisableTiming), "hipEventCreate");
+  // page-locked staging: pageable memory would be copied through the runtime's own bounce buffer by
+  // one thread; here a few host threads fill it and the DMA engine takes it from there
+  const size_t pinned_total = 2 * (size_t)per_set * sz_mask;
+  if (c->pinned_bytes < pinned_total) {
+    if (c->aux_stream) VCY_HIP_CHECK(hipStreamSynchronize(c->aux_stream));
+    if (c->h_pinned) VCY_HIP_CHECK(hipHostFree(c->h_pinned));
+    c->h_pinned = nullptr;
+    c->pinned_bytes = 0;
+    VCY_HIP_CHECK(hipHostMalloc(&c->h_pinned, pinned_total, hipHostMallocDefault));
+    c->pinned_bytes = pinned_total;
   }
+  if (!c->aux_stream) {
+    fail_hip(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking), "hipStreamCreate");
+    for (int k = 0; k < 2 && rc == VCY_OK; ++k) {
+      fail_hip(hipEventCreateWithFlags(&c->ev_ready[k], hipEventDisableTiming), "hipEventCreate");
+      fail_hip(hipEventCreateWithFlags(&c->ev_consumed[k], hipEventDisableTiming), "hipEventCreate");
+      fail_hip(hipEventCreateWithFlags(&c->ev_uploaded[k], hipEventDisableTiming), "hipEventCreate");
+    }
+    if (rc != VCY_OK) return rc;
+  }
+  hipStream_t aux = c->aux_stream;
+  char* pool = (char*)c->d_stream_pool;
   char* scratch = pool + 2 * per_set * (sz_sdf + sz_mask);
   auto sdf_buf = [&](int set, int j) { return (float*)(pool + ((size_t)set * per_set + j) * sz_sdf); };
   auto mask_buf = [&](int set, int j) {
     return (uint8_t*)(pool + 2 * per_set * sz_sdf + ((size_t)set * per_set + j) * sz_mask);
   };
+  auto stage_buf = [&](int set, int j) { return (uint8_t*)c->h_pinned + ((size_t)set * per_set + j) * sz_mask; };
   const int n_chunks = (n_views + chunk - 1) / chunk;
   // producer for chunk ci: upload + SDF on the aux stream
   auto produce = [&](int ci) {
     const int set = ci & 1, first = ci * chunk, m = std::min(chunk, n_views - first);
-    if (ci >= 2) fail_hip(hipStreamWaitEvent(aux, consumed[set], 0), "hipStreamWaitEvent");
+    if (ci >= 2) {
+      fail_hip(hipStreamWaitEvent(aux, c->ev_consumed[set], 0), "hipStreamWaitEvent");  // device buffers free
+      fail_hip(hipEventSynchronize(c->ev_uploaded[set]), "hipEventSynchronize");        // staging free
+    }
     std::vector<const uint8_t*> mptr(m);
     std::vector<float*> optr(m);
-    for (int j = 0; j < m && rc == VCY_OK; ++j) {
-      const vcy_view& v = views[first + j];
-      const size_t npx = (size_t)v.width * v.height;
+    for (int j = 0; j < m; ++j) {
       mptr[j] = mask_buf(set, j);
       optr[j] = sdf_buf(set, j);
-      fail_hip(hipMemcpyAsync(mask_buf(set, j), masks_host[first + j], npx, hipMemcpyHostToDevice, aux),
-               "mask upload");
     }
+    // host threads: copy silhouette j into the staging buffer, then queue its DMA
+    const int n_thr = std::max(1, std::min(m, std::min(4, (int)std::thread::hardware_concurrency())));
+    std::vector<hipError_t> terr((size_t)n_thr, hipSuccess);
+    auto worker = [&](int t) {
+      (void)hipSetDevice(c->device);
+      for (int j = t; j < m; j += n_thr) {
+        const vcy_view& v = views[first + j];
+        const size_t npx = (size_t)v.width * v.height;
+        std::memcpy(stage_buf(set, j), masks_host[first + j], npx);
+        const hipError_t e = hipMemcpyAsync(mask_buf(set, j), stage_buf(set, j), npx, hipMemcpyHostToDevice, aux);
+        if (e != hipSuccess) terr[(size_t)t] = e;
+      }
+    };
+    if (rc == VCY_OK) {
+      std::vector<std::thread> pool_thr;
+      for (int t = 1; t < n_thr; ++t) pool_thr.emplace_back(worker, t);
+      worker(0);
+      for (auto& th : pool_thr) th.join();
+      for (int t = 0; t < n_thr; ++t) fail_hip(terr[(size_t)t], "mask upload");
+    }
+    fail_hip(hipEventRecord(c->ev_uploaded[set], aux), "hipEventRecord");
     if (rc == VCY_OK) {
       // MakeSignedDistanceField(...) for the whole chunk at once, reference voxel_carver.cc:405-408
       int r2 = device_make_sdf_batch(aux, m, mptr.data(), views + first, c->opt.sdf_minmax_normalize != 0,
                                      u.use_truncation != 0, u.truncation_band, scratch, sz_scr, optr.data());
       if (r2 != VCY_OK) rc = r2;
     }
-    fail_hip(hipEventRecord(ready[set], aux), "hipEventRecord");
+    fail_hip(hipEventRecord(c->ev_ready[set], aux), "hipEventRecord");
   };
   if (rc == VCY_OK) produce(0);
   for (int ci = 0; ci < n_chunks && rc == VCY_OK; ++ci) {
     const int set = ci & 1, first = ci * chunk, m = std::min(chunk, n_views - first);
     if (ci + 1 < n_chunks) produce(ci + 1);  // next chunk's SDFs build while this chunk carves
     if (rc != VCY_OK) break;
-    fail_hip(hipStreamWaitEvent(c->stream, ready[set], 0), "hipStreamWaitEvent");
+    fail_hip(hipStreamWaitEvent(c->stream, c->ev_ready[set], 0), "hipStreamWaitEvent");
     std::vector<const float*> ptrs(m);
     for (int j = 0; j < m; ++j) ptrs[j] = sdf_buf(set, j);
     int r2 = launch_carve(c, m, views + first, ptrs.data());
     if (r2 != VCY_OK) rc = r2;
-    fail_hip(hipEventRecord(consumed[set], c->stream), "hipEventRecord");
+    fail_hip(hipEventRecord(c->ev_consumed[set], c->stream), "hipEventRecord");
   }
   (void)hipStreamSynchronize(c->stream);
-  if (aux) (void)hipStreamSynchronize(aux);
-  for (int k = 0; k < 2; ++k) {
-    if (ready[k]) (void)hipEventDestroy(ready[k]);
-    if (consumed[k]) (void)hipEventDestroy(consumed[k]);
-  }
-  if (aux) (void)hipStreamDestroy(aux);
+  (void)hipStreamSynchronize(aux);
   return rc;
 }
 

@@ -79,6 +79,10 @@ struct vcy_ctx {
   std::vector<float> fused_cache_c2;
   void* d_stream_pool = nullptr;      // staging of vcy_carve_batch_silhouettes (masks, SDFs, scratch)
   size_t stream_pool_bytes = 0;
+  hipStream_t aux_stream = nullptr;   // producer stream of the streamed batch (uploads + SDF build)
+  hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr}, ev_uploaded[2] = {nullptr, nullptr};
+  void* h_pinned = nullptr;           // page-locked staging of the silhouettes, two sets
+  size_t pinned_bytes = 0;
   void* d_mc_tables = nullptr;        // marching-cubes case tables (mc_kernels.hip)
   void* d_mc_scratch = nullptr;       // bit planes, active words, offsets, per-cell info
   size_t mc_scratch_bytes = 0;
