@@ -101,6 +101,23 @@ def test_random_scene(seed):
         assert np.array_equal(dm["keys"], om["keys"]) and np.array_equal(dm["faces"], om["faces"])
         assert np.array_equal(dm["vertices"].view(np.uint32), om["vertices"].view(np.uint32))
         dev.close()
+    # the same scene as two z-slab contexts cut at a random layer (what two ranks hold): the slab
+    # states tile the oracle's grid (the window maxima of a slab only cover its image band)
+    nz = orc.dims[2]
+    if nz >= 3:
+        cut = int(rng.randint(2, nz))  # a non-first slab starts at z >= 2 (two halo slices below it)
+        parts = []
+        for z0, z1 in ((0, cut), (cut, nz)):
+            dev = vc.VoxelCarver(opt, z_range=(z0, z1))
+            assert dev.Init(), vc.last_error()
+            d = [dev.upload_sdf(s) for s in sdfs]
+            assert dev.CarveBatchDevice(views, d), vc.last_error()
+            parts.append(dev.download())
+            dev.close()
+        ds = np.concatenate([p[0] for p in parts])
+        du = np.concatenate([p[1] for p in parts])
+        assert np.array_equal(du, ou), (seed, "slabs", cut)
+        assert np.array_equal(ds.view(np.uint32), os_.view(np.uint32)), (seed, "slabs", cut)
 
 
 @pytest.mark.parametrize("seed", range(12))
