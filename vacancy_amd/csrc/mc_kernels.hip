@@ -134,7 +134,10 @@ constexpr int kWordsPerBlock = 256;
 // wave are issued before the first ballot so that a wave keeps ~3 KB in flight.
 constexpr int kBitsWordsPerWave = 8;
 
-template <typename CountT, bool ISO_F32>
+// TC_FROM_OK: the state has only ever been written by the grid fill and the carve kernels, where
+// update_num == 0 implies sdf == lowest(); then OK(corner 6) already implies TC(corner 6) and the TC
+// plane may be any superset of OK -- OK itself, without reading update_num at all (see extract_iso).
+template <typename CountT, bool ISO_F32, bool TC_FROM_OK>
 __global__ __launch_bounds__(256) void mc_bits_kernel(const float* __restrict__ sdf,
                                                       const CountT* __restrict__ cnt, int nx, int Wr,
                                                       int64_t nwords, double iso, u64* __restrict__ in,
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void mc_bits_kernel(const float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < kBitsWordsPerWave; ++k) {
       s[k] = ps[k * 64];
-      n[k] = (int)pc[k * 64];
+      n[k] = TC_FROM_OK ? 1 : (int)pc[k * 64];
     }
 #pragma unroll
     for (int k = 0; k < kBitsWordsPerWave; ++k) {
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256) void mc_bits_kernel(const float* __restrict__ 
       // is itself a float value the comparison is the same in single precision
       const u64 a = __ballot(ISO_F32 ? s[k] < (float)iso : (double)s[k] < iso);
       const u64 b = __ballot(s[k] != kInvalidSdf);
-      const u64 c = __ballot(n[k] >= 1);
+      const u64 c = TC_FROM_OK ? b : __ballot(n[k] >= 1);
       const bool mine = lane == k;
       m_in = mine ? a : m_in;
       m_ok = mine ? b : m_ok;
@@ -177,11 +180,11 @@ __global__ __launch_bounds__(256) void mc_bits_kernel(const float* __restrict__ 
       int nv = 0;
       if (live) {
         sv = sdf[row * nx + x];
-        nv = (int)cnt[row * nx + x];
+        nv = TC_FROM_OK ? 1 : (int)cnt[row * nx + x];
       }
       const u64 a = __ballot(live && (ISO_F32 ? sv < (float)iso : (double)sv < iso));
       const u64 b = __ballot(live && sv != kInvalidSdf);
-      const u64 c = __ballot(live && nv >= 1);
+      const u64 c = TC_FROM_OK ? b : __ballot(live && nv >= 1);
       if (lane == k) {
         m_in = a;
         m_ok = b;
@@ -679,15 +682,40 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   } while (0)
 
   MC_TRY(hipEventRecord(c->ev_begin, s));
-  const unsigned bits_blocks = (unsigned)((vox_words + 4 * kBitsWordsPerWave - 1) / (4 * kBitsWordsPerWave));
   const bool iso_f32 = (double)(float)iso == iso;
-#define VCY_BITS(CT, F32)                                                                                  \
-  hipLaunchKernelGGL((mc_bits_kernel<CT, F32>), dim3(bits_blocks), dim3(256), 0, s, c->d_sdf,           \
-                     (const CT*)c->d_cnt, c->nx, p.Wr, vox_words, iso, d_in, d_ok, d_tc)
-  if (c->cnt_bytes == 1) { if (iso_f32) VCY_BITS(uint8_t, true); else VCY_BITS(uint8_t, false); }
-  else if (c->cnt_bytes == 2) { if (iso_f32) VCY_BITS(uint16_t, true); else VCY_BITS(uint16_t, false); }
-  else { if (iso_f32) VCY_BITS(uint32_t, true); else VCY_BITS(uint32_t, false); }
+  // the halo slices come from another context: their update_num is read; the owned slices need it
+  // only if the state was ever set from outside (vcy_upload), see mc_bits_kernel
+  auto launch_bits = [&](int64_t word0, int64_t nw, bool tc_from_ok) {
+    if (nw <= 0) return;
+    const unsigned blocks = (unsigned)((nw + 4 * kBitsWordsPerWave - 1) / (4 * kBitsWordsPerWave));
+    const float* sdf0 = c->d_sdf + word0 * 64;  // whole rows: only used when nx == Wr * 64 or word0 == 0
+    const char* cnt0 = (const char*)c->d_cnt + word0 * 64 * c->cnt_bytes;
+#define VCY_BITS(CT, F32, TCOK)                                                                          \
+  hipLaunchKernelGGL((mc_bits_kernel<CT, F32, TCOK>), dim3(blocks), dim3(256), 0, s, sdf0, (const CT*)cnt0, \
+                     c->nx, p.Wr, nw, iso, d_in + word0, d_ok + word0, d_tc + word0)
+#define VCY_BITS_F(CT, TCOK)                                                    \
+  do {                                                                          \
+    if (iso_f32) VCY_BITS(CT, true, TCOK); else VCY_BITS(CT, false, TCOK);      \
+  } while (0)
+    if (tc_from_ok) {
+      if (c->cnt_bytes == 1) VCY_BITS_F(uint8_t, true);
+      else if (c->cnt_bytes == 2) VCY_BITS_F(uint16_t, true);
+      else VCY_BITS_F(uint32_t, true);
+    } else {
+      if (c->cnt_bytes == 1) VCY_BITS_F(uint8_t, false);
+      else if (c->cnt_bytes == 2) VCY_BITS_F(uint16_t, false);
+      else VCY_BITS_F(uint32_t, false);
+    }
+#undef VCY_BITS_F
 #undef VCY_BITS
+  };
+  const int64_t halo_words = (int64_t)c->halo_lo * c->ny * p.Wr;
+  if (c->cnt_implied && c->nx == p.Wr * 64) {
+    launch_bits(0, halo_words, false);
+    launch_bits(halo_words, vox_words - halo_words, true);
+  } else {
+    launch_bits(0, vox_words, false);
+  }
   hipLaunchKernelGGL(mc_active_kernel, dim3(nblocks), dim3(256), 0, s, p, d_act, d_woff, d_wcounts);
   MC_TRY(hipGetLastError());
   int rc = exclusive_scan_u64(d_wcounts, nblocks, d_total, d_scan, s);

@@ -32,6 +32,7 @@ int fill_state(vcy_ctx* c) {
   c->fresh = true;  // written lazily, see vcy_ctx::fresh
   c->views_carved = 0;
   c->halo_valid = false;
+  c->cnt_implied = true;
   return VCY_OK;
 }
 
@@ -431,6 +432,7 @@ int vcy_upload(vcy_ctx* c, const float* sdf, const int32_t* update_num) {
     c->views_carved = std::max<int64_t>(c->views_carved, mx);
   }
   c->halo_valid = false;
+  c->cnt_implied = false;  // arbitrary state from outside
   return VCY_OK;
 }
 

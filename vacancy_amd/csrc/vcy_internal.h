@@ -71,6 +71,7 @@ struct vcy_ctx {
   float* h_pz = nullptr;              // host copy of d_pz (per-view z tables of the fused carve)
   void* d_fused_scratch = nullptr;    // view blocks + z tables of the fused carve kernel
   size_t fused_scratch_bytes = 0;
+  bool cnt_implied = true;            // update_num == 0 implies sdf == lowest(): no vcy_upload since the fill
   float* d_wmax = nullptr;            // window-maximum planes of the views of one fused launch
   size_t wmax_bytes = 0;
   bool fused_ortho = false;           // projection model of the launch being prepared
