@@ -121,9 +121,12 @@ int vcy_compute_dims(const float bb_min[3], const float bb_max[3],
 
 /* Replaces bool VoxelCarver::Carve(const Camera&, const Vector2i& roi_min,
  * const Vector2i& roi_max, const Image1f& sdf) (voxel_carver.cc:415-496).
- * `sdf_host` is row-major float[height*width]. */
+ * `sdf_host` is row-major float[height*width]; it is copied before the call returns.  The view is
+ * queued and applied later, in order (see "defer" under vcy_set_param); argument errors are reported
+ * here, a device failure by the call that applies the queue. */
 int vcy_carve(vcy_ctx* ctx, const vcy_view* view, const float* sdf_host);
-/* Same, SDF image already resident in HBM on the context's device. */
+/* Same, SDF image already resident in HBM on the context's device (copied, ordered on the context's
+ * stream: do not overwrite it before the stream has passed this call). */
 int vcy_carve_device(vcy_ctx* ctx, const vcy_view* view, const float* sdf_device);
 /* Replaces the loop of Carve(const std::vector<Camera>&, ...)
  * (voxel_carver.cc:516-528) for pre-built SDFs: fuses `n_views` views in
@@ -225,7 +228,12 @@ int vcy_reset(vcy_ctx* ctx);
 /* Tuning knobs that never change results.  "fused" (default 1): 0 forces one kernel launch
  * per view (the generic kernel) instead of the fused multi-view kernel.  "cull" (default 1): 0 never
  * drops provably idle (brick, view) pairs.  "tile" (default 0 = chosen from the pixel footprint of a
- * voxel): 1 / 2 force the small / big LDS tile of the fused kernel. */
+ * voxel): 1 / 2 force the small / big LDS tile of the fused kernel.  "defer" (default 1): the per-view
+ * entry points vcy_carve / vcy_carve_device / vcy_carve_silhouette keep a private device copy of the image
+ * and queue the view; queued views are carved together, in call order, by one fused launch when the
+ * state is next needed (extraction, download, upload, halo, vcy_sync, vcy_timer_end, a batch call) or
+ * when 32 wait, so the reference's `for each view: Carve()` loop costs one pass over the grid instead of
+ * one per view.  0 carves every view before its call returns.  vcy_reset drops queued views. */
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all launches. */
 int vcy_set_stream(vcy_ctx* ctx, void* hip_stream);

@@ -510,3 +510,44 @@ def test_selftest_and_unit_weight_average_many_views():
     assert_state_equal(dev, orc, "unit-weight average, 300 views")
     assert int(dev.download()[1].max()) == nv
     dev.free_device(d)
+
+
+def test_per_view_calls_are_applied_together_and_in_order():
+    """vcy_carve / vcy_carve_device only queue the view (private copy of the image); the queue is
+    carved by one fused launch when the state is needed or 32 views wait.  Same results as carving
+    each view at once ("defer" 0) and as the oracle, including a projection-model switch, a caller
+    that overwrites its image between calls, and a reset that discards queued views."""
+    n, nv = 28, 37
+    uo = UpdateOption(voxel_update=1, voxel_max_update_num=300)
+    opt = synth.sphere_option(n, uo)
+    views, masks = synth.sphere_views(n, nv, 96, 72)
+    for i in (5, 6, 20):  # orthographic views in between: the queue is flushed at each switch
+        views[i].is_ortho = 1
+        views[i].w2c[3] += 48.0
+        views[i].w2c[7] += 36.0
+    sdfs = [vc.make_sdf(m) * np.float32(1.0 + 0.01 * i) for i, m in enumerate(masks)]
+    orc = O.OracleGrid(opt)
+    for v, s in zip(views, sdfs):
+        orc.carve(v, s)
+    states = []
+    for defer in (1, 0):
+        dev = vc.VoxelCarver(opt)
+        assert dev.Init(), vc.last_error()
+        dev.set_param("defer", defer)
+        # queued views die with a reset
+        assert dev.Carve(views[3], sdfs[7])
+        dev.reset()
+        scratch = dev.upload_sdf(sdfs[0])
+        for i, (v, s) in enumerate(zip(views, sdfs)):
+            if i % 3 == 0:   # device image owned by the caller, overwritten right after the call
+                dev.memcpy_h2d(scratch, s)
+                assert dev.CarveDevice(v, scratch), vc.last_error()
+                dev.memcpy_h2d(scratch, np.full_like(s, 123.0))
+            else:
+                assert dev.Carve(v, s), vc.last_error()
+        states.append(dev.download())
+        assert_state_equal(dev, orc, "per-view calls, defer=%d" % defer)
+        dev.free_device(scratch)
+        dev.close()
+    assert np.array_equal(states[0][0].view(np.uint32), states[1][0].view(np.uint32))
+    assert np.array_equal(states[0][1], states[1][1])

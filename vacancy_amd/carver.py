@@ -130,6 +130,10 @@ class VoxelCarver:
         assert self._lib.vcy_memcpy_d2h(self._ctx, _p(out), ptr, out.nbytes) == 0, last_error()
         return out
 
+    def memcpy_h2d(self, ptr, array):
+        array = np.ascontiguousarray(array)
+        assert self._lib.vcy_memcpy_h2d(self._ctx, ptr, _p(array), array.nbytes) == 0, last_error()
+
     def free_device(self, ptr):
         self._lib.vcy_device_free(self._ctx, ptr)
 

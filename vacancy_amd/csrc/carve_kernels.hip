@@ -109,7 +109,29 @@ static void launch_view(vcy_ctx* c, const GridParams& g, const ViewParams& v, co
   }
 }
 
+// Applies the views queued by the per-view entry points, in order, as one batch.
+int flush_pending(vcy_ctx* c) {
+  if (c->pending.empty()) return VCY_OK;
+  std::vector<vcy_ctx::PendingView> todo;
+  todo.swap(c->pending);  // launch_carve flushes first: nothing left to recurse on
+  std::vector<vcy_view> views(todo.size());
+  std::vector<const float*> ptrs(todo.size());
+  for (size_t i = 0; i < todo.size(); ++i) {
+    views[i] = todo[i].view;
+    ptrs[i] = todo[i].d_sdf;
+  }
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  const int rc = launch_carve(c, (int)todo.size(), views.data(), ptrs.data());
+  // stream order: a buffer handed out again is only written after this launch
+  for (auto& t : todo) c->sdf_pool.emplace_back(t.d_sdf, t.bytes);
+  return rc;
+}
+
 int launch_carve(vcy_ctx* c, int n_views, const vcy_view* views, const float* const* sdf_dev) {
+  {
+    const int rcf = flush_pending(c);  // earlier per-view calls come first
+    if (rcf != VCY_OK) return rcf;
+  }
   const vcy_update_option& u = c->opt.update_option;
   GridParams g;
   g.sdf = c->owned_slab_sdf();

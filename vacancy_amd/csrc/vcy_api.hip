@@ -28,7 +28,13 @@ __global__ void fill_f32_kernel(float* __restrict__ p, float v, int64_t n) {
   for (; i < n; i += stride) p[i] = v;
 }
 
+static void discard_pending(vcy_ctx* c) {
+  for (auto& t : c->pending) c->sdf_pool.emplace_back(t.d_sdf, t.bytes);
+  c->pending.clear();
+}
+
 int fill_state(vcy_ctx* c) {
+  discard_pending(c);  // whatever they would have carved is wiped
   c->fresh = true;  // written lazily, see vcy_ctx::fresh
   c->views_carved = 0;
   c->halo_valid = false;
@@ -37,6 +43,10 @@ int fill_state(vcy_ctx* c) {
 }
 
 int materialize(vcy_ctx* c) {
+  {
+    const int rcf = flush_pending(c);  // every reader of the state comes through here
+    if (rcf != VCY_OK) return rcf;
+  }
   if (!c->fresh) return VCY_OK;
   // only the owned slab: halo slices are written by vcy_halo_install / _unpack
   const int64_t n = c->slab_voxels();
@@ -241,6 +251,8 @@ void vcy_destroy(vcy_ctx* c) {
   (void)hipFree(c->d_mc_cells);
   (void)hipFree(c->d_fused_scratch);
   (void)hipFree(c->d_wmax);
+  for (auto& t : c->pending) (void)hipFree(t.d_sdf);
+  for (auto& t : c->sdf_pool) (void)hipFree(t.first);
   delete[] c->h_pz;
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
@@ -266,6 +278,7 @@ int vcy_slab_range(const vcy_ctx* c, int32_t zr[2]) {
 int vcy_set_stream(vcy_ctx* c, void* s) {
   if (!c) return VCY_ERR_NOT_INITIALIZED;
   VCY_HIP_CHECK(hipSetDevice(c->device));
+  { const int rcf = flush_pending(c); if (rcf != VCY_OK) return rcf; }
   if (c->stream) VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (c->own_stream && c->stream) VCY_HIP_CHECK(hipStreamDestroy(c->stream));
   c->stream = (hipStream_t)s;
@@ -275,6 +288,11 @@ int vcy_set_stream(vcy_ctx* c, void* s) {
 
 int vcy_set_param(vcy_ctx* c, const char* name, int value) {
   if (!c || !name) return VCY_ERR_INVALID_ARG;
+  { const int rcf = flush_pending(c); if (rcf != VCY_OK) return rcf; }  // queued views keep the old setting
+  if (std::strcmp(name, "defer") == 0) {
+    c->defer = value != 0;
+    return VCY_OK;
+  }
   if (std::strcmp(name, "fused") == 0) {
     c->use_fused = value != 0;
     return VCY_OK;
@@ -301,6 +319,7 @@ int vcy_get_stream(vcy_ctx* c, void** out) {
 int vcy_sync(vcy_ctx* c) {
   if (!c) return VCY_ERR_NOT_INITIALIZED;
   VCY_HIP_CHECK(hipSetDevice(c->device));
+  { const int rcf = flush_pending(c); if (rcf != VCY_OK) return rcf; }
   VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
   return VCY_OK;
 }
@@ -313,6 +332,7 @@ int vcy_timer_begin(vcy_ctx* c) {
 
 int vcy_timer_end(vcy_ctx* c, float* ms) {
   if (!c) return VCY_ERR_NOT_INITIALIZED;
+  { const int rcf = flush_pending(c); if (rcf != VCY_OK) return rcf; }  // queued views belong to the interval
   VCY_HIP_CHECK(hipEventRecord(c->ev_end, c->stream));
   VCY_HIP_CHECK(hipEventSynchronize(c->ev_end));
   VCY_HIP_CHECK(hipEventElapsedTime(ms, c->ev_begin, c->ev_end));
@@ -584,8 +604,66 @@ int vcy_carve_batch_device(vcy_ctx* c, int n_views, const vcy_view* views,
   return launch_carve(c, n_views, views, sdf_device);
 }
 
+// An idle image buffer of at least `bytes` (from the pool, else newly allocated).
+static int acquire_sdf_buffer(vcy_ctx* c, size_t bytes, float** out, size_t* cap) {
+  for (size_t i = 0; i < c->sdf_pool.size(); ++i) {
+    if (c->sdf_pool[i].second >= bytes) {
+      *out = c->sdf_pool[i].first;
+      *cap = c->sdf_pool[i].second;
+      c->sdf_pool.erase(c->sdf_pool.begin() + (long)i);
+      return VCY_OK;
+    }
+  }
+  float* d = nullptr;
+  VCY_HIP_CHECK(hipMalloc(&d, bytes));
+  *out = d;
+  *cap = bytes;
+  return VCY_OK;
+}
+
+// Whether a view accepted by a per-view entry point may wait for a fused launch.
+static bool can_defer(vcy_ctx* c, const vcy_view* view) {
+  if (!c->defer || !c->use_fused || !fused_eligible(c, 1, view)) return false;
+  return true;
+}
+
+// Queues (view, private device image): flushes first if the queue is full or of the other projection
+// model (one model per fused launch).
+static int enqueue_view(vcy_ctx* c, const vcy_view* view, float* d_img, size_t cap) {
+  int rc = VCY_OK;
+  if (!c->pending.empty() && (c->pending.front().view.is_ortho != 0) != (view->is_ortho != 0)) rc = flush_pending(c);
+  if (rc == VCY_OK) {
+    c->pending.push_back(vcy_ctx::PendingView{*view, d_img, cap});
+    c->halo_valid = false;
+    if ((int)c->pending.size() >= fused_max_views()) rc = flush_pending(c);
+  } else {
+    c->sdf_pool.emplace_back(d_img, cap);
+  }
+  return rc;
+}
+
 int vcy_carve_device(vcy_ctx* c, const vcy_view* view, const float* sdf_device) {
-  return vcy_carve_batch_device(c, 1, view, &sdf_device);
+  int rc = check_view(c, view);
+  if (rc != VCY_OK) return rc;
+  if (!sdf_device) {
+    set_error("null SDF pointer");
+    return VCY_ERR_INVALID_ARG;
+  }
+  if (!can_defer(c, view)) return vcy_carve_batch_device(c, 1, view, &sdf_device);
+  // the caller may change or free its image after this returns: keep a copy (stream-ordered)
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  const size_t bytes = sizeof(float) * (size_t)view->width * view->height;
+  float* d = nullptr;
+  size_t cap = 0;
+  rc = acquire_sdf_buffer(c, bytes, &d, &cap);
+  if (rc != VCY_OK) return rc;
+  const hipError_t e = hipMemcpyAsync(d, sdf_device, bytes, hipMemcpyDeviceToDevice, c->stream);
+  if (e != hipSuccess) {
+    c->sdf_pool.emplace_back(d, cap);
+    set_error("SDF copy failed: %s", hipGetErrorString(e));
+    return VCY_ERR_HIP;
+  }
+  return enqueue_view(c, view, d, cap);
 }
 
 int vcy_carve(vcy_ctx* c, const vcy_view* view, const float* sdf_host) {
@@ -595,12 +673,29 @@ int vcy_carve(vcy_ctx* c, const vcy_view* view, const float* sdf_host) {
     set_error("null SDF pointer");
     return VCY_ERR_INVALID_ARG;
   }
+  if (!can_defer(c, view)) {
+    float* d = nullptr;
+    rc = vcy_sdf_upload(c, sdf_host, view->width, view->height, &d);
+    if (rc != VCY_OK) return rc;
+    rc = vcy_carve_batch_device(c, 1, view, (const float* const*)&d);
+    int rc2 = vcy_device_free(c, d);  // synchronises the stream first
+    return rc != VCY_OK ? rc : rc2;
+  }
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  const size_t bytes = sizeof(float) * (size_t)view->width * view->height;
   float* d = nullptr;
-  rc = vcy_sdf_upload(c, sdf_host, view->width, view->height, &d);
+  size_t cap = 0;
+  rc = acquire_sdf_buffer(c, bytes, &d, &cap);
   if (rc != VCY_OK) return rc;
-  rc = vcy_carve_device(c, view, d);
-  int rc2 = vcy_device_free(c, d);  // synchronises the stream first
-  return rc != VCY_OK ? rc : rc2;
+  // the previous user of a pooled buffer may be a launch still running: order the copy after it
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipMemcpy(d, sdf_host, bytes, hipMemcpyHostToDevice);  // caller's buffer is free on return
+  if (e != hipSuccess) {
+    c->sdf_pool.emplace_back(d, cap);
+    set_error("hipMemcpy H2D failed: %s", hipGetErrorString(e));
+    return VCY_ERR_HIP;
+  }
+  return enqueue_view(c, view, d, cap);
 }
 
 int vcy_carve_silhouette(vcy_ctx* c, const vcy_view* view, const uint8_t* mask, float* sdf_out) {

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "vacancy_hip.h"
@@ -66,6 +67,18 @@ struct vcy_ctx {
 
   int tile_mode = 0;                  // 0 auto, 1 small LDS tile, 2 big LDS tile (vcy_set_param "tile")
   bool use_cull = true;               // vcy_set_param("cull", 0): never drop provably idle views
+  // Views accepted by the per-view entry points (vcy_carve, vcy_carve_device, vcy_carve_silhouette) but
+  // not applied yet: they are carved together, in order, by ONE fused launch when the state is next
+  // needed (extraction, download, halo, timer, sync ...) or when 32 are waiting -- the reference's
+  // `for each view: Carve()` loop then costs one pass over the grid instead of one per view.
+  struct PendingView {
+    vcy_view view;
+    float* d_sdf;   // private device copy of the SDF image
+    size_t bytes;
+  };
+  std::vector<PendingView> pending;
+  std::vector<std::pair<float*, size_t>> sdf_pool;  // idle image buffers
+  bool defer = true;                  // vcy_set_param("defer", 0): apply every view at once
   bool use_fused = true;              // vcy_set_option("fused", 0) forces the per-view kernel
   float h_px_min = 0, h_px_max = 0, h_py_min = 0, h_py_max = 0;  // extreme voxel centres
   float* h_pz = nullptr;              // host copy of d_pz (per-view z tables of the fused carve)
@@ -113,6 +126,7 @@ bool fused_eligible(const vcy_ctx* ctx, int n_views, const vcy_view* views);
 int launch_carve_fused(vcy_ctx* ctx, const GridParams& g, int n_views, const ViewParams* vp);
 int fused_max_views();
 int selftest_fused(hipStream_t stream);
+int flush_pending(vcy_ctx* ctx);   // applies vcy_ctx::pending (no-op when empty)
 // mc_kernels.hip
 int extract_iso(vcy_ctx* ctx, double iso, int linear_interp, vcy_mesh* out);
 // sdf2d.hip
