@@ -253,6 +253,7 @@ void vcy_destroy(vcy_ctx* c) {
   (void)hipFree(c->d_wmax);
   for (auto& t : c->pending) (void)hipFree(t.d_sdf);
   for (auto& t : c->sdf_pool) (void)hipFree(t.first);
+  (void)hipFree(c->d_sil_scratch);
   delete[] c->h_pz;
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
@@ -708,34 +709,48 @@ int vcy_carve_silhouette(vcy_ctx* c, const vcy_view* view, const uint8_t* mask, 
   VCY_HIP_CHECK(hipSetDevice(c->device));
   const vcy_update_option& u = c->opt.update_option;
   const size_t npx = (size_t)view->width * view->height;
-  // device staging: [mask u8][sdf f32][transform scratch]
-  const size_t off_sdf = (npx + 255) / 256 * 256;
-  const size_t off_scr = off_sdf + npx * sizeof(float);
+  // device staging kept in the context: [mask u8][transform scratch]; the SDF goes to a pooled image
+  const size_t off_scr = (npx + 255) / 256 * 256;
   const size_t need = off_scr + device_make_sdf_scratch_bytes(view->width, view->height);
-  char* d = nullptr;
-  VCY_HIP_CHECK(hipMalloc(&d, need));
-  auto done = [&](int code) {
+  VCY_HIP_CHECK(hipStreamSynchronize(c->stream));  // the staging may still feed the previous call's kernels
+  if (c->sil_scratch_bytes < need) {
+    if (c->d_sil_scratch) VCY_HIP_CHECK(hipFree(c->d_sil_scratch));
+    c->d_sil_scratch = nullptr;
+    c->sil_scratch_bytes = 0;
+    VCY_HIP_CHECK(hipMalloc(&c->d_sil_scratch, need));
+    c->sil_scratch_bytes = need;
+  }
+  char* d = (char*)c->d_sil_scratch;
+  float* d_img = nullptr;
+  size_t cap = 0;
+  rc = acquire_sdf_buffer(c, npx * sizeof(float), &d_img, &cap);
+  if (rc != VCY_OK) return rc;
+  auto give_back = [&](int code) {
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
+    c->sdf_pool.emplace_back(d_img, cap);
     return code;
   };
-  if (hipMemcpyAsync(d, mask, npx, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+  if (hipMemcpy(d, mask, npx, hipMemcpyHostToDevice) != hipSuccess) {  // caller's mask is free on return
     set_error("mask upload failed");
-    return done(VCY_ERR_HIP);
+    return give_back(VCY_ERR_HIP);
   }
   // MakeSignedDistanceField(silhouette, roi_min, roi_max, sdf, option_.sdf_minmax_normalize,
   //   use_truncation, truncation_band), reference voxel_carver.cc:405-408 -- on the device
   rc = device_make_sdf(c->stream, (const uint8_t*)d, view->width, view->height, view->roi_min, view->roi_max,
-                       c->opt.sdf_minmax_normalize != 0, u.use_truncation != 0, u.truncation_band, d + off_scr,
-                       (float*)(d + off_sdf));
-  if (rc != VCY_OK) return done(rc);
-  if (sdf_out && hipMemcpyAsync(sdf_out, d + off_sdf, npx * sizeof(float), hipMemcpyDeviceToHost, c->stream) !=
-                     hipSuccess) {
-    set_error("sdf download failed");
-    return done(VCY_ERR_HIP);
+                       c->opt.sdf_minmax_normalize != 0, u.use_truncation != 0, u.truncation_band, d + off_scr, d_img);
+  if (rc != VCY_OK) return give_back(rc);
+  if (sdf_out) {
+    hipError_t e = hipMemcpyAsync(sdf_out, d_img, npx * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+      set_error("sdf download failed: %s", hipGetErrorString(e));
+      return give_back(VCY_ERR_HIP);
+    }
   }
-  rc = vcy_carve_device(c, view, (const float*)(d + off_sdf));
-  return done(rc);
+  if (can_defer(c, view)) return enqueue_view(c, view, d_img, cap);
+  const float* img = d_img;
+  rc = vcy_carve_batch_device(c, 1, view, &img);
+  return give_back(rc);
 }
 
 int vcy_make_sdf_device(vcy_ctx* c, const uint8_t* mask_host, int w, int h, const int32_t rmin[2],

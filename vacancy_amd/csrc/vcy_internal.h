@@ -78,6 +78,8 @@ struct vcy_ctx {
   };
   std::vector<PendingView> pending;
   std::vector<std::pair<float*, size_t>> sdf_pool;  // idle image buffers
+  void* d_sil_scratch = nullptr;      // staging of vcy_carve_silhouette (mask + transform scratch)
+  size_t sil_scratch_bytes = 0;
   bool defer = true;                  // vcy_set_param("defer", 0): apply every view at once
   bool use_fused = true;              // vcy_set_option("fused", 0) forces the per-view kernel
   float h_px_min = 0, h_px_max = 0, h_py_min = 0, h_py_max = 0;  // extreme voxel centres
