@@ -551,3 +551,36 @@ def test_per_view_calls_are_applied_together_and_in_order():
         dev.close()
     assert np.array_equal(states[0][0].view(np.uint32), states[1][0].view(np.uint32))
     assert np.array_equal(states[0][1], states[1][1])
+
+
+def test_queued_views_with_slabs_and_halo_exchange():
+    """Two z-slab contexts, per-view Carve() calls (queued), halo exchange and extraction with no read
+    of the state in between: packing flushes the lower slab, extraction the upper one, and the halo
+    installed in between stays valid."""
+    from vacancy_amd import dist as vdist
+    n, nv = 36, 9
+    opt = synth.sphere_option(n)
+    views, masks = synth.sphere_views(n, nv, 112, 84)
+    sdfs = [vc.make_sdf(m) for m in masks]
+    orc = O.OracleGrid(opt)
+    for v, s in zip(views, sdfs):
+        orc.carve(v, s)
+    ranks = []
+    for r in range(2):
+        c = vc.VoxelCarver(opt, z_range=vdist.slab_range(n, r, 2))
+        assert c.Init(), vc.last_error()
+        ranks.append(c)
+    for v, s in zip(views, sdfs):
+        for c in ranks:
+            assert c.Carve(v, s), vc.last_error()
+    gathered = np.concatenate([c.halo_pack_host() for c in ranks])
+    for r, c in enumerate(ranks):
+        c.halo_unpack_host(gathered, r, 2)
+    parts = [c.ExtractIsoSurface(0.0, True) for c in ranks]
+    assert_mesh_equal(vdist.merge_meshes(parts), orc.marching_cubes(0.0, True), "queued views, two slabs")
+    # a halo installed BEFORE more views are queued is stale: extraction must refuse
+    assert ranks[1].Carve(views[0], sdfs[0])
+    with pytest.raises(RuntimeError):
+        ranks[1].ExtractIsoSurface()
+    for c in ranks:
+        c.close()

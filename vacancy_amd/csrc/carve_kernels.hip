@@ -121,7 +121,11 @@ int flush_pending(vcy_ctx* c) {
     ptrs[i] = todo[i].d_sdf;
   }
   VCY_HIP_CHECK(hipSetDevice(c->device));
+  // the halo slices were invalidated when the views were queued; halos installed since then were taken
+  // from a neighbour that has applied the same views and stay valid
+  const bool halo_valid = c->halo_valid;
   const int rc = launch_carve(c, (int)todo.size(), views.data(), ptrs.data());
+  c->halo_valid = halo_valid;
   // stream order: a buffer handed out again is only written after this launch
   for (auto& t : todo) c->sdf_pool.emplace_back(t.d_sdf, t.bytes);
   return rc;
