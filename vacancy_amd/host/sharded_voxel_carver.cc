@@ -119,6 +119,8 @@ bool ShardedVoxelCarver::Carve(const std::vector<const Camera*>& cameras, const 
   std::vector<std::future<int>> jobs;
   for (vcy_ctx* ctx : impl_->slabs)
     jobs.push_back(std::async(std::launch::async, [ctx, n, &views, &masks]() {
+      // one view: queued by the library, carved together with the following calls (vcy_set_param "defer")
+      if (n == 1) return vcy_carve_silhouette(ctx, &views[0], masks[0], nullptr);
       return vcy_carve_batch_silhouettes(ctx, n, views.data(), masks.data());
     }));
   bool ok = true;
