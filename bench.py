@@ -225,7 +225,7 @@ def main():
     # launch duration from HIP events on the launch stream.
     bytes_per_vv = 4.0 if args.mode == "default" else 4.0 + (1 if uo.voxel_max_update_num <= 254 else 2)
     slab_vox = sum(c.slab_voxels for c in devs) / float(len(devs))  # per launch
-    FUSED_MAX = 32  # views per fused launch (carve_fused.hip)
+    FUSED_MAX = 64  # views per fused launch (carve_fused.hip)
     views_per_launch = min(nv, FUSED_MAX) if args.batch else 1
     launches_per_step = ((nv + views_per_launch - 1) // views_per_launch) * len(devs)
     avg_launch_ms = sum(kernel_ms) / len(kernel_ms) / launches_per_step

@@ -584,3 +584,27 @@ def test_queued_views_with_slabs_and_halo_exchange():
         ranks[1].ExtractIsoSurface()
     for c in ranks:
         c.close()
+
+
+@pytest.mark.parametrize("mode", ["default", "tsdf"])
+def test_batches_of_up_to_64_views_in_one_launch(mode):
+    """vcy_carve_batch_device fuses up to 64 views per launch (one prologue lane per view): 50 and 64 + 7
+    views against the oracle's per-view loop."""
+    n = 24
+    uo = UpdateOption(**SYN_MODES[mode])
+    opt = synth.sphere_option(n, uo)
+    for nv in (50, 71):
+        views, masks = synth.sphere_views(n, nv, 80, 60)
+        sdfs = [O.make_sdf(m, use_truncation=bool(uo.use_truncation), band=uo.truncation_band) * np.float32(1 + 0.003 * i)
+                for i, m in enumerate(masks)]
+        dev = vc.VoxelCarver(opt)
+        assert dev.Init(), vc.last_error()
+        orc = O.OracleGrid(opt)
+        d = [dev.upload_sdf(s) for s in sdfs]
+        assert dev.CarveBatchDevice(vc.VoxelCarver.prepare_batch(views, d)), vc.last_error()
+        for v, s in zip(views, sdfs):
+            orc.carve(v, s)
+        assert_state_equal(dev, orc, "%s %d views" % (mode, nv))
+        for p in d:
+            dev.free_device(p)
+        dev.close()

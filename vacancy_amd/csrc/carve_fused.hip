@@ -1,4 +1,4 @@
-// K1 (fused): carve up to 32 views per launch with the voxel state held in registers.
+// K1 (fused): carve up to 64 views per launch with the voxel state held in registers.
 //
 // Replaces the loop `for each view: Carve(camera, roi, sdf)` (reference voxel_carver.cc:516-528
 // around :415-496).  Voxels are independent and every voxel sees its views in sequence order,
@@ -38,7 +38,7 @@ namespace {
 
 constexpr int BX = 32, BY = 8, BZ = 8;  // voxels per workgroup: four 8x8x8 wave bricks along x
 constexpr int WX = 8;                    // wave brick is WX x BY x BZ, lane = (x & 7) | (y << 3)
-constexpr int kMaxFusedViews = 32;
+constexpr int kMaxFusedViews = 64;         // one prologue lane per view
 constexpr int kTileSmall = 128;          // quads per wave tile (2 KB): <= 2 per lane, prefetched in registers
 constexpr int kTileBig = 512;            // 8 KB per wave: footprints up to ~1.4 px per voxel, filled in place
 
@@ -477,9 +477,9 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
                                                           const float* __restrict__ c2_all,
                                                           int nviews, ModeParams mode, int nbx,
                                                           int nby, int cull_enabled, int fresh) {
-  __shared__ float4 tile_all[4][TQ];
+  // dynamic LDS: [4 waves][TQ] quads, then [4 waves][nviews] TileInfo (sized by the launch)
+  extern __shared__ float4 fused_lds[];
   constexpr bool kPrefetch = TQ <= 128;  // two quads per lane fit in registers
-  __shared__ TileInfo tinfo_all[4][kMaxFusedViews];
   // A view can be dropped for a whole wave brick when no voxel of the brick can change:
   //   - use_truncation and every sample is provably < -1 (voxel_carver.cc:478), or
   //   - kMax, every voxel already touched, and every sample is provably <= min(sdf) of the
@@ -493,8 +493,8 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  float4* tile = tile_all[wave];
-  TileInfo* tinfo = tinfo_all[wave];
+  float4* tile = fused_lds + wave * TQ;
+  TileInfo* tinfo = (TileInfo*)(fused_lds + 4 * TQ) + wave * nviews;
   const int lx = lane & (WX - 1), ly = lane >> 3;
   // XCD-aware order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, so
   // workgroup b runs on XCD b % 8.  Give every XCD one contiguous eighth of the brick list: bricks
@@ -711,7 +711,8 @@ void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const Gri
                     const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh) {
   const bool gen = m.ortho != 0 || m.interp == VCY_INTERP_NN;
 #define VCY_FUSED(CM, TQ_, GEN_)                                                                            \
-  hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, CM, TQ_, GEN_>), grid, dim3(256), 0, s, \
+  hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, CM, TQ_, GEN_>), grid, dim3(256),   \
+                     (size_t)4 * TQ_ * sizeof(float4) + (size_t)4 * nv * sizeof(TileInfo), s,              \
                      g, dv, c2, nv, m, nbx, nby, cull, fresh)
 #define VCY_FUSED_G(CM, TQ_)                                                                                \
   do {                                                                                                      \

@@ -628,6 +628,8 @@ static bool can_defer(vcy_ctx* c, const vcy_view* view) {
   return true;
 }
 
+constexpr int kMaxPendingViews = 32;  // queued images held at most (3.7 MB each at 1280x720)
+
 // Queues (view, private device image): flushes first if the queue is full or of the other projection
 // model (one model per fused launch).
 static int enqueue_view(vcy_ctx* c, const vcy_view* view, float* d_img, size_t cap) {
@@ -636,7 +638,7 @@ static int enqueue_view(vcy_ctx* c, const vcy_view* view, float* d_img, size_t c
   if (rc == VCY_OK) {
     c->pending.push_back(vcy_ctx::PendingView{*view, d_img, cap});
     c->halo_valid = false;
-    if ((int)c->pending.size() >= fused_max_views()) rc = flush_pending(c);
+    if ((int)c->pending.size() >= kMaxPendingViews) rc = flush_pending(c);
   } else {
     c->sdf_pool.emplace_back(d_img, cap);
   }
@@ -811,7 +813,7 @@ int vcy_carve_batch_silhouettes(vcy_ctx* c, int n_views, const vcy_view* views,
   }
   VCY_HIP_CHECK(hipSetDevice(c->device));
   const vcy_update_option& u = c->opt.update_option;
-  const int chunk = fused_max_views();
+  const int chunk = 32;  // per fused launch here: the next 32 silhouettes upload and transform meanwhile
   const int per_set = std::min(chunk, n_views);
   const size_t px_al = (max_px + 255) / 256 * 256;
   // [2 sets][per_set] SDF images + [2 sets][per_set] masks + [per_set] transform scratch; cached in
