@@ -128,6 +128,12 @@ int flush_pending(vcy_ctx* c) {
   c->halo_valid = halo_valid;
   // stream order: a buffer handed out again is only written after this launch
   for (auto& t : todo) c->sdf_pool.emplace_back(t.d_sdf, t.bytes);
+  // image sizes that keep changing would let idle buffers pile up: keep at most two queues' worth
+  // (hipFree waits for the device, so a buffer still read by the launch above is safe to free)
+  while (c->sdf_pool.size() > 64) {
+    (void)hipFree(c->sdf_pool.front().first);
+    c->sdf_pool.erase(c->sdf_pool.begin());
+  }
   return rc;
 }
 
