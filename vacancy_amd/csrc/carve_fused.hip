@@ -472,7 +472,7 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
 // GEN: nearest-neighbour sampling and/or an orthographic camera, selected at run time from `mode`
 // (compiled out of the default bilinear + pinhole kernels, where the extra branches cost 16 %).
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX, int TQ, bool GEN>
-__global__ __launch_bounds__(256) void carve_fused_kernel(GridParams g,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void carve_fused_kernel(GridParams g,
                                                           const FusedView* __restrict__ views,
                                                           const float* __restrict__ c2_all,
                                                           int nviews, ModeParams mode, int nbx,
