@@ -104,6 +104,12 @@ __device__ const Share kShare[12] = {
 // Cell rows: layer li = 0 is the ghost layer (z = zc0-1), li = l+1 the slab's own layer l;
 // word index of (li, cy = y-1, w):  li == 0 ? cy*Wr + w : G + ((li-1)*Y + cy)*Wr + w,
 // G = ghost words rounded up to a whole block so that own cells start on a block boundary.
+// Exact n / d for 32-bit unsigned n (Granlund-Montgomery): three integer instructions instead of the
+// long 64-bit division sequence.
+struct FastDiv {
+  uint32_t d, m, s1, s2;
+};
+
 struct McParams {
   const float* sdf;   // slab incl. halo slices
   const void* cnt;
@@ -125,6 +131,8 @@ struct McParams {
   int64_t nwords;     // G + L*Y*Wr
   double iso;
   int linear;
+  FastDiv div_row, div_layer;  // by Wr and by Y * Wr; used when small32 (every word index < 2^32)
+  int small32;
 };
 
 constexpr int kWordsPerBlock = 256;
@@ -204,7 +212,29 @@ __global__ __launch_bounds__(256) void mc_bits_kernel(const float* __restrict__ 
 }
 
 // ---- shared cell-word helpers -----------------------------------------------------------------
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv& f) {
+  const uint32_t t = __umulhi(n, f.m);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
 __device__ __forceinline__ bool decode_word(const McParams& p, int64_t cw, int* li, int* cy, int* w) {
+  if (p.small32) {
+    uint32_t r;
+    if (cw < p.G) {
+      if (cw >= (int64_t)p.Y * p.Wr) return false;  // padding
+      *li = 0;
+      r = (uint32_t)cw;
+    } else {
+      const uint32_t q = (uint32_t)(cw - p.G);
+      const uint32_t layer = fast_div(q, p.div_layer);
+      *li = (int)layer + 1;
+      r = q - layer * p.div_layer.d;
+    }
+    const uint32_t row = fast_div(r, p.div_row);
+    *cy = (int)row;
+    *w = (int)(r - row * p.div_row.d);
+    return true;
+  }
   int64_t r;
   if (cw < p.G) {
     if (cw >= (int64_t)p.Y * p.Wr) return false;  // padding
@@ -617,6 +647,21 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   const int64_t ghost_words = (int64_t)p.Y * p.Wr;
   p.G = (ghost_words + kWordsPerBlock - 1) / kWordsPerBlock * kWordsPerBlock;
   p.nwords = p.G + (int64_t)p.L * p.Y * p.Wr;
+  {
+    auto make_div = [](uint32_t d) {
+      FastDiv f;
+      uint32_t l = 0;
+      while ((1ull << l) < d) ++l;  // ceil(log2 d)
+      f.d = d;
+      f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+      f.s1 = l < 1 ? l : 1;
+      f.s2 = l < 1 ? 0 : l - 1;
+      return f;
+    };
+    p.small32 = p.nwords < 0xffffffffLL && (int64_t)p.Y * p.Wr < 0x7fffffffLL ? 1 : 0;
+    p.div_row = make_div((uint32_t)p.Wr);
+    p.div_layer = make_div(p.small32 ? (uint32_t)((int64_t)p.Y * p.Wr) : 1u);
+  }
   const int64_t nblocks64 = (p.nwords + kWordsPerBlock - 1) / kWordsPerBlock;
   const int64_t vox_rows = (int64_t)p.nslices * c->ny;
   const int64_t vox_words = vox_rows * p.Wr;
