@@ -3,7 +3,7 @@
 // Replaces the loop `for each view: Carve(camera, roi, sdf)` (reference voxel_carver.cc:516-528
 // around :415-496).  Voxels are independent and every voxel sees its views in sequence order,
 // so fusing views changes nothing but where the state lives.  A workgroup is four independent
-// waves; each WAVE owns an 8x8x8 brick (lane = (x & 7) | (y << 3), 8 voxels along z per lane),
+// waves; each WAVE owns an 8x8x8 brick (lane = (y & 7) | (z << 3), 8 voxels along x per lane),
 // loads sdf/update_num ONCE (not at all for a fresh grid), applies all views and writes back only
 // what changed.  The four wave bricks of a workgroup are adjacent in x, so together they read
 // 128-byte row segments.
@@ -37,7 +37,7 @@ namespace vcy {
 namespace {
 
 constexpr int BX = 32, BY = 8, BZ = 8;  // voxels per workgroup: four 8x8x8 wave bricks along x
-constexpr int WX = 8;                    // wave brick is WX x BY x BZ, lane = (x & 7) | (y << 3)
+constexpr int WX = 8;                    // wave brick is WX x BY x BZ, lane = (y & 7) | (z << 3), WX voxels per lane
 constexpr int kMaxFusedViews = 64;         // one prologue lane per view
 constexpr int kTileSmall = 128;          // quads per wave tile (2 KB): <= 2 per lane, prefetched in registers
 constexpr int kTileBig = 512;            // 8 KB per wave: footprints up to ~1.4 px per voxel, filled in place
@@ -59,7 +59,8 @@ struct FusedView {
   // a z-slab of a sharded grid often sees a narrow band of the image.
   int wrect[4];
 };
-// c2_all[view][3][nz_local] = R[i][2] * pz[z]  (one fp32 multiply per entry, done on the host)
+// c0_all[view][3][nxp] = R[i][0] * px[x]  (one fp32 multiply per entry, done on the host); nxp = nx rounded
+// up to whole bricks, the padding repeating the last column
 
 struct TileInfo {
   float lo_x, hi_x, lo_y, hi_y;  // closed range of (u,v) whose taps are in the tile
@@ -474,7 +475,7 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX, int TQ, bool GEN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void carve_fused_kernel(GridParams g,
                                                           const FusedView* __restrict__ views,
-                                                          const float* __restrict__ c2_all,
+                                                          const float* __restrict__ c0_all,
                                                           int nviews, ModeParams mode, int nbx,
                                                           int nby, int cull_enabled, int fresh) {
   // dynamic LDS: [4 waves][TQ] quads, then [4 waves][nviews] TileInfo (sized by the launch)
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
   const int wave = tid >> 6, lane = tid & 63;
   float4* tile = fused_lds + wave * TQ;
   TileInfo* tinfo = (TileInfo*)(fused_lds + 4 * TQ) + wave * nviews;
-  const int lx = lane & (WX - 1), ly = lane >> 3;
+  const int ly = lane & (BY - 1), lz = lane >> 3;
   // XCD-aware order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, so
   // workgroup b runs on XCD b % 8.  Give every XCD one contiguous eighth of the brick list: bricks
   // that follow each other on an XCD are neighbours in x and share SDF footprint pixels and
@@ -509,12 +510,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
   b /= nbx;
   const int by = b % nby;
   const int bz = b / nby;
-  const int x_first = bx * BX + wave * WX;  // wave brick origin
-  const int x_raw = x_first + lx, y_raw = by * BY + ly;
-  const bool col_valid = x_raw < g.nx && y_raw < g.ny;
-  const int x = min(x_raw, g.nx - 1), y = min(y_raw, g.ny - 1);  // clones for out-of-grid lanes
+  // (the wave index is uniform, which the compiler cannot see: readfirstlane keeps the x tables in scalar loads)
+  const int x_first = __builtin_amdgcn_readfirstlane(bx * BX + wave * WX);  // wave brick origin
+  if (x_first >= g.nx) return;              // (no workgroup barriers: a wave may leave alone)
   const int zl0 = bz * BZ;
-  const float px = g.px[x], py = g.py[y];
+  const int y_raw = by * BY + ly, zl_raw = zl0 + lz;
+  const bool lane_valid = y_raw < g.ny && zl_raw < g.nz_local;
+  const int y = min(y_raw, g.ny - 1), zl = min(zl_raw, g.nz_local - 1);  // clones for out-of-grid lanes
+  const float py = g.py[y], pz = g.pz[g.z0 + zl];
+  // Lane (y, z) walks the WX voxels of its x run: in pc = t + (c0 + (c1 + c2)) (reference association) the
+  // inner sum c1 + c2 = R[:,1] y + R[:,2] z is the same for the whole run and computed once per view.
+  const int nxp = (g.nx + WX - 1) & ~(WX - 1);
   const bool want_bound = kNeedBound && cull_enabled;
 
   // ---- prologue: lane vi bounds the footprint of the wave brick in view vi (brick_footprints) -------
@@ -532,16 +538,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
 
   // ---- load the wave brick's state ----------------------------------------------------------
   CountT* __restrict__ cnt = (CountT*)g.cnt;
-  float s[BZ];
-  int n[BZ];
-  const int64_t slice = (int64_t)g.nx * g.ny;
-  const int64_t col = (int64_t)y * g.nx + x;
+  float s[WX];
+  int n[WX];
+  const int64_t row0 = ((int64_t)zl * g.ny + y) * g.nx;  // this lane's row; voxel k is at row0 + min(x_first + k, nx - 1)
+  // rows are whole bricks when nx % 8 == 0: the run is one 32-byte (sdf) and one 8/16-byte (update_num) vector
+  const bool vec_io = (g.nx & (WX - 1)) == 0;
+  typedef CountT CountVec __attribute__((ext_vector_type(WX)));
+  if (fresh) {  // a fresh slab is known to be untouched everywhere: nothing to read
 #pragma unroll
-  for (int k = 0; k < BZ; ++k) {
-    const int zl = min(zl0 + k, g.nz_local - 1);
-    // a fresh slab is known to be untouched everywhere: nothing to read
-    s[k] = fresh ? kInvalidSdf : g.sdf[(int64_t)zl * slice + col];
-    n[k] = fresh ? 0 : (int)cnt[(int64_t)zl * slice + col];
+    for (int k = 0; k < WX; ++k) {
+      s[k] = kInvalidSdf;
+      n[k] = 0;
+    }
+  } else if (vec_io) {
+    const float4 a = *(const float4*)(g.sdf + row0 + x_first), b4 = *(const float4*)(g.sdf + row0 + x_first + 4);
+    const CountVec cv = *(const CountVec*)(cnt + row0 + x_first);
+    s[0] = a.x, s[1] = a.y, s[2] = a.z, s[3] = a.w, s[4] = b4.x, s[5] = b4.y, s[6] = b4.z, s[7] = b4.w;
+#pragma unroll
+    for (int k = 0; k < WX; ++k) n[k] = (int)cv[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < WX; ++k) {
+      const int xk = min(x_first + k, g.nx - 1);
+      s[k] = g.sdf[row0 + xk];
+      n[k] = (int)cnt[row0 + xk];
+    }
   }
 
   // views that may still change something, as a wave-uniform bit mask
@@ -553,11 +574,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
       if (UPDATE == VCY_UPDATE_MAX) {
         float m = s[0];
 #pragma unroll
-        for (int k = 1; k < BZ; ++k) m = fminf(m, s[k]);
+        for (int k = 1; k < WX; ++k) m = fminf(m, s[k]);
         if (!all_touched) {  // update_num never decreases: once every voxel is touched it stays so
           int nmin = n[0];
 #pragma unroll
-          for (int k = 1; k < BZ; ++k) nmin = min(nmin, n[k]);
+          for (int k = 1; k < WX; ++k) nmin = min(nmin, n[k]);
           all_touched = __all(nmin >= 1);
         }
         const float smin = wave_min(m);
@@ -580,7 +601,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
   // ---- views ------------------------------------------------------------------------------
   while (vi < nviews) {
     const ViewParams& v = views[vi].v;
-    cfloat_ptr c2 = (cfloat_ptr)(c2_all + (size_t)vi * 3 * g.nz_local);
+    cfloat_ptr c0 = (cfloat_ptr)(c0_all + (size_t)vi * 3 * nxp) + x_first;  // rows i at c0 + i * nxp, entry k = voxel k
     // stage this view's tile (wave-private: program order is enough)
     wave_lds_fence();
     if (kPrefetch) {
@@ -599,8 +620,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
     const float pitchf = tinfo[vi].pitchf;
     const int base = tinfo[vi].base;
     const bool is_ortho = GEN && mode.ortho != 0, is_nn = GEN && mode.interp == VCY_INTERP_NN;
-    const float c0x = v.r[0][0] * px, c0y = v.r[1][0] * px, c0z = v.r[2][0] * px;
-    const float c1x = v.r[0][1] * py, c1y = v.r[1][1] * py, c1z = v.r[2][1] * py;
+    // c1 + c2 of this lane's (y, z): the inner sum of pc = t + (c0 + (c1 + c2)) (voxel_carver.cc:453)
+    const float h12x = v.r[0][1] * py + v.r[0][2] * pz, h12y = v.r[1][1] * py + v.r[1][2] * pz;
+    const float h12z = v.r[2][1] * py + v.r[2][2] * pz;
 
     // Straight-line fast path for the 8 voxels of this thread (no divergent control flow, so
     // the eight LDS reads and the arithmetic interleave); voxels the tile does not cover are
@@ -608,16 +630,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
     // brick samples inside this tile (TileInfo::sure), so the per-voxel tests are compiled out.
     auto carve_view = [&](auto sure_tag) {
       constexpr bool SURE = decltype(sure_tag)::value;
-      bool slow[BZ];
+      bool slow[WX];
       bool any_slow = false;
       // Two voxels (k, k+1) share the packed-FP32 instructions of the depth and of the divide;
       // within a voxel the (x, y) pair and the (1-l, l) weight pairs are packed.  Every single
       // operation is still the reference's, in its order (v_pk_* are two independent fp32 ops).
 #pragma unroll
-      for (int kp = 0; kp < BZ; kp += 2) {
-        const int zla = min(zl0 + kp, g.nz_local - 1), zlb = min(zl0 + kp + 1, g.nz_local - 1);
-        const f2 c2z = {c2[2 * g.nz_local + zla], c2[2 * g.nz_local + zlb]};
-        const f2 pcz2 = v.t[2] + (c0z + (c1z + c2z));
+      for (int kp = 0; kp < WX; kp += 2) {
+        const f2 c0z = {c0[2 * nxp + kp], c0[2 * nxp + kp + 1]};
+        const f2 pcz2 = v.t[2] + (c0z + h12z);
         // pinhole: u = fx / z * x + cx (camera.cc:133-136); orthographic: u = x (camera.cc:201-205)
         f2 qx2 = {1.0f, 1.0f}, qy2 = {1.0f, 1.0f};
         if (!is_ortho) {
@@ -627,9 +648,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int k = kp + h;
-          const int zl = h ? zlb : zla;
           const float pcz = h ? pcz2.y : pcz2.x;
-          const f2 pcxy = (f2){v.t[0], v.t[1]} + ((f2){c0x, c0y} + ((f2){c1x, c1y} + (f2){c2[zl], c2[g.nz_local + zl]}));
+          const f2 pcxy = (f2){v.t[0], v.t[1]} + ((f2){c0[k], c0[nxp + k]} + (f2){h12x, h12y});
           const f2 uw = is_ortho ? pcxy : (f2){h ? qx2.y : qx2.x, h ? qy2.y : qy2.x} * pcxy + (f2){v.cx, v.cy};
           const float u = uw.x, w = uw.y;
           bool in_tile = true;
@@ -664,11 +684,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
       }
       if (!SURE && any_slow) {
 #pragma unroll
-        for (int k = 0; k < BZ; ++k) {
+        for (int k = 0; k < WX; ++k) {
           if (slow[k]) {
-            const int zl = min(zl0 + k, g.nz_local - 1);
             float dist = 0.0f;
-            bool ok = sample_generic(&v, mode, px, py, g.pz[g.z0 + zl], &dist);
+            bool ok = sample_generic(&v, mode, g.px[min(x_first + k, g.nx - 1)], py, pz, &dist);
             if (CHECKMAX) ok = ok && !(n[k] > g.max_update_num);
             apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]);
           }
@@ -691,15 +710,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
   }
 
   // ---- write back what changed (update_num grows with every change) ----------------------------
-  if (col_valid) {
+  if (lane_valid) {
+    if (vec_io) {
+      bool changed = fresh != 0;  // (a fresh slab has never been written: every voxel is stored)
+      if (!fresh) {
+        const CountVec cv = *(const CountVec*)(cnt + row0 + x_first);
 #pragma unroll
-    for (int k = 0; k < BZ; ++k) {
-      if (zl0 + k < g.nz_local) {
-        const int64_t idx = (int64_t)(zl0 + k) * slice + col;
-        // (a fresh slab has never been written: every voxel is stored)
-        if (fresh || n[k] != (int)cnt[idx]) {
-          g.sdf[idx] = s[k];
-          cnt[idx] = (CountT)n[k];
+        for (int k = 0; k < WX; ++k) changed = changed || n[k] != (int)cv[k];
+      }
+      if (changed) {
+        *(float4*)(g.sdf + row0 + x_first) = make_float4(s[0], s[1], s[2], s[3]);
+        *(float4*)(g.sdf + row0 + x_first + 4) = make_float4(s[4], s[5], s[6], s[7]);
+        CountVec cv;
+#pragma unroll
+        for (int k = 0; k < WX; ++k) cv[k] = (CountT)n[k];
+        *(CountVec*)(cnt + row0 + x_first) = cv;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < WX; ++k) {
+        if (x_first + k < g.nx) {
+          const int64_t idx = row0 + x_first + k;
+          if (fresh || n[k] != (int)cnt[idx]) {
+            g.sdf[idx] = s[k];
+            cnt[idx] = (CountT)n[k];
+          }
         }
       }
     }
@@ -772,12 +807,13 @@ bool fused_eligible(const vcy_ctx* c, int n_views, const vcy_view* views) {
 int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewParams* vp) {
   const vcy_update_option& u = c->opt.update_option;
   const int nzl = c->nz_local();
-  // per-view tables c2[i][zl] = R[i][2] * pz[z0+zl]
-  std::vector<float> c2((size_t)n_views * 3 * nzl);
+  // per-view tables c0[i][x] = R[i][0] * px[x], padded to whole bricks with the last column
+  const int nxp = (c->nx + WX - 1) / WX * WX;
+  std::vector<float> c2((size_t)n_views * 3 * nxp);
   for (int vi = 0; vi < n_views; ++vi)
     for (int i = 0; i < 3; ++i)
-      for (int zl = 0; zl < nzl; ++zl)
-        c2[((size_t)vi * 3 + i) * nzl + zl] = vp[vi].r[i][2] * c->h_pz[c->z0 + zl];
+      for (int x = 0; x < nxp; ++x)
+        c2[((size_t)vi * 3 + i) * nxp + x] = vp[vi].r[i][0] * c->h_px[std::min(x, c->nx - 1)];
   const size_t c2_bytes = c2.size() * sizeof(float);
   const size_t fv_bytes = sizeof(FusedView) * (size_t)n_views;
   // staging buffer owned by the context, grown on demand

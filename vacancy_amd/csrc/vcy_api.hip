@@ -209,6 +209,8 @@ int vcy_create(const vcy_carver_option* o, int device_id, int z_begin, int z_end
       p[i] = diff * (static_cast<float>(i) / static_cast<float>(n[a])) + o->bb_min[a] + offset;
     VCY_TRY(hipMemcpy(d_axis[a], p.data(), sizeof(float) * n[a], hipMemcpyHostToDevice));
     if (a == 0) {
+      c->h_px = new float[n[0]];
+      std::memcpy(c->h_px, p.data(), sizeof(float) * n[0]);
       c->h_px_min = p.front();
       c->h_px_max = p.back();
     } else if (a == 1) {
@@ -255,6 +257,7 @@ void vcy_destroy(vcy_ctx* c) {
   for (auto& t : c->sdf_pool) (void)hipFree(t.first);
   (void)hipFree(c->d_sil_scratch);
   delete[] c->h_pz;
+  delete[] c->h_px;
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
