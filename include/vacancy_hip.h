@@ -130,8 +130,10 @@ int vcy_carve(vcy_ctx* ctx, const vcy_view* view, const float* sdf_host);
 int vcy_carve_device(vcy_ctx* ctx, const vcy_view* view, const float* sdf_device);
 /* Replaces the loop of Carve(const std::vector<Camera>&, ...)
  * (voxel_carver.cc:516-528) for pre-built SDFs: fuses `n_views` views in
- * sequence order with the voxel state held in registers across views.  The
- * result is bit-identical to n_views calls of vcy_carve_device. */
+ * sequence order with the voxel state held in registers across views (up to 64
+ * views per kernel launch, more are split).  The result is bit-identical to
+ * n_views calls of vcy_carve_device.  The images are read while the launch runs:
+ * keep them unchanged until the context's stream has passed this call. */
 int vcy_carve_batch_device(vcy_ctx* ctx, int n_views, const vcy_view* views,
                            const float* const* sdf_device);
 /* Replaces bool VoxelCarver::Carve(const Camera&, const Image1b& silhouette,
