@@ -235,7 +235,11 @@ int vcy_reset(vcy_ctx* ctx);
  * and queue the view; queued views are carved together, in call order, by one fused launch when the
  * state is next needed (extraction, download, upload, halo, vcy_sync, vcy_timer_end, a batch call) or
  * when 32 wait, so the reference's `for each view: Carve()` loop costs one pass over the grid instead of
- * one per view.  0 carves every view before its call returns.  vcy_reset drops queued views. */
+ * one per view.  0 carves every view before its call returns.  vcy_reset drops queued views.
+ * "shortdiv" (default 1): fx / z in the fused kernel may use a 4- or 6-instruction sequence instead of
+ * the full IEEE expansion, but only after the library has checked on the device, for each focal length
+ * in use, that the sequence equals IEEE division for EVERY admissible depth (all 2^23 significands in 121
+ * binades, about a millisecond once per focal length per process). */
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all launches. */
 int vcy_set_stream(vcy_ctx* ctx, void* hip_stream);

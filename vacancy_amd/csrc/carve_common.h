@@ -33,6 +33,7 @@ struct GridParams {
 
 struct ModeParams {
   int update, interp, outside, trunc, ortho;
+  int div_level;  // host side only: which division sequence the fused kernel is instantiated with
 };
 
 // ---- sampling, shared by every carve kernel --------------------------------------------

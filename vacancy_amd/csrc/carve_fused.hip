@@ -27,6 +27,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <type_traits>
 #include <vector>
 
@@ -98,6 +101,36 @@ __device__ __forceinline__ f2 div_fast2(float n, f2 d) {
   q = __builtin_elementwise_fma(e2, r, q);
   const f2 e3 = __builtin_elementwise_fma(-d, q, nn);
   return __builtin_elementwise_fma(e3, r, q);
+}
+
+// Shorter sequences for n / d.  They are NOT correct for every pair of floats, but for a given numerator
+// they usually are for EVERY denominator: the host checks that exhaustively on the device, once per
+// focal length (div_level below: all 2^23 significands in each of the 121 binades [2^-60, 2^61) the fast
+// path admits), and only then selects the variant.  DIV 2: v_rcp_f32, one multiply, one correction;
+// DIV 1: Newton step on the reciprocal first; DIV 0: the full IEEE expansion (div_fast2).
+template <int DIV>
+__device__ __forceinline__ f2 div_view2(float n, f2 d) {
+  if (DIV == 0) return div_fast2(n, d);
+  const f2 nn = {n, n}, one = {1.0f, 1.0f};
+  f2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  if (DIV == 1) {
+    const f2 e = __builtin_elementwise_fma(-d, r, one);
+    r = __builtin_elementwise_fma(e, r, r);
+  }
+  const f2 q = nn * r;
+  const f2 e2 = __builtin_elementwise_fma(-d, q, nn);
+  return __builtin_elementwise_fma(e2, r, q);
+}
+
+__device__ __forceinline__ float div_view1(int div, float n, float d) {  // scalar twin, for the checker
+  float r = __builtin_amdgcn_rcpf(d);
+  if (div == 1) {
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+  }
+  const float q = n * r;
+  const float e2 = __builtin_fmaf(-d, q, n);
+  return __builtin_fmaf(e2, r, q);
 }
 
 // 2^-60 <= z <= 2^60 (also false for negative z, NaN, inf, 0)
@@ -472,7 +505,7 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
 
 // GEN: nearest-neighbour sampling and/or an orthographic camera, selected at run time from `mode`
 // (compiled out of the default bilinear + pinhole kernels, where the extra branches cost 16 %).
-template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX, int TQ, bool GEN>
+template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX, int TQ, bool GEN, int DIV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void carve_fused_kernel(GridParams g,
                                                           const FusedView* __restrict__ views,
                                                           const float* __restrict__ c0_all,
@@ -642,8 +675,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
         // pinhole: u = fx / z * x + cx (camera.cc:133-136); orthographic: u = x (camera.cc:201-205)
         f2 qx2 = {1.0f, 1.0f}, qy2 = {1.0f, 1.0f};
         if (!is_ortho) {
-          qx2 = div_fast2(v.fx, pcz2);
-          qy2 = SAMEF ? qx2 : div_fast2(v.fy, pcz2);
+          qx2 = div_view2<DIV>(v.fx, pcz2);
+          qy2 = SAMEF ? qx2 : div_view2<DIV>(v.fy, pcz2);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -745,13 +778,16 @@ template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF>
 void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const GridParams& g, const FusedView* dv,
                     const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh) {
   const bool gen = m.ortho != 0 || m.interp == VCY_INTERP_NN;
-#define VCY_FUSED(CM, TQ_, GEN_)                                                                            \
-  hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, CM, TQ_, GEN_>), grid, dim3(256),   \
-                     (size_t)4 * TQ_ * sizeof(float4) + (size_t)4 * nv * sizeof(TileInfo), s,              \
+#define VCY_FUSED(CM, TQ_, GEN_, DIV_)                                                                           \
+  hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, CM, TQ_, GEN_, DIV_>), grid, dim3(256),     \
+                     (size_t)4 * TQ_ * sizeof(float4) + (size_t)4 * nv * sizeof(TileInfo), s,                    \
                      g, dv, c2, nv, m, nbx, nby, cull, fresh)
-#define VCY_FUSED_G(CM, TQ_)                                                                                \
-  do {                                                                                                      \
-    if (gen) VCY_FUSED(CM, TQ_, true); else VCY_FUSED(CM, TQ_, false);                                    \
+#define VCY_FUSED_G(CM, TQ_)                                                                                     \
+  do {                                                                                                           \
+    if (gen) VCY_FUSED(CM, TQ_, true, 0);                                                                        \
+    else if (m.div_level == 2) VCY_FUSED(CM, TQ_, false, 2);                                                     \
+    else if (m.div_level == 1) VCY_FUSED(CM, TQ_, false, 1);                                                     \
+    else VCY_FUSED(CM, TQ_, false, 0);                                                                           \
   } while (0)
   if (big) {
     if (checkmax) VCY_FUSED_G(true, kTileBig); else VCY_FUSED_G(false, kTileBig);
@@ -783,6 +819,51 @@ void launch_fused_1(bool big, int update, bool trunc, bool samef, bool checkmax,
     launch_fused_2<CountT, kUpdateWaUnitWeight>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
   else
     launch_fused_2<CountT, VCY_UPDATE_WEIGHTED_AVERAGE>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
+}
+
+// Exhaustive check of the short division sequences for ONE numerator: every significand of the
+// denominator (blockIdx.x * 256 + threadIdx.x) in every binade 2^-60 .. 2^60 (blockIdx.y) the fast path
+// admits (in_fast_div_range), against the IEEE quotient.  bad[0]: DIV 2 differs somewhere, bad[1]: DIV 1.
+__global__ __launch_bounds__(256) void div_verify_kernel(float n, unsigned* __restrict__ bad) {
+  const unsigned sig = blockIdx.x * 256u + threadIdx.x;
+  const unsigned expo = 127u - 60u + blockIdx.y;
+  const float d = __uint_as_float((expo << 23) | sig);
+  const float ref = n / d;  // -fhip-fp32-correctly-rounded-divide-sqrt
+  const bool b2 = div_view1(2, n, d) != ref, b1 = div_view1(1, n, d) != ref;
+  if (__any(b2) && (threadIdx.x & 63) == 0) atomicOr(&bad[0], 1u);
+  if (__any(b1) && (threadIdx.x & 63) == 0) atomicOr(&bad[1], 1u);
+}
+
+std::mutex g_div_mutex;
+std::map<std::pair<int, uint32_t>, int> g_div_cache;  // (device, numerator bits) -> level
+
+// 2, 1 or 0: the shortest sequence of div_view2 that equals IEEE division by every admissible depth for
+// this numerator on this device.  ~1 G cases, about a millisecond, once per distinct focal length.
+int div_level(vcy_ctx* c, float n) {
+  uint32_t bits;
+  std::memcpy(&bits, &n, 4);
+  const std::pair<int, uint32_t> key(c->device, bits);
+  std::lock_guard<std::mutex> lock(g_div_mutex);
+  auto it = g_div_cache.find(key);
+  if (it != g_div_cache.end()) return it->second;
+  int level = 0;
+  unsigned* d_bad = nullptr;
+  unsigned h_bad[2] = {1u, 1u};
+  if (hipMalloc(&d_bad, 2 * sizeof(unsigned)) == hipSuccess) {
+    hipError_t e = hipMemsetAsync(d_bad, 0, 2 * sizeof(unsigned), c->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(div_verify_kernel, dim3((1u << 23) / 256u, 121u), dim3(256), 0, c->stream, n, d_bad);
+      e = hipMemcpyAsync(h_bad, d_bad, sizeof(h_bad), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_bad);
+    if (e == hipSuccess) level = h_bad[0] == 0 ? 2 : (h_bad[1] == 0 ? 1 : 0);
+    else (void)hipGetLastError();
+  } else {
+    (void)hipGetLastError();
+  }
+  g_div_cache[key] = level;
+  return level;
 }
 
 bool sane(float f) { return f >= 0x1p-40f && f <= 0x1p40f; }
@@ -925,7 +1006,16 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     set_error("slab too large for one launch");
     return VCY_ERR_TOO_MANY_VOXELS;
   }
-  ModeParams m{u.voxel_update, u.sdf_interp, u.update_outside, u.use_truncation ? 1 : 0, c->fused_ortho ? 1 : 0};
+  ModeParams m{u.voxel_update, u.sdf_interp, u.update_outside, u.use_truncation ? 1 : 0, c->fused_ortho ? 1 : 0, 0};
+  // shortest division sequence that is exact for every focal length of this batch (checked on the device)
+  if (!c->fused_ortho && c->use_short_div) {
+    int level = 2;
+    for (int vi = 0; vi < n_views && level > 0; ++vi) {
+      level = std::min(level, div_level(c, vp[vi].fx));
+      if (vp[vi].fy != vp[vi].fx && level > 0) level = std::min(level, div_level(c, vp[vi].fy));
+    }
+    m.div_level = level;
+  }
   // update_num can only exceed voxel_max_update_num after more than that many views
   const bool checkmax = c->views_carved + n_views > (int64_t)u.voxel_max_update_num;
   const dim3 grid((unsigned)nblocks);

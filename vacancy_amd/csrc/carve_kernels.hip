@@ -198,7 +198,7 @@ int launch_carve(vcy_ctx* c, int n_views, const vcy_view* views, const float* co
   } else {
     for (int i = 0; i < n_views; ++i) {
       ModeParams m{u.voxel_update, u.sdf_interp, u.update_outside, u.use_truncation ? 1 : 0,
-                   views[i].is_ortho ? 1 : 0};
+                   views[i].is_ortho ? 1 : 0, 0};
       if (c->cnt_bytes == 1) launch_view<uint8_t>(c, g, vp[i], m);
       else if (c->cnt_bytes == 2) launch_view<uint16_t>(c, g, vp[i], m);
       else launch_view<uint32_t>(c, g, vp[i], m);

@@ -306,6 +306,10 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
     c->tile_mode = value;
     return VCY_OK;
   }
+  if (std::strcmp(name, "shortdiv") == 0) {
+    c->use_short_div = value != 0;
+    return VCY_OK;
+  }
   if (std::strcmp(name, "cull") == 0) {
     c->use_cull = value != 0;
     return VCY_OK;
