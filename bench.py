@@ -288,7 +288,9 @@ def main():
                                % (n, nv, args.width, args.height, args.mode, world),
                    "grid": n, "views": nv, "image": [args.width, args.height], "mode": args.mode,
                    "fused_views_per_launch": views_per_launch, "view_dropping": bool(args.cull),
-                   "slabs_per_gpu": k_slabs},
+                   "slabs_per_gpu": k_slabs,
+                   "division": {2: "rcp + 3 (verified for this focal length)", 1: "rcp + 5 (verified)",
+                                0: "full IEEE expansion"}.get(dev.get_param("div_level"), "?")},
         "roofline": roofline, "mc": mc,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

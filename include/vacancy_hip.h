@@ -241,6 +241,9 @@ int vcy_reset(vcy_ctx* ctx);
  * in use, that the sequence equals IEEE division for EVERY admissible depth (all 2^23 significands in 121
  * binades, about a millisecond once per focal length per process). */
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
+/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv"), or "div_level": the division sequence
+ * the last fused launch was instantiated with (2: 4 instructions, 1: 6, 0: full IEEE expansion). */
+int vcy_get_param(vcy_ctx* ctx, const char* name, int* value);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all launches. */
 int vcy_set_stream(vcy_ctx* ctx, void* hip_stream);
 int vcy_get_stream(vcy_ctx* ctx, void** hip_stream_out);

@@ -608,3 +608,35 @@ def test_batches_of_up_to_64_views_in_one_launch(mode):
         for p in d:
             dev.free_device(p)
         dev.close()
+
+
+def test_short_division_is_only_used_when_verified():
+    """fx / z in the fused kernel: the 4- / 6-instruction sequences are selected per focal length after an
+    exhaustive device check; results equal the full sequence ("shortdiv" 0) and the oracle for focal
+    lengths that pass either check and for ones that fall back."""
+    n, nv = 32, 5
+    opt = synth.sphere_option(n)
+    views, masks = synth.sphere_views(n, nv, 96, 72)
+    sdfs = [O.make_sdf(m) for m in masks]
+    levels = set()
+    rng = np.random.RandomState(11)
+    for trial in range(12):
+        f = np.float32(rng.uniform(60, 140))
+        for v in views:
+            v.fx = v.fy = float(f)
+        orc = O.OracleGrid(opt)
+        for v, s in zip(views, sdfs):
+            orc.carve(v, s)
+        for short in (1, 0):
+            dev = vc.VoxelCarver(opt)
+            assert dev.Init(), vc.last_error()
+            dev.set_param("shortdiv", short)
+            d = [dev.upload_sdf(s) for s in sdfs]
+            assert dev.CarveBatchDevice(views, d), vc.last_error()
+            lvl = dev.get_param("div_level")
+            assert (lvl == 0) if not short else lvl in (0, 1, 2)
+            if short:
+                levels.add(lvl)
+            assert_state_equal(dev, orc, "f=%r shortdiv=%d level=%d" % (float(f), short, lvl))
+            dev.close()
+    assert 2 in levels  # the common case

@@ -143,6 +143,7 @@ def load():
         "vcy_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_int64]),
         "vcy_reset": (C.c_int, [vp]),
         "vcy_set_param": (C.c_int, [vp, C.c_char_p, C.c_int]),
+        "vcy_get_param": (C.c_int, [vp, C.c_char_p, P(C.c_int)]),
         "vcy_set_stream": (C.c_int, [vp, vp]),
         "vcy_get_stream": (C.c_int, [vp, P(vp)]),
         "vcy_sync": (C.c_int, [vp]),

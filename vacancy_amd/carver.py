@@ -252,6 +252,11 @@ class VoxelCarver:
     def set_param(self, name, value):
         assert self._lib.vcy_set_param(self._ctx, name.encode(), int(value)) == 0, last_error()
 
+    def get_param(self, name):
+        v = C.c_int()
+        assert self._lib.vcy_get_param(self._ctx, name.encode(), C.byref(v)) == 0, last_error()
+        return v.value
+
     def reset(self):
         """Back to the state right after Init(): sdf = lowest(), update_num = 0."""
         assert self._lib.vcy_reset(self._ctx) == 0, last_error()

@@ -1016,6 +1016,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     }
     m.div_level = level;
   }
+  c->last_div_level = m.div_level;
   // update_num can only exceed voxel_max_update_num after more than that many views
   const bool checkmax = c->views_carved + n_views > (int64_t)u.voxel_max_update_num;
   const dim3 grid((unsigned)nblocks);

@@ -318,6 +318,21 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
   return VCY_ERR_INVALID_ARG;
 }
 
+int vcy_get_param(vcy_ctx* c, const char* name, int* value) {
+  if (!c || !name || !value) return VCY_ERR_INVALID_ARG;
+  if (std::strcmp(name, "fused") == 0) *value = c->use_fused ? 1 : 0;
+  else if (std::strcmp(name, "cull") == 0) *value = c->use_cull ? 1 : 0;
+  else if (std::strcmp(name, "tile") == 0) *value = c->tile_mode;
+  else if (std::strcmp(name, "defer") == 0) *value = c->defer ? 1 : 0;
+  else if (std::strcmp(name, "shortdiv") == 0) *value = c->use_short_div ? 1 : 0;
+  else if (std::strcmp(name, "div_level") == 0) *value = c->last_div_level;
+  else {
+    set_error("unknown parameter %s", name);
+    return VCY_ERR_INVALID_ARG;
+  }
+  return VCY_OK;
+}
+
 int vcy_get_stream(vcy_ctx* c, void** out) {
   if (!c || !out) return VCY_ERR_INVALID_ARG;
   *out = (void*)c->stream;

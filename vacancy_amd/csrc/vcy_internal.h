@@ -81,6 +81,7 @@ struct vcy_ctx {
   void* d_sil_scratch = nullptr;      // staging of vcy_carve_silhouette (mask + transform scratch)
   size_t sil_scratch_bytes = 0;
   bool defer = true;                  // vcy_set_param("defer", 0): apply every view at once
+  int last_div_level = 0;             // division variant of the last fused launch (vcy_get_param "div_level")
   bool use_short_div = true;          // vcy_set_param("shortdiv", 0): always the full division sequence
   bool use_fused = true;              // vcy_set_option("fused", 0) forces the per-view kernel
   float* h_px = nullptr;              // host copy of the x axis table (c0 tables of the fused carve)
