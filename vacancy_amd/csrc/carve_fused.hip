@@ -174,11 +174,12 @@ __device__ __forceinline__ float rcp_count(float m) {
 // Branch-free voxel update (select form of fuse() in carve_common.h): first touch
 // (voxel_carver.cc:482-486), UpdateVoxelMax (:78-86) or UpdateVoxelWeightedAverage (:88-95).
 template <int UPDATE>
-__device__ __forceinline__ void apply_sample(bool ok, float dist, float wgt, float& s, int& n) {
+__device__ __forceinline__ bool apply_sample(bool ok, float dist, float wgt, float& s, int& n) {
   if (UPDATE == VCY_UPDATE_MAX) {
     const bool take = ok && (n < 1 || dist > s);
     s = take ? dist : s;
     n += take ? 1 : 0;
+    return take;
   } else if (UPDATE == kUpdateWaUnitWeight) {
     // voxel_update_weight == 1: w * x == x exactly, and the denominator is the integer n + 1
     const float inv_denom = rcp_count((float)(n + 1));
@@ -193,6 +194,7 @@ __device__ __forceinline__ void apply_sample(bool ok, float dist, float wgt, flo
     s = ok ? ns : s;
     n += ok ? 1 : 0;
   }
+  return ok;
 }
 
 // q / d for 0 <= q < 4096, 1 <= d <= 1024, given inv = 1.0f / d: (q + 0.5) / d is never within
@@ -665,6 +667,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
       constexpr bool SURE = decltype(sure_tag)::value;
       bool slow[WX];
       bool any_slow = false;
+      bool moved = false;  // some voxel of this lane changed
       // Two voxels (k, k+1) share the packed-FP32 instructions of the depth and of the divide;
       // within a voxel the (x, y) pair and the (1-l, l) weight pairs are packed.  Every single
       // operation is still the reference's, in its order (v_pk_* are two independent fp32 ops).
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
           bool ok = in_tile;
           if (TRUNC) ok = ok && !(dist < -1.0f);
           if (CHECKMAX) ok = ok && !(n[k] > g.max_update_num);
-          apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]);
+          moved = apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]) || moved;
         }
       }
       if (!SURE && any_slow) {
@@ -722,16 +725,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
             float dist = 0.0f;
             bool ok = sample_generic(&v, mode, g.px[min(x_first + k, g.nx - 1)], py, pz, &dist);
             if (CHECKMAX) ok = ok && !(n[k] > g.max_update_num);
-            apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]);
+            moved = apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]) || moved;
           }
         }
       }
+      return __any(moved);
     };
-    if (!GEN && __builtin_amdgcn_readfirstlane(tinfo[vi].sure) != 0) carve_view(std::true_type{});
-    else carve_view(std::false_type{});
+    bool brick_moved;
+    if (!GEN && __builtin_amdgcn_readfirstlane(tinfo[vi].sure) != 0) brick_moved = carve_view(std::true_type{});
+    else brick_moved = carve_view(std::false_type{});
 
     // state moved: some of the remaining views may have become droppable (min(sdf) only grows)
-    if (want_bound && UPDATE == VCY_UPDATE_MAX) {
+    // (an unchanged brick leaves every bound comparison as it was)
+    if (want_bound && UPDATE == VCY_UPDATE_MAX && brick_moved) {
       live = live_views();
       const int v2 = next_view(live, vi);
       if (v2 != vnext) {
