@@ -7,6 +7,13 @@ BASELINE.json configs[2]/[3]: 1024^3 voxels x 32 views at 1280x720, default upda
 bilinear); with --gpus G the grid is sharded by z-slab across G ranks (one process per GPU,
 no collective in the carve path, so total work is fixed: strong scaling).
 
+`python bench.py --gpus N` works from a plain shell: without WORLD_SIZE in the environment and
+N > 1 the script re-executes itself under `torch.distributed.run --nproc-per-node N` (one process
+per GPU).  The driver's own `python -m torch.distributed.run ... bench.py --gpus N` form is the same
+code path.  The only collective of the path -- the halo all-gather before marching cubes -- goes
+through RCCL (backend "nccl"); if RCCL cannot initialise the run FAILS unless --allow-gloo is given,
+and the JSON line records which backend and how many ranks the collective saw ("collective").
+
 Prints ONE JSON line (rank 0).  value = whole-job Mvoxel*views/s.  The marching-cubes rate
 (Mcells/s) is measured after the timed region and reported in the same line under "mc".
 """
@@ -14,20 +21,24 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+N_SIMD = 256 * 4          # 256 CUs x 4 SIMD-32
+CLOCK_HZ = 2.4e9          # max shader clock (same guide); the effective clock under load is lower
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=int, default=1024)
     ap.add_argument("--views", type=int, default=32)
     ap.add_argument("--width", type=int, default=1280)
@@ -44,8 +55,16 @@ def parse():
                          "the data-dependent cost of view dropping)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the extra measurements of the same kernel without view dropping and in TSDF mode")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    a = ap.parse_args()
+    ap.add_argument("--allow-gloo", action="store_true",
+                    help="let the halo exchange fall back to gloo (host staging) when RCCL cannot initialise; "
+                         "without this flag that is a failure")
+    ap.add_argument("--plumbing-check", action="store_true",
+                    help="no GPU work: launch, rendezvous and the halo all-gather of this configuration with "
+                         "rank-stamped host buffers (CPU test of the multi-rank launch path)")
+    a = ap.parse_args(argv)
     if a.config == 1:
         a.grid, a.views, a.width, a.height, a.mode = 512, 16, 640, 480, "tsdf"
     elif a.config in (2, 3):
@@ -55,18 +74,22 @@ def parse():
     return a
 
 
-def cpu_baseline(args, views, sdfs, budget_s):
-    """Times the CPU oracle (faithful restatement of the reference's OpenMP loop, AoS 40-byte
-    voxels) on a bounded sample of the same workload: a (grid/4)^3... sub-sampled grid with the
-    same bounding box, cameras and SDF images, as many views as fit the time budget."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-    from vacancy_amd import synth
-    from vacancy_amd.capi import UpdateOption
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain shell: one process per GPU under torch.distributed.run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
-    lib = O.load()
-    # host cores this process may really use: the cgroup CPU quota, not nproc (oversubscribing a
-    # throttled container makes the OpenMP loop 10x slower than it is)
+
+def usable_cores():
+    """Host cores this process may really use: the cgroup CPU quota, not nproc (oversubscribing a
+    throttled container makes the OpenMP loop 10x slower than it is)."""
     usable = os.cpu_count() or 1
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
@@ -74,8 +97,22 @@ def cpu_baseline(args, views, sdfs, budget_s):
             usable = max(1, min(usable, int(round(int(quota) / float(period)))))
     except Exception:
         pass
-    if "OMP_NUM_THREADS" in os.environ:
-        usable = int(os.environ["OMP_NUM_THREADS"])
+    return usable
+
+
+def cpu_baseline(args, views, sdfs, budget_s):
+    """Times the CPU oracle (faithful restatement of the reference's OpenMP loop, AoS 40-byte
+    voxels) on a bounded sample of the same workload: a coarser grid over the same bounding box,
+    cameras and SDF images, as many views as fit the time budget."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from vacancy_amd import synth
+    from vacancy_amd.capi import UpdateOption
+
+    lib = O.load()
+    usable = usable_cores()
+    if "VCY_CPU_THREADS" in os.environ:
+        usable = int(os.environ["VCY_CPU_THREADS"])
     lib.orc_set_num_threads(usable)
     n_cpu = min(args.grid, 512)
     uo = UpdateOption(voxel_update=1, use_truncation=True, truncation_band=0.1) if args.mode == "tsdf" \
@@ -103,58 +140,134 @@ def cpu_baseline(args, views, sdfs, budget_s):
         del g1
     finally:
         lib.orc_set_num_threads(usable)
-    t0 = time.time()
     mesh = g.marching_cubes(0.0, True)
     mc_s = mesh["ms"] / 1e3
     cells = (g.dims[0] - 1) * (g.dims[1] - 1) * (g.dims[2] - 1)
     threads = lib.orc_omp_max_threads()
+    extrapolated = n_cpu != args.grid
     return {
         "value": round(g.n * n_done / t_total / 1e6, 2),
         "unit": "Mvoxel*views/s",
         "cores": int(threads),
         "kind": "port",
+        "extrapolated": extrapolated,
         "single_thread_value": single,
-        "sample": "oracle (OpenMP over z, %d threads = usable host cores of %d visible), %d^3 grid over the same "
-                  "scene, %d of %d views at %dx%d; times the Carve main loop only (reference "
+        "sample": "%soracle (OpenMP over z, %d threads = usable host cores of %d visible) on a %d^3 grid over the "
+                  "same scene (the rate per voxel*view is what is reported; the %d^3 AoS grid of the reference "
+                  "needs 43 GB), %d of %d views at %dx%d; times the Carve main loop only (reference "
                   "voxel_carver.cc:435,492)"
-                  % (threads, os.cpu_count() or 1, n_cpu, n_done, len(views), args.width, args.height),
+                  % ("EXTRAPOLATED from a smaller grid: " if extrapolated else "", threads, os.cpu_count() or 1,
+                     n_cpu, args.grid, n_done, len(views), args.width, args.height),
         "mc_mcells_per_s": round(cells / mc_s / 1e6, 2),
         "mc_sample": "oracle MarchingCubes (serial std::map, like the reference) on the carved %d^3 grid" % n_cpu,
     }
 
 
+def load_counters(key):
+    """Per-launch hardware counters of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/counters.json, written by profiles/tools/summarize_pmc.py), or None."""
+    path = os.path.join(ROOT, "profiles", "counters.json")
+    try:
+        return json.load(open(path)).get(key)
+    except Exception:
+        return None
+
+
+def valu_issue_cycles(ctr):
+    """SIMD issue cycles of the VALU work of one launch: dynamic wave-instruction counts by class
+    (SQ_INSTS_VALU_*) x cycles per wave64 instruction on a SIMD-32 (MI355X_MICROARCH.md: 2 cycles
+    full rate; transcendentals quarter rate = 8; 64-bit integer and packed-fp32 pairs two passes = 4).
+    Instructions outside the measured classes count as full rate."""
+    if not ctr or "SQ_INSTS_VALU" not in ctr:
+        return None
+    total = ctr["SQ_INSTS_VALU"]
+    trans = ctr.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+    int64 = ctr.get("SQ_INSTS_VALU_INT64", 0.0)
+    packed = ctr.get("packed_f32_fraction", 0.0) * total   # static share of v_pk_*_f32 in the run loop
+    rest = max(0.0, total - trans - int64 - packed)
+    return 2.0 * rest + 8.0 * trans + 4.0 * int64 + 4.0 * packed
+
+
+def plumbing_check(args, rank, world, dist, backend):
+    """CPU-only check of the launch path: the halo all-gather of this configuration with host buffers."""
+    import numpy as np
+    import torch
+    from vacancy_amd import dist as vdist
+    n = args.grid
+    k = args.slabs_per_gpu if args.slabs_per_gpu > 0 else (1 if world == 1 else 2)
+    nbytes = 2 * n * n * 6  # two xy slices of (f32 sdf, u16 update_num)
+    slabs = vdist.slabs_of_rank(n, rank, world, k)
+    send = torch.from_numpy(np.concatenate([np.full(nbytes, s % 251, np.uint8) for s, _, _ in slabs]))
+    ok = True
+    if world > 1:
+        parts = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(parts, send)
+        flat = np.concatenate([p.numpy() for p in parts])
+        for s, _, _ in slabs:
+            if s > 0:
+                off = vdist._pack_offset(s - 1, world, k, nbytes)
+                ok = ok and bool((flat[off:off + nbytes] == (s - 1) % 251).all())
+        t = torch.tensor([1.0 if ok else 0.0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item() == 1.0)
+    if rank == 0:
+        print(json.dumps({"metric": "Mvoxel*views/s (Carve)", "value": None, "unit": "Mvoxel*views/s",
+                          "plumbing_check": True, "ok": ok, "n_gpus": world,
+                          "collective": {"backend": backend, "ranks": world, "bytes_per_rank": nbytes * k,
+                                         "op": "all_gather", "slabs_per_rank": k}}))
+    return 0 if ok else 1
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
     torch = None
     backend = os.environ.get("VCY_BENCH_BACKEND", "nccl")  # "gloo": debugging N ranks on one GPU
+    if args.plumbing_check:
+        backend = "gloo"
+    if backend != "nccl" and not (args.allow_gloo or args.plumbing_check):
+        raise SystemExit("bench: backend %s needs --allow-gloo (the halo exchange is an RCCL all-gather)" % backend)
     if "VCY_BENCH_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["VCY_BENCH_FORCE_DEVICE"])
+    backend_note = None
     if world > 1:
         import torch  # device plumbing + RCCL only
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         if backend == "nccl":
+            torch.cuda.set_device(local_rank)
             try:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
                 probe = torch.ones(1, device="cuda")
                 dist.all_reduce(probe)  # fail here, on every rank alike, rather than mid-benchmark
                 torch.cuda.synchronize()
-            except Exception as e:  # RCCL unusable in this environment: the carve path needs no collective,
-                # so keep measuring it; timing reductions and the halo exchange go through gloo instead
-                sys.stderr.write("bench: nccl backend failed (%s); falling back to gloo\n" % e)
+                if int(probe.item()) != world:
+                    raise RuntimeError("all_reduce over RCCL returned %r for %d ranks" % (probe.item(), world))
+            except Exception as e:
+                if not args.allow_gloo:
+                    sys.stderr.write("bench: RCCL (backend nccl) failed: %s\n" % e)
+                    raise SystemExit(3)
+                # explicitly allowed: the carve path needs no collective, so keep measuring it; the halo
+                # exchange and the timing reductions go through gloo and the JSON line says so
+                sys.stderr.write("bench: nccl backend failed (%s); --allow-gloo: falling back to gloo\n" % e)
+                backend_note = "nccl failed: %s" % str(e)[:200]
                 if dist.is_initialized():
                     dist.destroy_process_group()
                 backend = "gloo"
                 dist.init_process_group("gloo")
         else:
             dist.init_process_group(backend)
+    if args.plumbing_check:
+        rc = plumbing_check(args, rank, world, dist, backend)
+        if dist is not None:
+            dist.destroy_process_group()
+        raise SystemExit(rc)
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
     from vacancy_amd import carver as vc
@@ -163,8 +276,12 @@ def main():
     from vacancy_amd.capi import UpdateOption
 
     n, nv = args.grid, args.views
-    uo = UpdateOption(voxel_update=1, use_truncation=True, truncation_band=0.1) if args.mode == "tsdf" \
-        else UpdateOption()
+
+    def update_option(mode):
+        return UpdateOption(voxel_update=1, use_truncation=True, truncation_band=0.1) if mode == "tsdf" \
+            else UpdateOption()
+
+    uo = update_option(args.mode)
     opt = synth.sphere_option(n, uo)
     views, masks = synth.sphere_views(n, nv, args.width, args.height)
     sdf0 = vc.make_sdf(masks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
@@ -172,45 +289,50 @@ def main():
 
     k_slabs = args.slabs_per_gpu if args.slabs_per_gpu > 0 else (1 if world == 1 else 2)
     my_slabs = vdist.slabs_of_rank(n, rank, world, k_slabs)
-    devs = []
-    for _, z0, z1 in my_slabs:
-        c = vc.VoxelCarver(opt, device_id=local_rank, z_range=(z0, z1))
-        if not c.Init():
-            raise SystemExit("vcy_create failed: " + vc.last_error())
-        if devs:
-            c.use_stream_of(devs[0])  # one stream per GPU: slabs run back to back
-        c.set_param("fused", args.batch)
-        c.set_param("cull", args.cull)
-        devs.append(c)
+
+    def make_carvers(option, cull, slabs):
+        out = []
+        for _, z0, z1 in slabs:
+            c = vc.VoxelCarver(option, device_id=local_rank, z_range=(z0, z1))
+            if not c.Init():
+                raise SystemExit("vcy_create failed: " + vc.last_error())
+            if out:
+                c.use_stream_of(out[0])  # one stream per GPU: slabs run back to back
+            c.set_param("fused", args.batch)
+            c.set_param("cull", cull)
+            out.append(c)
+        return out
+
+    devs = make_carvers(opt, args.cull, my_slabs)
     dev = devs[0]
     d_sdf = [dev.upload_sdf(s) for s in sdfs]  # inputs resident in HBM before the timed region
 
     def barrier():
         dev.sync()
         if dist is not None:
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
+
+    def run_steps(carvers, batch, count, record=None):
+        lead = carvers[0]
+        for _ in range(count):
+            for c in carvers:
+                c.reset()
+            lead.timer_begin()
+            ok = all(c.CarveBatchDevice(batch) for c in carvers)
+            ms = lead.timer_end()
+            if not ok:
+                raise SystemExit("carve failed: " + vc.last_error())
+            if record is not None:
+                record.append(ms)
 
     kernel_ms = []
     batch = vc.VoxelCarver.prepare_batch(views, d_sdf)
-
-    def step(record):
-        for c in devs:
-            c.reset()
-        dev.timer_begin()
-        ok = all(c.CarveBatchDevice(batch) for c in devs)
-        ms = dev.timer_end()
-        if not ok:
-            raise SystemExit("carve failed: " + vc.last_error())
-        if record:
-            kernel_ms.append(ms)
-
-    for _ in range(args.warmup):
-        step(False)
+    run_steps(devs, batch, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    run_steps(devs, batch, args.steps, kernel_ms)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -223,27 +345,40 @@ def main():
 
     # roofline of the dominant kernel (carve), this rank's slab: algorithmic bytes per launch /
     # launch duration from HIP events on the launch stream.
-    bytes_per_vv = 4.0 if args.mode == "default" else 4.0 + (1 if uo.voxel_max_update_num <= 254 else 2)
+    def bytes_per_vv(mode, u):
+        return 4.0 if mode == "default" else 4.0 + (1 if u.voxel_max_update_num <= 254 else 2)
+
     slab_vox = sum(c.slab_voxels for c in devs) / float(len(devs))  # per launch
     FUSED_MAX = 64  # views per fused launch (carve_fused.hip)
     views_per_launch = min(nv, FUSED_MAX) if args.batch else 1
     launches_per_step = ((nv + views_per_launch - 1) // views_per_launch) * len(devs)
     avg_launch_ms = sum(kernel_ms) / len(kernel_ms) / launches_per_step
-    achieved = slab_vox * views_per_launch * bytes_per_vv / (avg_launch_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            key = "%s_%d_%d_b%d" % (args.mode, n, nv, args.batch)
-            traffic = tj.get(key, {}).get("hbm_bytes_per_launch") if world == 1 else None
-        except Exception:
-            traffic = None
+    alg_bytes = slab_vox * views_per_launch * bytes_per_vv(args.mode, uo)
+    achieved = alg_bytes / (avg_launch_ms * 1e-3) / 1e9
+    ckey = "%s_%d_%d_b%d_c%d" % (args.mode, n, nv, args.batch, args.cull)
+    ctr = load_counters(ckey) if world == 1 else None
+    traffic = ctr.get("hbm_bytes_per_launch") if ctr else None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "carve_batch" if args.batch else "carve_view",
+                "kernel": "carve_fused_kernel" if args.batch else "carve_view_kernel",
                 "avg_launch_ms": round(avg_launch_ms, 4),
-                "algorithmic_bytes_per_launch": slab_vox * views_per_launch * bytes_per_vv}
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "achieved/frac use SURVEY 8(d)'s ALGORITHMIC bytes (one state read per voxel*view, the "
+                        "reference's per-view API); the fused kernel keeps the state in registers across the views, "
+                        "so its real HBM traffic is `traffic` and the roof that binds it is VALU issue: see "
+                        "hbm_real_frac and valu_issue_frac"}
+    # the roofs that actually bind the kernel: real HBM traffic and VALU issue slots (counters of the
+    # committed PMC passes for this workload, duration measured live above)
+    if traffic:
+        roofline["hbm_real_gbs"] = round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1)
+        roofline["hbm_real_frac"] = round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    vcyc = valu_issue_cycles(ctr)
+    if vcyc:
+        roofline["bound_actual"] = "valu"
+        roofline["valu_issue_frac"] = round(vcyc / (N_SIMD * CLOCK_HZ * avg_launch_ms * 1e-3), 4)
+        roofline["valu_wave_insts_per_launch"] = ctr["SQ_INSTS_VALU"]
+        roofline["valu_insts_per_voxel_view"] = round(ctr["SQ_INSTS_VALU"] * 64.0 / (slab_vox * views_per_launch), 3)
+        roofline["counters_source"] = ctr.get("source")
     # measured streaming bandwidth of this box next to the vendor figure (after the timed region)
     try:
         rd, cp = vc.measure_bandwidth(local_rank, 1 << 31, 3)
@@ -256,28 +391,79 @@ def main():
 
     # marching cubes (second half of the metric), outside the timed region
     mc = None
+    collective = {"backend": "none", "ranks": world, "bytes_per_rank": 0, "note": "one slab: nothing to exchange"}
     if not args.no_mc:
         try:
-            vdist.exchange_halo(devs, rank, world)
-            mc_ms, nvert, nface = 0.0, 0, 0
+            info = vdist.exchange_halo(devs, rank, world)
+            if info:
+                collective = info
+            if backend_note:
+                collective["note"] = backend_note
+            mc_ms, mc_wall, nvert, nface = 0.0, 0.0, 0, 0
             for c in devs:
+                mesh = c.ExtractIsoSurface(0.0, True)  # first run: scratch allocation
+                tw = time.perf_counter()
                 mesh = c.ExtractIsoSurface(0.0, True)
-                mesh = c.ExtractIsoSurface(0.0, True)  # second run: scratch allocation warmed
+                mc_wall += (time.perf_counter() - tw) * 1e3
                 mc_ms += mesh["device_ms"]
                 nvert += len(mesh["vertices"]) - mesh["n_foreign"]
                 nface += len(mesh["faces"])
             if dist is not None:
-                t = torch.tensor([mc_ms, float(nvert), float(nface)], dtype=torch.float64, device=red_dev)
+                t = torch.tensor([mc_ms, mc_wall, float(nvert), float(nface)], dtype=torch.float64, device=red_dev)
                 tmax = t.clone()
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                mc_ms, nvert, nface = float(tmax[0].item()), int(t[1].item()), int(t[2].item())
+                mc_ms, mc_wall = float(tmax[0].item()), float(tmax[1].item())
+                nvert, nface = int(t[2].item()), int(t[3].item())
             cells = float(n - 1) ** 2 * (n - 1)
             mc = {"mcells_per_s": round(cells / (mc_ms * 1e-3) / 1e6, 1), "device_ms": round(mc_ms, 3),
+                  "wall_ms": round(mc_wall, 3),
+                  "wall_note": "call entry -> mesh arrays in host memory (what the reference's MarchingCubes timer "
+                               "brackets, marching_cubes.cc:65-66,226-227); device_ms = kernels only",
                   "vertices": int(nvert), "faces": int(nface),
                   "roofline_frac": round(cells * 4.0 / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            mctr = load_counters("mc_%d" % n) if world == 1 else None
+            if mctr:
+                mc["traffic"] = mctr.get("hbm_bytes_per_call")
         except Exception as e:  # the carve metric above stands on its own
             mc = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # the same kernel without view dropping and in TSDF mode (weighted average + truncation), measured in
+    # the same run so that the headline's dependence on the scene is visible in the driver's record
+    variants = None
+    if world == 1 and not args.no_variants and args.batch:
+        variants = {}
+        for name, mode, cull in (("cull0", args.mode, 0), ("tsdf", "tsdf", 1)):
+            if mode == args.mode and cull == args.cull:
+                continue
+            try:
+                u2 = update_option(mode)
+                cs = make_carvers(synth.sphere_option(n, u2), cull, my_slabs)
+                if mode == args.mode:
+                    dsdf2, own = d_sdf, False
+                else:
+                    s2 = vc.make_sdf(masks[0], use_truncation=bool(u2.use_truncation), band=u2.truncation_band)
+                    p = cs[0].upload_sdf(s2)
+                    dsdf2, own = [p] * nv, True
+                b2 = vc.VoxelCarver.prepare_batch(views, dsdf2)
+                ms2 = []
+                run_steps(cs, b2, 1)
+                run_steps(cs, b2, 3, ms2)
+                avg = sum(ms2) / len(ms2)
+                bpv = bytes_per_vv(mode, u2)
+                variants[name] = {"value": round(float(n) ** 3 * nv / (avg * 1e-3) / 1e6, 1),
+                                  "unit": "Mvoxel*views/s", "ms_per_step": round(avg, 3), "mode": mode,
+                                  "view_dropping": bool(cull),
+                                  "algorithmic_frac": round(float(n) ** 3 * nv * bpv / (avg * 1e-3) / 1e9
+                                                            / HBM_PEAK_GBS, 4)}
+                if own:
+                    cs[0].free_device(dsdf2[0])
+                for c in reversed(cs):
+                    c.close()
+            except Exception as e:
+                variants[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        roofline["value_cull0"] = variants.get("cull0", {}).get("value")
+        roofline["value_tsdf"] = variants.get("tsdf", {}).get("value")
 
     out = {
         "metric": "Mvoxel*views/s (Carve)", "value": round(value, 1), "unit": "Mvoxel*views/s",
@@ -291,8 +477,10 @@ def main():
                    "slabs_per_gpu": k_slabs,
                    "division": {2: "rcp + 3 (verified for this focal length)", 1: "rcp + 5 (verified)",
                                 0: "full IEEE expansion"}.get(dev.get_param("div_level"), "?")},
-        "roofline": roofline, "mc": mc,
+        "roofline": roofline, "mc": mc, "collective": collective,
     }
+    if variants is not None:
+        out["variants"] = variants
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, views, sdfs, args.cpu_seconds)
     if rank == 0:

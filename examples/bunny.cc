@@ -100,9 +100,9 @@ int main(int argc, char* argv[]) {
       bool same = sm.vertices().size() == mesh.vertices().size() &&
                   sm.vertex_indices().size() == mesh.vertex_indices().size();
       for (size_t k = 0; same && k < sm.vertices().size(); ++k)
-        for (int a = 0; a < 3; ++a) same = sm.vertices()[k][a] == mesh.vertices()[k][a];
+        for (int a = 0; a < 3; ++a) same = same && sm.vertices()[k][a] == mesh.vertices()[k][a];
       for (size_t k = 0; same && k < sm.vertex_indices().size(); ++k)
-        for (int a = 0; a < 3; ++a) same = sm.vertex_indices()[k][a] == mesh.vertex_indices()[k][a];
+        for (int a = 0; a < 3; ++a) same = same && sm.vertex_indices()[k][a] == mesh.vertex_indices()[k][a];
       std::printf("SHARDED view %zu slabs %d identical %d\n", i, sharded->slab_count(), same ? 1 : 0);
     }
     carver.ExtractIsoSurface(&mesh, 0.0, false);

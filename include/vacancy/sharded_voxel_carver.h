@@ -2,9 +2,10 @@
 //
 // The grid is cut into z-slabs (k per device, dealt cyclically so that slabs near the object and
 // empty ones mix on every device); carving needs no exchange, extraction needs the two slices below
-// each slab, copied peer-to-peer (vcy_halo_copy_from), and the per-slab meshes are stitched by edge
-// key into exactly the mesh a single VoxelCarver returns.  (The one-process-per-GPU form of the same
-// scheme, with a single RCCL all-gather for the halos, is vacancy_amd/dist.py + bench.py.)
+// each slab -- ONE RCCL all-gather of every slab's boundary slices (vcy_halo_allgather: one
+// communicator rank per device, ncclCommInitAll) -- and the per-slab meshes are stitched by edge key
+// into exactly the mesh a single VoxelCarver returns.  (The one-process-per-GPU form of the same
+// scheme is vacancy_amd/dist.py + bench.py, where the all-gather goes through torch.distributed.)
 #pragma once
 
 #include <memory>
@@ -23,6 +24,10 @@ class ShardedVoxelCarver {
 
   bool Init();
   int slab_count() const;
+  // how the halo slices travel before extraction: the RCCL all-gather (default) or explicit
+  // peer-to-peer copies slab by slab (vcy_halo_copy_from)
+  enum class HaloTransport { kRcclAllGather, kPeerCopy };
+  void set_halo_transport(HaloTransport t);
   // one view / a batch of views into every slab (slabs of different devices run concurrently)
   bool Carve(const Camera& camera, const Image1b& silhouette);
   bool Carve(const std::vector<const Camera*>& cameras, const std::vector<Image1b>& silhouettes);

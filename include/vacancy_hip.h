@@ -123,7 +123,9 @@ int vcy_compute_dims(const float bb_min[3], const float bb_max[3],
  * const Vector2i& roi_max, const Image1f& sdf) (voxel_carver.cc:415-496).
  * `sdf_host` is row-major float[height*width]; it is copied before the call returns.  The view is
  * queued and applied later, in order (see "defer" under vcy_set_param); argument errors are reported
- * here, a device failure by the call that applies the queue. */
+ * here.  A failure while applying queued views is returned by the call that applies them AND, if that
+ * call was not a carve entry point (an extraction, a download), once more by the next vcy_carve* call,
+ * so a `for each view: if (!Carve()) ...` loop sees it like the reference's bool Carve() would. */
 int vcy_carve(vcy_ctx* ctx, const vcy_view* view, const float* sdf_host);
 /* Same, SDF image already resident in HBM on the context's device (copied, ordered on the context's
  * stream: do not overwrite it before the stream has passed this call). */
@@ -192,6 +194,10 @@ int vcy_last_extract_ms(const vcy_ctx* ctx, float* device_ms);
  * id = z*nx*ny + y*nx + x (voxel_carver.cc:333,349-355).  Either may be NULL. */
 int vcy_download(vcy_ctx* ctx, float* sdf, int32_t* update_num);
 int vcy_upload(vcy_ctx* ctx, const float* sdf, const int32_t* update_num);
+/* Device-side comparison of two contexts that own the same slab of the same grid (on one device):
+ * *n_diff = number of voxels whose (sdf bits, update_num) differ.  Nothing is downloaded -- this is
+ * how the tests cross-check two kernel paths over a whole 1024^3 / 2048^3 grid. */
+int vcy_state_equal(vcy_ctx* a, vcy_ctx* b, int64_t* n_diff);
 /* Point query: state of `n` voxels given by global id (must lie in this context's slab). */
 int vcy_download_voxels(vcy_ctx* ctx, int64_t n, const int64_t* voxel_ids, float* sdf, int32_t* update_num);
 /* Voxel centres of the slab, 3 floats per voxel (Voxel::pos, voxel_carver.cc:315-337). */
@@ -214,6 +220,18 @@ int vcy_halo_install(vcy_ctx* ctx, const void* prev_slab_pack_device);
 /* Single-process multi-GPU: copies the last two slices of `below` (the slab that ends at ctx's
  * z_begin, on any device of this process) straight into ctx's halo (peer-to-peer over xGMI). */
 int vcy_halo_copy_from(vcy_ctx* ctx, vcy_ctx* below);
+/* Single-process multi-GPU, the north star's "single RCCL all-gather of boundary slabs before mesh
+ * extraction" (the exchange step of MarchingCubes(), marching_cubes.cc:93-101 reads z-1): `slabs` are
+ * ALL z-slabs of one grid in z order (slab i ends where slab i+1 begins), on any devices of this
+ * process.  Every slab's pack goes into its device's send buffer, ONE ncclAllGather (one communicator
+ * rank per distinct device, ncclCommInitAll; communicators and staging are cached per device list)
+ * hands every device every pack, and each slab installs the pack of the slab below it.  librccl.so is
+ * opened on first use; VCY_ERR_UNSUPPORTED if it cannot be loaded -- there is no silent fallback to
+ * peer copies (vcy_halo_copy_from is the explicit alternative). */
+int vcy_halo_allgather(vcy_ctx* const* slabs, int n_slabs);
+/* What the last vcy_halo_allgather of this process did, as text:
+ * "backend=rccl op=ncclAllGather version=V ranks=R bytes_per_rank=B calls=N lib=..." or "none". */
+const char* vcy_last_collective(void);
 
 /* ---- device memory / stream / timing helpers ----------------------------- */
 

@@ -114,6 +114,17 @@ extern "C" {
 
 int orc_sizeof_voxel(void) { return (int)sizeof(Voxel); }
 
+// The tables MarchingCubes() below walks, as the reference lays them out (kEdgeTable[256],
+// kTriTable[256][16], marching_cubes_lut.cc:15-298): pinned by tests/test_mc_tables.py against
+// tests/golden/mc_tables.bin, which oracle/_ref dumped from the reference's own translation unit.
+void orc_mc_tables(int* edge256, int* tri256x16) {
+  const McTables& t = tables();
+  for (int c = 0; c < 256; ++c) {
+    edge256[c] = t.edge[c];
+    for (int k = 0; k < 16; ++k) tri256x16[c * 16 + k] = t.tri[c][k];
+  }
+}
+
 void orc_set_num_threads(int n) {
 #ifdef _OPENMP
   if (n > 0) omp_set_num_threads(n);

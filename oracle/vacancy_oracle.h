@@ -72,6 +72,8 @@ void orc_affine_to_float(const double m[12], float out[12]);
 float orc_focal_from_fov_y(int height, float fov_y_deg);
 
 int orc_omp_max_threads(void);
+/* kEdgeTable[256] / kTriTable[256][16] as the oracle uses them (marching_cubes_lut.cc:15-298). */
+void orc_mc_tables(int* edge256, int* tri256x16);
 void orc_set_num_threads(int n);
 
 #ifdef __cplusplus

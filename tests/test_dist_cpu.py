@@ -107,3 +107,38 @@ def test_slab_sharded_extraction_merges_to_the_serial_mesh(world, k):
         mp.spawn(_worker, args=(world, port, k, ret), nprocs=world, join=True)
         assert ret.get("ok") is True
         assert ret["nv"] == 8672
+
+
+# ---- bench.py launch path (no GPU): `python bench.py --gpus N` from a plain shell -------------------
+
+def _run_bench(extra, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, cwd=root, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{"):
+            line = json.loads(ln)
+    return r.returncode, line, r.stderr
+
+
+def test_bench_self_launches_two_ranks_and_records_the_collective():
+    """Without WORLD_SIZE, --gpus 2 re-executes under torch.distributed.run (one process per rank); the
+    plumbing check runs the configuration's halo all-gather over gloo with rank-stamped buffers."""
+    rc, line, err = _run_bench(["--gpus", "2", "--plumbing-check", "--grid", "64"])
+    assert rc == 0, err[-2000:]
+    assert line is not None and line["plumbing_check"] and line["ok"]
+    assert line["n_gpus"] == 2
+    c = line["collective"]
+    assert c["ranks"] == 2 and c["backend"] == "gloo" and c["bytes_per_rank"] == 2 * 64 * 64 * 6 * 2
+
+
+def test_bench_refuses_a_gloo_halo_exchange_unless_allowed():
+    rc, line, err = _run_bench(["--gpus", "2", "--grid", "64"], {"VCY_BENCH_BACKEND": "gloo"})
+    assert rc != 0 and line is None
+    assert "allow-gloo" in err

@@ -1,7 +1,8 @@
 """Parity at BASELINE.json's full sizes (configs[1], configs[2]): the grids are too large for the
 CPU oracle, so the HIP path is checked through
   * a random SAMPLE of voxels carved by the oracle (same loop, bit-exact),
-  * fused + view-dropping kernel == per-view generic kernel on the WHOLE grid (bit-exact),
+  * fused + view-dropping kernel == per-view generic kernel on the WHOLE grid (bit-exact; compared on
+    the device by vcy_state_equal, also at 2048^3),
   * idempotence of kMax carving (a second pass over the same views changes nothing),
   * mesh invariants of the extracted surface (closed 2-manifold, Euler characteristic of a
     sphere-like hull, unique edge keys, faces in range) and slab-sharded == single-context."""
@@ -17,28 +18,27 @@ from vacancy_amd.capi import UpdateOption
 pytestmark = pytest.mark.gpu
 
 
-def _sample_check(dev, opt, views, sdfs, n, nsample=400000, seed=5):
+def _sample_ids(n, nsample, seed):
+    """Voxel indices for the oracle cross-check: uniform random, the grid corners, and a second half
+    concentrated where the decisions of the fast path matter -- a shell around the carved surface
+    (radius 0.35 n) and the planes where 8x8x8 bricks meet."""
     rng = np.random.RandomState(seed)
-    ix = rng.randint(0, n, (nsample, 3))
-    # include the grid corners and faces
+    half = nsample // 2
+    ix = rng.randint(0, n, (half, 3))
     ix[:8] = [[a, b, c] for a in (0, n - 1) for b in (0, n - 1) for c in (0, n - 1)]
-    ax = O.axis_positions(-n / 2.0, n / 2.0, 1.0, n)
-    pos = np.stack([ax[ix[:, 0]], ax[ix[:, 1]], ax[ix[:, 2]]], 1)
-    orc = O.OracleGrid(opt, positions=pos)
-    for v, s in zip(views, sdfs):
-        orc.carve(v, s)
-    os_, ou = orc.download()
-    ds, du = dev.download()
-    lin = (ix[:, 2].astype(np.int64) * n + ix[:, 1]) * n + ix[:, 0]
-    assert np.array_equal(du[lin], ou)
-    assert np.array_equal(ds[lin].view(np.uint32), os_.view(np.uint32))
+    d = rng.normal(size=(nsample - half, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = 0.35 * n + rng.uniform(-4.0, 4.0, (nsample - half, 1))
+    shell = np.clip(np.floor(d * r + n / 2.0).astype(np.int64), 0, n - 1)
+    edge = rng.rand(nsample - half) < 0.25  # snap a quarter of them onto brick faces
+    shell[edge, 0] = np.clip((shell[edge, 0] // 8) * 8 + rng.randint(-1, 1, edge.sum()), 0, n - 1)
+    return np.concatenate([ix, shell])
 
 
-def _sample_check_queries(dev, opt, views, sdfs, n, nsample=300000, seed=9):
-    """Like _sample_check but through vcy_download_voxels (no 50 GB download)."""
-    rng = np.random.RandomState(seed)
-    ix = rng.randint(0, n, (nsample, 3))
-    ix[:8] = [[a, b, c] for a in (0, n - 1) for b in (0, n - 1) for c in (0, n - 1)]
+def _sample_check(dev, opt, views, sdfs, n, nsample=2_000_000, seed=5):
+    """Oracle carve of a sample of voxels against the device state, read back through
+    vcy_download_voxels (no whole-grid download)."""
+    ix = _sample_ids(n, nsample, seed)
     ax = O.axis_positions(-n / 2.0, n / 2.0, 1.0, n)
     pos = np.stack([ax[ix[:, 0]], ax[ix[:, 1]], ax[ix[:, 2]]], 1)
     orc = O.OracleGrid(opt, positions=pos)
@@ -49,6 +49,9 @@ def _sample_check_queries(dev, opt, views, sdfs, n, nsample=300000, seed=9):
     ds, du = dev.download_voxels(lin)
     assert np.array_equal(du, ou)
     assert np.array_equal(ds.view(np.uint32), os_.view(np.uint32))
+
+
+_sample_check_queries = _sample_check
 
 
 def _mesh_invariants(m, expect_closed=True):
@@ -87,8 +90,8 @@ def test_config1_512_tsdf():
     assert ref.Init()
     ref.set_param("fused", 0)
     assert ref.CarveBatchDevice(views, [ref.upload_sdf(s) for s in sdfs])
-    a, b = dev.download(), ref.download()
-    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    assert dev.state_diff(ref) == 0
+    ref.close()
     m = dev.ExtractIsoSurface(0.0, True)
     assert len(m["faces"]) > 100000
     _mesh_invariants(m, expect_closed=False)  # truncation leaves untouched voxels: open patches allowed
@@ -106,21 +109,24 @@ def test_config2_1024_default():
     d0 = dev.upload_sdf(sdf0)
     assert dev.CarveBatchDevice(views, [d0] * nv), vc.last_error()
     _sample_check(dev, opt, views, sdfs, n)
-    a = dev.download()
-    # whole grid: per-view generic kernel, no fusion, no dropping
+    # whole grid: per-view generic kernel, no fusion, no dropping -- compared on the device
     ref = vc.VoxelCarver(opt)
     assert ref.Init()
     ref.set_param("fused", 0)
     assert ref.CarveBatchDevice(views, [ref.upload_sdf(sdf0)] * nv)
-    b = ref.download()
-    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
-    del b
+    assert dev.state_diff(ref) == 0
+    # the comparison itself must see a difference: one more view on one side only
+    assert ref.CarveBatchDevice(views[:1], [ref.upload_sdf(sdf0 * np.float32(1.5))])
+    assert ref.state_diff(dev) > 0
+    # idempotence of kMax: a second pass over the same views changes nothing
+    assert ref.CarveBatchDevice(views, [ref.upload_sdf(sdf0)] * nv)
     ref.close()
-    # idempotence of kMax
-    assert dev.CarveBatchDevice(views, [d0] * nv)
-    c = dev.download()
-    assert np.array_equal(a[1], c[1]) and np.array_equal(a[0].view(np.uint32), c[0].view(np.uint32))
-    del c
+    ref = vc.VoxelCarver(opt)
+    assert ref.Init()
+    assert ref.CarveBatchDevice(views, [ref.upload_sdf(sdf0)] * nv)
+    assert ref.CarveBatchDevice(views, [ref.upload_sdf(sdf0)] * nv)
+    assert dev.state_diff(ref) == 0
+    ref.close()
     m = dev.ExtractIsoSurface(0.0, True)
     _mesh_invariants(m)
     # every vertex lies between the two voxel centres of its edge key
@@ -138,9 +144,9 @@ def test_config2_1024_default():
         assert c.Init(), vc.last_error()
         assert c.CarveBatchDevice(views, [c.upload_sdf(sdf0)] * nv)
         ranks.append(c)
-    g = np.concatenate([c.halo_pack_host() for c in ranks])
-    for r, c in enumerate(ranks):
-        c.halo_unpack_host(g, r, 2)
+    info = vc.halo_allgather(ranks)  # the library's RCCL all-gather (one rank: both slabs are on this GPU)
+    assert "op=ncclAllGather" in info and "ranks=1" in info
+    for c in ranks:
         parts.append(c.ExtractIsoSurface(0.0, True))
         c.close()
     merged = vdist.merge_meshes(parts)
@@ -161,6 +167,16 @@ def test_config4_2048_64_views_streamed():
     assert dev.CarveBatchSilhouettes(views, masks), vc.last_error()
     sdf0 = O.make_sdf(masks[0])
     _sample_check_queries(dev, opt, views, [sdf0] * nv, n)
+    # whole grid at 2048^3 (sub-half-pixel voxel footprints: where the `sure`-tile, short-division and
+    # view-dropping decisions differ from the 1024^3 case): per-view generic kernel in a second context
+    # (2 x 51.5 GB), compared on the device
+    ref = vc.VoxelCarver(opt)
+    assert ref.Init(), vc.last_error()
+    ref.set_param("fused", 0)
+    d0 = ref.upload_sdf(sdf0)
+    assert ref.CarveBatchDevice(views, [d0] * nv), vc.last_error()
+    assert dev.state_diff(ref) == 0
+    ref.close()
     m = dev.ExtractIsoSurface(0.0, True)
     assert len(m["faces"]) > 15_000_000
     _mesh_invariants(m)

@@ -354,6 +354,44 @@ def test_z_slab_sharding_on_one_gpu(world):
         assert_mesh_equal(merged, orc.marching_cubes(iso, interp), "merged vs oracle")
 
 
+def test_native_rccl_halo_allgather_equals_host_exchange():
+    """vcy_halo_allgather (ncclCommInitAll + ONE ncclAllGather, one communicator rank per device; here
+    4 slabs on cuda:0 share one rank) installs the same halo slices as packing through the host."""
+    from vacancy_amd import dist as vdist
+    n, nv, w, h = 40, 4, 128, 96
+    opt = synth.sphere_option(n, UpdateOption(voxel_update=1, use_truncation=True, truncation_band=0.1))
+    views, masks = synth.sphere_views(n, nv, w, h)
+    world = 4
+
+    def slabs():
+        out = []
+        for r in range(world):
+            c = vc.VoxelCarver(opt, z_range=vdist.slab_range(n, r, world))
+            assert c.Init(), vc.last_error()
+            for v, m in zip(views, masks):
+                assert c.CarveSilhouette(v, m)  # queued: the exchange must apply them first
+            out.append(c)
+        return out
+
+    a, b = slabs(), slabs()
+    info = vc.halo_allgather(a)
+    assert "backend=rccl" in info and "op=ncclAllGather" in info and "ranks=1" in info
+    assert "bytes_per_rank=%d" % (world * 2 * n * n * 6) in info
+    gathered = np.concatenate([c.halo_pack_host() for c in b])
+    for r, c in enumerate(b):
+        c.halo_unpack_host(gathered, r, world)
+    for ca, cb in zip(a, b):
+        ma, mb = ca.ExtractIsoSurface(0.0, True), cb.ExtractIsoSurface(0.0, True)
+        assert ma["n_foreign"] == mb["n_foreign"]
+        assert_mesh_equal(ma, mb, "rccl vs host halo")
+    # slabs that do not tile z in order are refused
+    with pytest.raises(RuntimeError):
+        vc.halo_allgather([a[0], a[2]])
+    # a second exchange reuses the cached communicator
+    calls = lambda text: int([kv for kv in text.split() if kv.startswith("calls=")][0][6:])
+    assert calls(vc.halo_allgather(a)) == calls(info) + 1
+
+
 def test_torch_shares_device_memory_with_the_library():
     """bench.py's multi-GPU halo exchange hands torch CUDA tensors to the C-ABI: the library and
     torch must sit on the same HIP runtime in one process."""

@@ -135,6 +135,9 @@ def load():
         "vcy_halo_unpack": (C.c_int, [vp, vp, C.c_int, C.c_int]),
         "vcy_halo_install": (C.c_int, [vp, vp]),
         "vcy_halo_copy_from": (C.c_int, [vp, vp]),
+        "vcy_halo_allgather": (C.c_int, [P(vp), C.c_int]),
+        "vcy_last_collective": (C.c_char_p, []),
+        "vcy_state_equal": (C.c_int, [vp, vp, P(C.c_int64)]),
         "vcy_device_count": (C.c_int, [P(C.c_int)]),
         "vcy_sdf_upload": (C.c_int, [vp, vp, C.c_int, C.c_int, P(vp)]),
         "vcy_device_free": (C.c_int, [vp, vp]),

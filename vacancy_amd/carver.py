@@ -243,6 +243,14 @@ class VoxelCarver:
         assert self._lib.vcy_halo_install(self._ctx, dev) == 0, last_error()
         self._lib.vcy_device_free(self._ctx, dev)
 
+    def state_diff(self, other):
+        """Number of voxels whose (sdf bits, update_num) differ from `other` (same slab, same device);
+        compared on the device (vcy_state_equal), nothing is downloaded."""
+        n = C.c_int64(-1)
+        if self._lib.vcy_state_equal(self._ctx, other._ctx, C.byref(n)) != 0:
+            raise RuntimeError(last_error())
+        return int(n.value)
+
     def use_stream_of(self, other):
         """Launch on another context's stream (several slabs of one GPU in sequence)."""
         st = C.c_void_p()
@@ -275,6 +283,16 @@ class VoxelCarver:
         ms = C.c_float()
         self._lib.vcy_timer_end(self._ctx, C.byref(ms))
         return ms.value
+
+
+def halo_allgather(carvers):
+    """All z-slabs of one grid held by THIS process, in z order: one native RCCL all-gather
+    (vcy_halo_allgather) installs every slab's two halo slices."""
+    lib = capi.load()
+    arr = (C.c_void_p * len(carvers))(*[c.ctx for c in carvers])
+    if lib.vcy_halo_allgather(arr, len(carvers)) != 0:
+        raise RuntimeError(last_error())
+    return lib.vcy_last_collective().decode()
 
 
 def measure_bandwidth(device_id=0, nbytes=1 << 31, reps=3):

@@ -22,18 +22,20 @@ namespace vcy {
 
 // ---- kernel A: one thread per voxel, one view per launch (generic, every mode) ---------
 //
-// Grid: 1-D over (row, x-segment); a row is a (y, z) line of nx voxels, x fastest, so a
-// wave reads 64 consecutive floats of the slab (256 B) and the SDF taps of neighbouring
-// lanes fall in the same few cache lines.
+// Grid: x over (y, x-segment), y over the slab's z slices (a 1-D grid of a 2048^3 slab would exceed
+// the 2^32 threads a launch dimension may hold); a row is a (y, z) line of nx voxels, x fastest, so
+// a wave reads 64 consecutive floats of the slab (256 B) and the SDF taps of neighbouring lanes fall
+// in the same few cache lines.
 template <typename CountT, bool RT, int UPDATE, int INTERP, int OUTSIDE, bool TRUNC, bool ORTHO>
 __global__ __launch_bounds__(256) void carve_view_kernel(GridParams g, ViewParams v, ModeParams m,
                                                          int segs_per_row) {
-  const int64_t row = blockIdx.x / segs_per_row;
-  const int seg = blockIdx.x - (int)(row * segs_per_row);
+  const int y = blockIdx.x / segs_per_row;
+  const int seg = blockIdx.x - y * segs_per_row;
   const int x = seg * 256 + threadIdx.x;
   if (x >= g.nx) return;
-  const int zl = (int)(row / g.ny);
-  const int y = (int)(row - (int64_t)zl * g.ny);
+  const int zl = blockIdx.y + blockIdx.z * 65535;
+  if (zl >= g.nz_local) return;
+  const int64_t row = (int64_t)zl * g.ny + y;
   const int64_t idx = row * g.nx + x;
 
   CountT* __restrict__ cnt = (CountT*)g.cnt;
@@ -89,8 +91,8 @@ static void fill_view(const vcy_view& in, const float* sdf_dev, float max_sdf, V
 template <typename CountT>
 static void launch_view(vcy_ctx* c, const GridParams& g, const ViewParams& v, const ModeParams& m) {
   const int segs = (c->nx + 255) / 256;
-  const int64_t rows = (int64_t)c->ny * c->nz_local();
-  const dim3 grid((unsigned)(rows * segs)), block(256);
+  const int nzl = c->nz_local();
+  const dim3 grid((unsigned)(c->ny * segs), (unsigned)std::min(nzl, 65535), (unsigned)((nzl + 65534) / 65535)), block(256);
   const bool is_default = m.update == VCY_UPDATE_MAX && m.interp == VCY_INTERP_BILINEAR &&
                           m.outside == VCY_OUTSIDE_NONE && !m.trunc && !m.ortho;
   const bool is_tsdf = m.update == VCY_UPDATE_WEIGHTED_AVERAGE && m.interp == VCY_INTERP_BILINEAR &&
@@ -125,6 +127,10 @@ int flush_pending(vcy_ctx* c) {
   // from a neighbour that has applied the same views and stay valid
   const bool halo_valid = c->halo_valid;
   const int rc = launch_carve(c, (int)todo.size(), views.data(), ptrs.data());
+  if (rc != VCY_OK) {  // also reported by the next carve call, whoever triggered this flush
+    c->deferred_rc = rc;
+    c->deferred_msg = vcy_last_error();
+  }
   c->halo_valid = halo_valid;
   // stream order: a buffer handed out again is only written after this launch
   for (auto& t : todo) c->sdf_pool.emplace_back(t.d_sdf, t.bytes);
@@ -155,7 +161,7 @@ int launch_carve(vcy_ctx* c, int n_views, const vcy_view* views, const float* co
   g.nz_local = c->nz_local();
   g.max_update_num = u.voxel_max_update_num;
   g.weight = u.voxel_update_weight;
-  if ((int64_t)c->ny * c->nz_local() * ((c->nx + 255) / 256) > 0x7fffffffLL) {
+  if ((int64_t)c->ny * ((c->nx + 255) / 256) > 0xffffffLL) {
     set_error("slab too large for one launch");
     return VCY_ERR_TOO_MANY_VOXELS;
   }

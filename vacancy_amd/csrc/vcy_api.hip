@@ -35,6 +35,8 @@ static void discard_pending(vcy_ctx* c) {
 
 int fill_state(vcy_ctx* c) {
   discard_pending(c);  // whatever they would have carved is wiped
+  c->deferred_rc = VCY_OK;
+  c->deferred_msg.clear();
   c->fresh = true;  // written lazily, see vcy_ctx::fresh
   c->views_carved = 0;
   c->halo_valid = false;
@@ -594,6 +596,14 @@ static int check_view(const vcy_ctx* c, const vcy_view* v) {
     set_error("VoxelCarver::Carve voxel grid has not been initialized");
     return VCY_ERR_NOT_INITIALIZED;
   }
+  if (c->deferred_rc != VCY_OK) {  // views queued by earlier calls failed to apply (see vcy_ctx::deferred_rc)
+    vcy_ctx* m = const_cast<vcy_ctx*>(c);
+    const int rc = m->deferred_rc;
+    set_error("an earlier queued view failed: %s", m->deferred_msg.c_str());
+    m->deferred_rc = VCY_OK;
+    m->deferred_msg.clear();
+    return rc;
+  }
   if (!v || v->width <= 0 || v->height <= 0) {
     set_error("invalid view");
     return VCY_ERR_INVALID_ARG;
@@ -991,6 +1001,61 @@ int vcy_download_voxels(vcy_ctx* c, int64_t n, const int64_t* voxel_ids, float* 
     set_error("vcy_download_voxels: %s", hipGetErrorString(e));
     return VCY_ERR_HIP;
   }
+  return VCY_OK;
+}
+
+// Counts voxels whose state differs between two slabs (bit compare of sdf, value compare of update_num).
+__device__ __forceinline__ int load_count(const void* cnt, int cnt_bytes, int64_t i) {
+  return cnt_bytes == 1 ? (int)((const uint8_t*)cnt)[i]
+       : cnt_bytes == 2 ? (int)((const uint16_t*)cnt)[i] : ((const int*)cnt)[i];
+}
+
+__global__ __launch_bounds__(256) void state_diff_kernel(const float* __restrict__ sa, const void* __restrict__ ca,
+                                                         int cba, const float* __restrict__ sb,
+                                                         const void* __restrict__ cb, int cbb, int64_t n,
+                                                         unsigned long long* __restrict__ n_diff) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  unsigned local = 0;
+  for (; i < n; i += stride) {
+    const bool diff = __float_as_uint(sa[i]) != __float_as_uint(sb[i]) || load_count(ca, cba, i) != load_count(cb, cbb, i);
+    local += diff ? 1u : 0u;
+  }
+  const unsigned long long m = __ballot(local != 0);
+  if (m) {  // rare: serialise only when something differs
+    for (int d = 32; d > 0; d >>= 1) local += __shfl_down(local, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(n_diff, (unsigned long long)local);
+  }
+}
+
+int vcy_state_equal(vcy_ctx* a, vcy_ctx* b, int64_t* n_diff) {
+  if (!a || !b || !n_diff) return VCY_ERR_INVALID_ARG;
+  if (a->device != b->device || a->nx != b->nx || a->ny != b->ny || a->z0 != b->z0 || a->z1 != b->z1) {
+    set_error("vcy_state_equal: the contexts do not own the same slab on the same device");
+    return VCY_ERR_INVALID_ARG;
+  }
+  VCY_HIP_CHECK(hipSetDevice(a->device));
+  { int rcm = materialize(a); if (rcm != VCY_OK) return rcm; }
+  { int rcm = materialize(b); if (rcm != VCY_OK) return rcm; }
+  VCY_HIP_CHECK(hipStreamSynchronize(b->stream));
+  unsigned long long* d = nullptr;
+  unsigned long long h = 0;
+  VCY_HIP_CHECK(hipMalloc(&d, sizeof(unsigned long long)));
+  hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned long long), a->stream);
+  if (e == hipSuccess) {
+    const int64_t n = a->slab_voxels();
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(state_diff_kernel, dim3(grid), dim3(256), 0, a->stream, a->owned_slab_sdf(), a->owned_slab_cnt(),
+                       a->cnt_bytes, b->owned_slab_sdf(), b->owned_slab_cnt(), b->cnt_bytes, n, d);
+    e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, a->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) {
+    set_error("vcy_state_equal: %s", hipGetErrorString(e));
+    return VCY_ERR_HIP;
+  }
+  *n_diff = (int64_t)h;
   return VCY_OK;
 }
 

@@ -81,6 +81,10 @@ struct vcy_ctx {
   void* d_sil_scratch = nullptr;      // staging of vcy_carve_silhouette (mask + transform scratch)
   size_t sil_scratch_bytes = 0;
   bool defer = true;                  // vcy_set_param("defer", 0): apply every view at once
+  // A queued view that failed to apply inside a call that cannot report it to a Carve() caller (an
+  // extraction, a download ...) is remembered: the NEXT carve entry point returns it (then clears it).
+  int deferred_rc = 0;
+  std::string deferred_msg;
   int last_div_level = 0;             // division variant of the last fused launch (vcy_get_param "div_level")
   bool use_short_div = true;          // vcy_set_param("shortdiv", 0): always the full division sequence
   bool use_fused = true;              // vcy_set_option("fused", 0) forces the per-view kernel

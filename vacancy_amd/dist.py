@@ -36,26 +36,39 @@ def _pack_offset(slab_id, world, k, nbytes):
 
 def exchange_halo(carvers, rank, world):
     """carvers: this rank's slab contexts ordered by slab id (slab ids rank, rank+world, ...).
-    Installs, for every slab but the first of the grid, the last two slices of the slab below."""
+    Installs, for every slab but the first of the grid, the last two slices of the slab below.
+    Returns what the exchange was, for the benchmark record: {"backend", "ranks", "bytes_per_rank", "op"}
+    (None when there is a single slab and nothing to exchange)."""
     if not isinstance(carvers, (list, tuple)):
         carvers = [carvers]
     k = len(carvers)
     lib = carvers[0]._lib
     if world * k == 1:
-        return
+        return None
     nbytes = int(lib.vcy_halo_bytes(carvers[0].ctx))
     slab_ids = [rank + i * world for i in range(k)]
     if world == 1:
-        # all slabs live in this process: hand the packs over directly
-        packs = [c.halo_pack_host() for c in carvers]
+        # all slabs live in this process: the library's own RCCL all-gather (one communicator rank per
+        # distinct device, vcy_halo_allgather)
+        if hasattr(lib, "vcy_halo_allgather"):
+            from . import carver as _vc
+            text = _vc.halo_allgather(carvers)
+            info = dict(kv.split("=", 1) for kv in text.split() if "=" in kv)
+            return {"backend": "rccl (native, vcy_halo_allgather)", "op": info.get("op"),
+                    "ranks": int(info.get("ranks", 0)), "bytes_per_rank": int(info.get("bytes_per_rank", 0)),
+                    "rccl_version": int(info.get("version", 0)), "slabs": k}
+        packs = [c.halo_pack_host() for c in carvers]  # host stand-ins of the CPU tests
         for i, c in enumerate(carvers):
             if slab_ids[i] > 0:
                 c.halo_install_host(packs[i - 1])
-        return
+        return {"backend": "host", "op": "copy", "ranks": 1, "bytes_per_rank": nbytes * k}
     import torch
     import torch.distributed as dist
 
     on_gpu = dist.get_backend() == "nccl"
+    result = {"backend": "rccl (torch.distributed nccl)" if on_gpu else "gloo (host staging)",
+              "op": "all_gather_into_tensor" if on_gpu else "all_gather", "ranks": dist.get_world_size(),
+              "bytes_per_rank": nbytes * k, "slabs_per_rank": k}
     if on_gpu:
         send = torch.empty(nbytes * k, dtype=torch.uint8, device="cuda")
         recv = torch.empty(nbytes * k * world, dtype=torch.uint8, device="cuda")
@@ -83,6 +96,7 @@ def exchange_halo(carvers, rank, world):
             if s > 0:
                 off = _pack_offset(s - 1, world, k, nbytes)
                 c.halo_install_host(flat[off:off + nbytes])
+    return result
 
 
 def merge_meshes(meshes):

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <future>
 #include <limits>
+#include <string>
 #include <unordered_map>
 
 #include "vacancy_hip.h"
@@ -47,6 +48,7 @@ struct ShardedVoxelCarver::Impl {
   std::vector<int> devices;
   int per_device = 2;
   std::vector<vcy_ctx*> slabs;  // in z order
+  bool peer_copy_halo = false;
   ~Impl() {
     for (vcy_ctx* c : slabs) vcy_destroy(c);
   }
@@ -59,6 +61,8 @@ ShardedVoxelCarver::ShardedVoxelCarver(VoxelCarverOption option, std::vector<int
   impl_->per_device = slabs_per_device < 1 ? 1 : slabs_per_device;
 }
 ShardedVoxelCarver::~ShardedVoxelCarver() {}
+
+void ShardedVoxelCarver::set_halo_transport(HaloTransport t) { impl_->peer_copy_halo = t == HaloTransport::kPeerCopy; }
 
 int ShardedVoxelCarver::slab_count() const { return static_cast<int>(impl_->slabs.size()); }
 
@@ -115,17 +119,24 @@ bool ShardedVoxelCarver::Carve(const std::vector<const Camera*>& cameras, const 
     views[i] = MakeView(*cameras[i], silhouettes[i].width(), silhouettes[i].height());
     masks[i] = silhouettes[i].data().data();
   }
-  // one host thread per slab: a context is single-threaded, different contexts are independent
-  std::vector<std::future<int>> jobs;
+  // one host thread per slab: a context is single-threaded, different contexts are independent.
+  // vcy_last_error() is per thread: the worker hands its message back with the status.
+  std::vector<std::future<std::pair<int, std::string>>> jobs;
   for (vcy_ctx* ctx : impl_->slabs)
     jobs.push_back(std::async(std::launch::async, [ctx, n, &views, &masks]() {
       // one view: queued by the library, carved together with the following calls (vcy_set_param "defer")
-      if (n == 1) return vcy_carve_silhouette(ctx, &views[0], masks[0], nullptr);
-      return vcy_carve_batch_silhouettes(ctx, n, views.data(), masks.data());
+      const int rc = n == 1 ? vcy_carve_silhouette(ctx, &views[0], masks[0], nullptr)
+                            : vcy_carve_batch_silhouettes(ctx, n, views.data(), masks.data());
+      return std::make_pair(rc, rc == VCY_OK ? std::string() : std::string(vcy_last_error()));
     }));
   bool ok = true;
-  for (auto& j : jobs) ok = (j.get() == VCY_OK) && ok;
-  if (!ok) LOGE("sharded carve failed\n");
+  for (auto& j : jobs) {
+    const std::pair<int, std::string> r = j.get();
+    if (r.first != VCY_OK) {
+      LOGE("sharded carve failed: %s\n", r.second.c_str());
+      ok = false;
+    }
+  }
   return ok;
 }
 
@@ -133,19 +144,31 @@ void ShardedVoxelCarver::ExtractIsoSurface(Mesh* mesh, double iso_level, bool li
   mesh->Clear();
   const size_t ns = impl_->slabs.size();
   if (ns == 0) return;
-  for (size_t s = 1; s < ns; ++s)
-    if (vcy_halo_copy_from(impl_->slabs[s], impl_->slabs[s - 1]) != VCY_OK) {
-      LOGE("%s\n", vcy_last_error());
-      return;
-    }
+  // the two slices below every slab: ONE RCCL all-gather over the devices that hold slabs
+  // (vcy_halo_allgather); peer-to-peer copies only when asked for (set_halo_transport)
+  if (impl_->peer_copy_halo) {
+    for (size_t s = 1; s < ns; ++s)
+      if (vcy_halo_copy_from(impl_->slabs[s], impl_->slabs[s - 1]) != VCY_OK) {
+        LOGE("%s\n", vcy_last_error());
+        return;
+      }
+  } else if (vcy_halo_allgather(impl_->slabs.data(), static_cast<int>(ns)) != VCY_OK) {
+    LOGE("%s\n", vcy_last_error());
+    return;
+  }
   std::vector<vcy_mesh> parts(ns);
+  std::vector<std::string> errors(ns);
   std::vector<std::future<int>> jobs;
   for (size_t s = 0; s < ns; ++s)
-    jobs.push_back(std::async(std::launch::async, [this, s, iso_level, linear_interp, &parts]() {
-      return vcy_extract_iso(impl_->slabs[s], iso_level, linear_interp ? 1 : 0, &parts[s]);
+    jobs.push_back(std::async(std::launch::async, [this, s, iso_level, linear_interp, &parts, &errors]() {
+      const int rc = vcy_extract_iso(impl_->slabs[s], iso_level, linear_interp ? 1 : 0, &parts[s]);
+      if (rc != VCY_OK) errors[s] = vcy_last_error();
+      return rc;
     }));
   bool ok = true;
   for (auto& j : jobs) ok = (j.get() == VCY_OK) && ok;
+  for (const std::string& e : errors)
+    if (!e.empty()) LOGE("sharded extraction failed: %s\n", e.c_str());
   if (ok) {
     // stitch: a slab's first n_foreign vertices are owned by the slab below -> look them up by edge key
     std::vector<Eigen::Vector3f>* V = mesh->mutable_vertices();
@@ -179,10 +202,7 @@ void ShardedVoxelCarver::ExtractIsoSurface(Mesh* mesh, double iso_level, bool li
       offset += nown;
     }
   }
-  if (!ok) {
-    mesh->Clear();
-    LOGE("%s\n", vcy_last_error());
-  }
+  if (!ok) mesh->Clear();
   for (vcy_mesh& m : parts) vcy_mesh_free(&m);
 }
 

@@ -92,9 +92,12 @@ bool VoxelCarver::Carve(const Camera& camera, const Image1b& silhouette, const E
   sdf->Init(silhouette.width(), silhouette.height(), 0.0f);
   const vcy_view v = ToView(camera, roi_min, roi_max, silhouette.width(), silhouette.height());
   const double t0 = NowMs();
+  // The view is QUEUED by the library (vcy_set_param "defer"): this call returns after the silhouette has
+  // been uploaded and its SDF built and downloaded; queued views are carved together by one fused
+  // launch when the state is next needed (Extract*, Download).  No vcy_sync here -- it would flush the
+  // queue after every view and turn the fused pass into one pass per view.
   const int rc = vcy_carve_silhouette(impl_->ctx, &v, silhouette.data().data(), sdf->data_ptr()->data());
-  if (rc == VCY_OK) vcy_sync(impl_->ctx);
-  LOGI("VoxelCarver::Carve make SDF + main loop %02f\n", NowMs() - t0);
+  LOGI("VoxelCarver::Carve make SDF + enqueue %02f\n", NowMs() - t0);
   if (rc != VCY_OK) LOGE("%s\n", vcy_last_error());
   return rc == VCY_OK;
 }
@@ -107,9 +110,8 @@ bool VoxelCarver::Carve(const Camera& camera, const Eigen::Vector2i& roi_min, co
   }
   const vcy_view v = ToView(camera, roi_min, roi_max, sdf.width(), sdf.height());
   const double t0 = NowMs();
-  const int rc = vcy_carve(impl_->ctx, &v, sdf.data().data());
-  if (rc == VCY_OK) vcy_sync(impl_->ctx);
-  LOGI("VoxelCarver::Carve main loop %02f\n", NowMs() - t0);
+  const int rc = vcy_carve(impl_->ctx, &v, sdf.data().data());  // copied and queued, see above
+  LOGI("VoxelCarver::Carve enqueue %02f\n", NowMs() - t0);
   if (rc != VCY_OK) LOGE("%s\n", vcy_last_error());
   return rc == VCY_OK;
 }
