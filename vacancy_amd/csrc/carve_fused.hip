@@ -62,8 +62,12 @@ struct FusedView {
   // a z-slab of a sharded grid often sees a narrow band of the image.
   int wrect[4];
 };
-// c0_all[view][3][nxp] = R[i][0] * px[x]  (one fp32 multiply per entry, done on the host); nxp = nx rounded
-// up to whole bricks, the padding repeating the last column
+// c0_all[view][x brick][32]: the products c0 = R[i][0] * px[x] (one fp32 multiply per entry, done on the
+// host) of the 8 voxels of one wave brick along x, laid out for wide scalar loads:
+//   [2 k + 0] = R[0][0] px[x_k], [2 k + 1] = R[1][0] px[x_k]  (the (x, y) pair a packed add takes as one operand)
+//   [16 + k]  = R[2][0] px[x_k]                               (two neighbours = one packed operand)
+// 24 of 32 floats used (128-byte records); columns beyond nx repeat the last one.
+constexpr int kC0Stride = 32;
 
 struct TileInfo {
   float lo_x, hi_x, lo_y, hi_y;  // closed range of (u,v) whose taps are in the tile
@@ -194,6 +198,86 @@ __device__ __forceinline__ bool apply_sample(bool ok, float dist, float wgt, flo
     s = ok ? ns : s;
     n += ok ? 1 : 0;
   }
+  return ok;
+}
+
+// ---- full-rate update sequences ---------------------------------------------------------------
+// Measured on MI355X (profiles/r02/valu_ubench.txt): v_add/sub/mul/fma_f32, v_mov_b32 and v_add_u32 issue
+// in 2 SIMD cycles per wave; compares, selects, carries, conversions, min/max and ANY VALU instruction
+// with a scalar-register operand take 4.  The select forms of the update rules cost 12 (kMax) to ~50
+// (weighted average) cycles per sample; executed under an EXEC mask they are moves and adds.
+//
+// UpdateVoxelMax for a voxel that has been touched before (voxel_carver.cc:78-86):
+//   if (dist > sdf) { sdf = dist; ++update_num; }      -- NaN compares false, -0 == +0 stay put
+// v_cmpx writes the lanes where the test holds to EXEC (and to `took`); the two updates then run on those
+// lanes only.  Returns the lanes that changed.
+__device__ __forceinline__ unsigned long long update_max_touched(float dist, float& s, int& n) {
+  unsigned long long took, saved;
+  asm volatile(
+      "s_mov_b64 %[saved], exec\n\t"
+      "v_cmpx_gt_f32_e64 %[took], %[d], %[s]\n\t"
+      "v_mov_b32_e32 %[s], %[d]\n\t"
+      "v_add_u32_e32 %[n], 1, %[n]\n\t"
+      "s_mov_b64 exec, %[saved]"
+      : [s] "+v"(s), [n] "+v"(n), [took] "=&s"(took), [saved] "=&s"(saved)
+      : [d] "v"(dist)
+      : "memory");
+  return took;
+}
+
+// UpdateVoxelWeightedAverage with voxel_update_weight == 1 (voxel_carver.cc:88-95) behind the truncation
+// skip (:478), for a voxel whose counter is kept as a float `fn` (exact below 2^24):
+//   if (!(dist < -1)) { sdf = (fn * sdf + dist) * (1 / (fn + 1)); fn += 1; }
+// 1 / (fn + 1) is rcp_count() -- v_rcp_f32 and one Newton step, the correctly rounded quotient for every
+// count a u8 / u16 counter can hold (vcy_selftest).  Requires "update_num == 0 implies sdf == lowest()"
+// (state only ever written by the fill and the carve kernels): then the first touch needs no special
+// case, (0 * sdf + dist) * 1 == dist bit for bit (0 * lowest() = -0, -0 + dist = dist).
+template <bool TRUNC>
+__device__ __forceinline__ void update_wa_unit(float dist, float& s, float& fn) {
+  unsigned long long saved, took;
+  float f1, r, e;
+  if (TRUNC) {
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n\t"
+        "v_cmpx_nlt_f32_e64 %[took], %[d], -1.0\n\t"
+        "v_add_f32_e32 %[f1], 1.0, %[fn]\n\t"
+        "v_mul_f32_e32 %[s], %[fn], %[s]\n\t"
+        "v_rcp_f32_e32 %[r], %[f1]\n\t"
+        "v_add_f32_e32 %[s], %[s], %[d]\n\t"
+        "v_mov_b32_e32 %[fn], %[f1]\n\t"
+        "v_fma_f32 %[e], -%[f1], %[r], 1.0\n\t"
+        "v_fmac_f32_e32 %[r], %[e], %[r]\n\t"
+        "v_mul_f32_e32 %[s], %[s], %[r]\n\t"
+        "s_mov_b64 exec, %[saved]"
+        : [s] "+v"(s), [fn] "+v"(fn), [took] "=&s"(took), [saved] "=&s"(saved), [f1] "=&v"(f1), [r] "=&v"(r),
+          [e] "=&v"(e)
+        : [d] "v"(dist)
+        : "memory");
+  } else {
+    f1 = fn + 1.0f;
+    s = (fn * s + dist) * rcp_count(f1);
+    fn = f1;
+  }
+}
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef f4 __attribute__((address_space(3))) lds_float4;
+
+// The weighted-average kernels keep update_num as a float in registers (exact below 2^24; it is converted
+// at the load and the store of the brick): (float)n and (float)(n + 1) of the reference's formula are
+// then fn and fn + 1 without conversions.
+template <int UPDATE>
+__device__ __forceinline__ bool apply_sample(bool ok, float dist, float wgt, float& s, float& fn) {
+  const float f1 = fn + 1.0f;
+  float avg;
+  if (UPDATE == kUpdateWaUnitWeight) {
+    avg = (fn * s + dist) * rcp_count(f1);
+  } else {
+    avg = (wgt * fn * s + wgt * dist) * div_fast(1.0f, wgt * f1);
+  }
+  const float ns = (fn < 1.0f) ? dist : avg;
+  s = ok ? ns : s;
+  fn = ok ? f1 : fn;
   return ok;
 }
 
@@ -447,7 +531,9 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
         const bool unclipped = (int)floorf(umin - margin) >= v.roi_min_xi && (int)floorf(wmin - margin) >= v.roi_min_yi &&
                                (int)floorf(umax + margin) < v.roi_max_xi && (int)floorf(wmax_ + margin) < v.roi_max_yi;
         const bool depth_ok = 0x1p-20f * mag[2] <= 0.25f * zmin && zmin >= 0x1p-58f && zmax <= 0x1p58f;
-        ti.sure = (!ortho && unclipped && depth_ok) ? 1 : 0;
+        // (|16 base| < 2^22: the fast path forms LDS addresses in the float pipeline, carve_view_fast)
+        const bool small_base = ty0 * tw + tx0 < (1 << 18);
+        ti.sure = (!ortho && unclipped && depth_ok && small_base) ? 1 : 0;
         ti.tx0 = tx0;
         ti.ty0 = ty0;
         ti.tw = tw;
@@ -512,7 +598,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
                                                           const FusedView* __restrict__ views,
                                                           const float* __restrict__ c0_all,
                                                           int nviews, ModeParams mode, int nbx,
-                                                          int nby, int cull_enabled, int fresh) {
+                                                          int nby, int cull_enabled, int state_flags) {
+  // state_flags: bit 0 = the slab is fresh (known sdf = lowest(), update_num = 0, never written);
+  //              bit 1 = update_num == 0 implies sdf == lowest() (no vcy_upload since the fill)
+  const int fresh = state_flags & 1;
+  const bool implied = (state_flags & 2) != 0;
   // dynamic LDS: [4 waves][TQ] quads, then [4 waves][nviews] TileInfo (sized by the launch)
   extern __shared__ float4 fused_lds[];
   constexpr bool kPrefetch = TQ <= 128;  // two quads per lane fit in registers
@@ -573,8 +663,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
 
   // ---- load the wave brick's state ----------------------------------------------------------
   CountT* __restrict__ cnt = (CountT*)g.cnt;
+  // update_num in registers: an int for kMax, a float for the weighted-average modes (see apply_sample)
+  constexpr bool kFloatCount = UPDATE != VCY_UPDATE_MAX;
+  typedef typename std::conditional<kFloatCount, float, int>::type NT;
   float s[WX];
-  int n[WX];
+  NT n[WX];
   const int64_t row0 = ((int64_t)zl * g.ny + y) * g.nx;  // this lane's row; voxel k is at row0 + min(x_first + k, nx - 1)
   // rows are whole bricks when nx % 8 == 0: the run is one 32-byte (sdf) and one 8/16-byte (update_num) vector
   const bool vec_io = (g.nx & (WX - 1)) == 0;
@@ -583,41 +676,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
 #pragma unroll
     for (int k = 0; k < WX; ++k) {
       s[k] = kInvalidSdf;
-      n[k] = 0;
+      n[k] = (NT)0;
     }
   } else if (vec_io) {
     const float4 a = *(const float4*)(g.sdf + row0 + x_first), b4 = *(const float4*)(g.sdf + row0 + x_first + 4);
     const CountVec cv = *(const CountVec*)(cnt + row0 + x_first);
     s[0] = a.x, s[1] = a.y, s[2] = a.z, s[3] = a.w, s[4] = b4.x, s[5] = b4.y, s[6] = b4.z, s[7] = b4.w;
 #pragma unroll
-    for (int k = 0; k < WX; ++k) n[k] = (int)cv[k];
+    for (int k = 0; k < WX; ++k) n[k] = (NT)cv[k];
   } else {
 #pragma unroll
     for (int k = 0; k < WX; ++k) {
       const int xk = min(x_first + k, g.nx - 1);
       s[k] = g.sdf[row0 + xk];
-      n[k] = (int)cnt[row0 + xk];
+      n[k] = (NT)cnt[row0 + xk];
     }
   }
 
+  // Every voxel of the brick touched (update_num >= 1)?  Wave-uniform; update_num never decreases, so
+  // once true it stays true.  Selects the select-free update (update_max_touched) and one of the two
+  // view-dropping rules.
+  bool all_touched = false;
+  auto refresh_all_touched = [&]() {
+    if (UPDATE != VCY_UPDATE_MAX || all_touched) return;
+    NT nmin = n[0];
+#pragma unroll
+    for (int k = 1; k < WX; ++k) nmin = min(nmin, n[k]);
+    all_touched = __all(nmin >= (NT)1);
+  };
+  if (!fresh) refresh_all_touched();
   // views that may still change something, as a wave-uniform bit mask
-  bool all_touched = false;  // wave-uniform
   auto live_views = [&]() -> unsigned long long {
     bool drop = false;
     if (want_bound) {
       if (TRUNC) drop = ub_lane < -1.0f;
-      if (UPDATE == VCY_UPDATE_MAX) {
+      if (UPDATE == VCY_UPDATE_MAX && all_touched) {
         float m = s[0];
 #pragma unroll
         for (int k = 1; k < WX; ++k) m = fminf(m, s[k]);
-        if (!all_touched) {  // update_num never decreases: once every voxel is touched it stays so
-          int nmin = n[0];
-#pragma unroll
-          for (int k = 1; k < WX; ++k) nmin = min(nmin, n[k]);
-          all_touched = __all(nmin >= 1);
-        }
         const float smin = wave_min(m);
-        drop = drop || (all_touched && ub_lane <= smin);
+        drop = drop || ub_lane <= smin;
       }
     }
     return __ballot(!drop) & view_mask;
@@ -636,7 +734,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
   // ---- views ------------------------------------------------------------------------------
   while (vi < nviews) {
     const ViewParams& v = views[vi].v;
-    cfloat_ptr c0 = (cfloat_ptr)(c0_all + (size_t)vi * 3 * nxp) + x_first;  // rows i at c0 + i * nxp, entry k = voxel k
+    // this view's record of the wave brick's x products: (x, y) pairs at [2 k], z at [16 + k]
+    cfloat_ptr c0 = (cfloat_ptr)(c0_all + ((size_t)vi * (nxp / WX) + (x_first / WX)) * kC0Stride);
     // stage this view's tile (wave-private: program order is enough)
     wave_lds_fence();
     if (kPrefetch) {
@@ -673,7 +772,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
       // operation is still the reference's, in its order (v_pk_* are two independent fp32 ops).
 #pragma unroll
       for (int kp = 0; kp < WX; kp += 2) {
-        const f2 c0z = {c0[2 * nxp + kp], c0[2 * nxp + kp + 1]};
+        const f2 c0z = {c0[16 + kp], c0[16 + kp + 1]};
         const f2 pcz2 = v.t[2] + (c0z + h12z);
         // pinhole: u = fx / z * x + cx (camera.cc:133-136); orthographic: u = x (camera.cc:201-205)
         f2 qx2 = {1.0f, 1.0f}, qy2 = {1.0f, 1.0f};
@@ -685,7 +784,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
         for (int h = 0; h < 2; ++h) {
           const int k = kp + h;
           const float pcz = h ? pcz2.y : pcz2.x;
-          const f2 pcxy = (f2){v.t[0], v.t[1]} + ((f2){c0[k], c0[nxp + k]} + (f2){h12x, h12y});
+          const f2 pcxy = (f2){v.t[0], v.t[1]} + ((f2){c0[2 * k], c0[2 * k + 1]} + (f2){h12x, h12y});
           const f2 uw = is_ortho ? pcxy : (f2){h ? qx2.y : qx2.x, h ? qy2.y : qy2.x} * pcxy + (f2){v.cx, v.cy};
           const float u = uw.x, w = uw.y;
           bool in_tile = true;
@@ -714,7 +813,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
           }
           bool ok = in_tile;
           if (TRUNC) ok = ok && !(dist < -1.0f);
-          if (CHECKMAX) ok = ok && !(n[k] > g.max_update_num);
+          if (CHECKMAX) ok = ok && !(n[k] > (NT)g.max_update_num);
           moved = apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]) || moved;
         }
       }
@@ -724,16 +823,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
           if (slow[k]) {
             float dist = 0.0f;
             bool ok = sample_generic(&v, mode, g.px[min(x_first + k, g.nx - 1)], py, pz, &dist);
-            if (CHECKMAX) ok = ok && !(n[k] > g.max_update_num);
+            if (CHECKMAX) ok = ok && !(n[k] > (NT)g.max_update_num);
             moved = apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]) || moved;
           }
         }
       }
       return __any(moved);
     };
+    // ---- select-free fast path -------------------------------------------------------------
+    // A `sure` tile (every sample provably inside it and inside div_view2's depth range) whose update
+    // needs no per-voxel case distinction: kMax on a brick that is touched everywhere, or the unit-weight
+    // average on a state with "update_num == 0 implies sdf == lowest()".  Same operations as above, in
+    // the same order; what changes is what they cost on the SIMD (see update_max_touched):
+    //  - the LDS byte address of the quad comes out of the float pipeline: with K = 2^23 and every term
+    //    an integer below 2^22, a = fw * (16 tw) + (fu * 16 + (K + 16 base + tile offset)) is exact and
+    //    its low 23 bits ARE the address (2 fma + 1 and instead of fma, cvt, shift-add);
+    //  - wave-uniform factors of per-sample fma's sit in VGPRs (a scalar operand halves the issue rate);
+    //  - the update runs under an EXEC mask.
+    constexpr bool kFastMax = !GEN && UPDATE == VCY_UPDATE_MAX && !TRUNC && !CHECKMAX;
+    constexpr bool kFastWa = !GEN && UPDATE == kUpdateWaUnitWeight && !CHECKMAX;
+    auto carve_view_fast = [&]() -> bool {
+      // uniform -> VGPR (opaque to the compiler, which would otherwise fold them back into SGPR operands)
+      float pitch16, cmagic;
+      {
+        const float p16 = pitchf * 16.0f;  // tw <= 512: exact
+        const unsigned lds_off = (unsigned)(size_t)(lds_float4*)tile;
+        const float cm = 8388608.0f + (float)(16 * base + (int)lds_off);  // |16 base| < 2^22 (TileInfo::sure)
+        asm volatile("v_mov_b32_e32 %0, %1" : "=v"(pitch16) : "s"(p16));
+        asm volatile("v_mov_b32_e32 %0, %1" : "=v"(cmagic) : "s"(cm));
+      }
+      unsigned long long took = 0;
+#pragma unroll
+      for (int kp = 0; kp < WX; kp += 2) {
+        const f2 c0z = {c0[16 + kp], c0[16 + kp + 1]};
+        const f2 pcz2 = v.t[2] + (c0z + h12z);
+        const f2 qx2 = div_view2<DIV>(v.fx, pcz2);
+        const f2 qy2 = SAMEF ? qx2 : div_view2<DIV>(v.fy, pcz2);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int k = kp + h;
+          const f2 pcxy = (f2){v.t[0], v.t[1]} + ((f2){c0[2 * k], c0[2 * k + 1]} + (f2){h12x, h12y});
+          const f2 uw = (f2){h ? qx2.y : qx2.x, h ? qy2.y : qy2.x} * pcxy + (f2){v.cx, v.cy};
+          const float fu = floorf(uw.x), fw = floorf(uw.y);
+          const float lu = uw.x - fu, lv = uw.y - fw;
+          const float a = __builtin_fmaf(fw, pitch16, __builtin_fmaf(fu, 16.0f, cmagic));
+          const f4 q = *(const lds_float4*)(size_t)(__float_as_uint(a) & 0x7fffffu);
+          const float mu = 1.0f - lu, mv = 1.0f - lv;
+          const float dist = ((((mu * mv) * q.x) + ((lu * mv) * q.y)) + ((mu * lv) * q.z)) + ((lu * lv) * q.w);
+          if constexpr (kFastMax) took |= update_max_touched(dist, s[k], n[k]);
+          else if constexpr (kFastWa) update_wa_unit<TRUNC>(dist, s[k], n[k]);
+        }
+      }
+      return kFastMax ? took != 0ull : true;
+    };
     bool brick_moved;
-    if (!GEN && __builtin_amdgcn_readfirstlane(tinfo[vi].sure) != 0) brick_moved = carve_view(std::true_type{});
+    const bool sure = !GEN && __builtin_amdgcn_readfirstlane(tinfo[vi].sure) != 0;
+    if ((kFastMax && sure && all_touched) || (kFastWa && sure && implied)) brick_moved = carve_view_fast();
+    else if (sure) brick_moved = carve_view(std::true_type{});
     else brick_moved = carve_view(std::false_type{});
+    refresh_all_touched();
 
     // state moved: some of the remaining views may have become droppable (min(sdf) only grows)
     // (an unchanged brick leaves every bound comparison as it was)
@@ -755,7 +903,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
       if (!fresh) {
         const CountVec cv = *(const CountVec*)(cnt + row0 + x_first);
 #pragma unroll
-        for (int k = 0; k < WX; ++k) changed = changed || n[k] != (int)cv[k];
+        for (int k = 0; k < WX; ++k) changed = changed || (int)n[k] != (int)cv[k];
       }
       if (changed) {
         *(float4*)(g.sdf + row0 + x_first) = make_float4(s[0], s[1], s[2], s[3]);
@@ -770,7 +918,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
       for (int k = 0; k < WX; ++k) {
         if (x_first + k < g.nx) {
           const int64_t idx = row0 + x_first + k;
-          if (fresh || n[k] != (int)cnt[idx]) {
+          if (fresh || (int)n[k] != (int)cnt[idx]) {
             g.sdf[idx] = s[k];
             cnt[idx] = (CountT)n[k];
           }
@@ -894,13 +1042,20 @@ bool fused_eligible(const vcy_ctx* c, int n_views, const vcy_view* views) {
 int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewParams* vp) {
   const vcy_update_option& u = c->opt.update_option;
   const int nzl = c->nz_local();
-  // per-view tables c0[i][x] = R[i][0] * px[x], padded to whole bricks with the last column
-  const int nxp = (c->nx + WX - 1) / WX * WX;
-  std::vector<float> c2((size_t)n_views * 3 * nxp);
+  // per-view records of c0 = R[i][0] * px[x] for every wave brick along x (layout: kC0Stride above);
+  // columns beyond nx repeat the last one
+  const int nxp = (c->nx + WX - 1) / WX * WX, nbw = nxp / WX;
+  std::vector<float> c2((size_t)n_views * nbw * kC0Stride, 0.0f);
   for (int vi = 0; vi < n_views; ++vi)
-    for (int i = 0; i < 3; ++i)
-      for (int x = 0; x < nxp; ++x)
-        c2[((size_t)vi * 3 + i) * nxp + x] = vp[vi].r[i][0] * c->h_px[std::min(x, c->nx - 1)];
+    for (int b = 0; b < nbw; ++b) {
+      float* rec = &c2[((size_t)vi * nbw + b) * kC0Stride];
+      for (int k = 0; k < WX; ++k) {
+        const float px = c->h_px[std::min(b * WX + k, c->nx - 1)];
+        rec[2 * k + 0] = vp[vi].r[0][0] * px;
+        rec[2 * k + 1] = vp[vi].r[1][0] * px;
+        rec[16 + k] = vp[vi].r[2][0] * px;
+      }
+    }
   const size_t c2_bytes = c2.size() * sizeof(float);
   const size_t fv_bytes = sizeof(FusedView) * (size_t)n_views;
   // staging buffer owned by the context, grown on demand
@@ -1048,12 +1203,13 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     if (c->tile_mode == 1) big = false;
     if (c->tile_mode == 2) big = true;
   }
+  const int state_flags = (c->fresh ? 1 : 0) | (c->cnt_implied ? 2 : 0);
   if (c->cnt_bytes == 1)
     launch_fused_1<uint8_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, g, d_views,
-                            d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, c->fresh ? 1 : 0);
+                            d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, state_flags);
   else
     launch_fused_1<uint16_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, g, d_views,
-                             d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, c->fresh ? 1 : 0);
+                             d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, state_flags);
   VCY_HIP_CHECK(hipGetLastError());
   c->fresh = false;  // the launch stores every voxel of a fresh slab
   return VCY_OK;
