@@ -92,38 +92,24 @@ __device__ __forceinline__ float div_fast(float n, float d) {
   return __builtin_fmaf(e3, r, q);
 }
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-// div_fast on two values at once (v_pk_fma_f32 / v_pk_mul_f32; v_rcp_f32 has no packed form)
-__device__ __forceinline__ f2 div_fast2(float n, f2 d) {
-  const f2 nn = {n, n}, one = {1.0f, 1.0f};
-  f2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-  const f2 e = __builtin_elementwise_fma(-d, r, one);
-  r = __builtin_elementwise_fma(e, r, r);
-  f2 q = nn * r;
-  const f2 e2 = __builtin_elementwise_fma(-d, q, nn);
-  q = __builtin_elementwise_fma(e2, r, q);
-  const f2 e3 = __builtin_elementwise_fma(-d, q, nn);
-  return __builtin_elementwise_fma(e3, r, q);
-}
-
 // Shorter sequences for n / d.  They are NOT correct for every pair of floats, but for a given numerator
 // they usually are for EVERY denominator: the host checks that exhaustively on the device, once per
 // focal length (div_level below: all 2^23 significands in each of the 121 binades [2^-60, 2^61) the fast
 // path admits), and only then selects the variant.  DIV 2: v_rcp_f32, one multiply, one correction;
-// DIV 1: Newton step on the reciprocal first; DIV 0: the full IEEE expansion (div_fast2).
+// DIV 1: Newton step on the reciprocal first; DIV 0: the full IEEE expansion (div_fast).
+// Plain (unpacked) fp32 throughout: on MI355X v_pk_*_f32 issue at half rate AND slow the scalar
+// fp32 instructions around them (profiles/r02/valu_ubench.txt), while v_mul/v_fma_f32 issue every 2 cycles.
 template <int DIV>
-__device__ __forceinline__ f2 div_view2(float n, f2 d) {
-  if (DIV == 0) return div_fast2(n, d);
-  const f2 nn = {n, n}, one = {1.0f, 1.0f};
-  f2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+__device__ __forceinline__ float div_view(float n, float d) {
+  if (DIV == 0) return div_fast(n, d);
+  float r = __builtin_amdgcn_rcpf(d);
   if (DIV == 1) {
-    const f2 e = __builtin_elementwise_fma(-d, r, one);
-    r = __builtin_elementwise_fma(e, r, r);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
   }
-  const f2 q = nn * r;
-  const f2 e2 = __builtin_elementwise_fma(-d, q, nn);
-  return __builtin_elementwise_fma(e2, r, q);
+  const float q = n * r;
+  const float e2 = __builtin_fmaf(-d, q, n);
+  return __builtin_fmaf(e2, r, q);
 }
 
 __device__ __forceinline__ float div_view1(int div, float n, float d) {  // scalar twin, for the checker
@@ -201,28 +187,24 @@ __device__ __forceinline__ bool apply_sample(bool ok, float dist, float wgt, flo
   return ok;
 }
 
-// ---- full-rate update sequences ---------------------------------------------------------------
-// Measured on MI355X (profiles/r02/valu_ubench.txt): v_add/sub/mul/fma_f32, v_mov_b32 and v_add_u32 issue
-// in 2 SIMD cycles per wave; compares, selects, carries, conversions, min/max and ANY VALU instruction
-// with a scalar-register operand take 4.  The select forms of the update rules cost 12 (kMax) to ~50
-// (weighted average) cycles per sample; executed under an EXEC mask they are moves and adds.
+// ---- update sequences of the fast path ---------------------------------------------------------
+// Measured on MI355X (profiles/r02/valu_ubench.txt): a compare / select / carry chain through VCC (the
+// VOPC / VOP2 encodings) issues in about 3.5 cycles per instruction and overlaps with full-rate fp32
+// instructions of other voxels; the same chain through an arbitrary SGPR pair (VOP3 encodings, what the
+// compiler picks once several voxels are in flight) takes 7 per instruction, and an EXEC-masked variant
+// (v_cmpx) more.  The chains are therefore written out with VCC.
 //
 // UpdateVoxelMax for a voxel that has been touched before (voxel_carver.cc:78-86):
 //   if (dist > sdf) { sdf = dist; ++update_num; }      -- NaN compares false, -0 == +0 stay put
-// v_cmpx writes the lanes where the test holds to EXEC (and to `took`); the two updates then run on those
-// lanes only.  Returns the lanes that changed.
-__device__ __forceinline__ unsigned long long update_max_touched(float dist, float& s, int& n) {
-  unsigned long long took, saved;
-  asm volatile(
-      "s_mov_b64 %[saved], exec\n\t"
-      "v_cmpx_gt_f32_e64 %[took], %[d], %[s]\n\t"
-      "v_mov_b32_e32 %[s], %[d]\n\t"
-      "v_add_u32_e32 %[n], 1, %[n]\n\t"
-      "s_mov_b64 exec, %[saved]"
-      : [s] "+v"(s), [n] "+v"(n), [took] "=&s"(took), [saved] "=&s"(saved)
+// `took` accumulates the lanes that changed.
+__device__ __forceinline__ void update_max_touched(float dist, float& s, int& n, unsigned long long& took) {
+  asm("v_cmp_gt_f32_e32 vcc, %[d], %[s]\n\t"
+      "s_or_b64 %[took], %[took], vcc\n\t"
+      "v_cndmask_b32_e32 %[s], %[s], %[d], vcc\n\t"
+      "v_addc_co_u32_e32 %[n], vcc, 0, %[n], vcc"
+      : [s] "+v"(s), [n] "+v"(n), [took] "+s"(took)
       : [d] "v"(dist)
-      : "memory");
-  return took;
+      : "vcc");
 }
 
 // UpdateVoxelWeightedAverage with voxel_update_weight == 1 (voxel_carver.cc:88-95) behind the truncation
@@ -234,28 +216,17 @@ __device__ __forceinline__ unsigned long long update_max_touched(float dist, flo
 // case, (0 * sdf + dist) * 1 == dist bit for bit (0 * lowest() = -0, -0 + dist = dist).
 template <bool TRUNC>
 __device__ __forceinline__ void update_wa_unit(float dist, float& s, float& fn) {
-  unsigned long long saved, took;
-  float f1, r, e;
+  const float f1 = fn + 1.0f;
+  const float avg = (fn * s + dist) * rcp_count(f1);
   if (TRUNC) {
-    asm volatile(
-        "s_mov_b64 %[saved], exec\n\t"
-        "v_cmpx_nlt_f32_e64 %[took], %[d], -1.0\n\t"
-        "v_add_f32_e32 %[f1], 1.0, %[fn]\n\t"
-        "v_mul_f32_e32 %[s], %[fn], %[s]\n\t"
-        "v_rcp_f32_e32 %[r], %[f1]\n\t"
-        "v_add_f32_e32 %[s], %[s], %[d]\n\t"
-        "v_mov_b32_e32 %[fn], %[f1]\n\t"
-        "v_fma_f32 %[e], -%[f1], %[r], 1.0\n\t"
-        "v_fmac_f32_e32 %[r], %[e], %[r]\n\t"
-        "v_mul_f32_e32 %[s], %[s], %[r]\n\t"
-        "s_mov_b64 exec, %[saved]"
-        : [s] "+v"(s), [fn] "+v"(fn), [took] "=&s"(took), [saved] "=&s"(saved), [f1] "=&v"(f1), [r] "=&v"(r),
-          [e] "=&v"(e)
-        : [d] "v"(dist)
-        : "memory");
+    asm("v_cmp_ngt_f32_e32 vcc, -1.0, %[d]\n\t"   // !(-1 > d)  ==  !(d < -1), true for NaN like the reference
+        "v_cndmask_b32_e32 %[s], %[s], %[avg], vcc\n\t"
+        "v_cndmask_b32_e32 %[fn], %[fn], %[f1], vcc"
+        : [s] "+v"(s), [fn] "+v"(fn)
+        : [d] "v"(dist), [avg] "v"(avg), [f1] "v"(f1)
+        : "vcc");
   } else {
-    f1 = fn + 1.0f;
-    s = (fn * s + dist) * rcp_count(f1);
+    s = avg;
     fn = f1;
   }
 }
@@ -767,55 +738,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
       bool slow[WX];
       bool any_slow = false;
       bool moved = false;  // some voxel of this lane changed
-      // Two voxels (k, k+1) share the packed-FP32 instructions of the depth and of the divide;
-      // within a voxel the (x, y) pair and the (1-l, l) weight pairs are packed.  Every single
-      // operation is still the reference's, in its order (v_pk_* are two independent fp32 ops).
+      // Every operation is the reference's, in its order, as plain fp32 instructions.
 #pragma unroll
-      for (int kp = 0; kp < WX; kp += 2) {
-        const f2 c0z = {c0[16 + kp], c0[16 + kp + 1]};
-        const f2 pcz2 = v.t[2] + (c0z + h12z);
+      for (int k = 0; k < WX; ++k) {
+        const float pcz = v.t[2] + (c0[16 + k] + h12z);
         // pinhole: u = fx / z * x + cx (camera.cc:133-136); orthographic: u = x (camera.cc:201-205)
-        f2 qx2 = {1.0f, 1.0f}, qy2 = {1.0f, 1.0f};
+        float qx = 1.0f, qy = 1.0f;
         if (!is_ortho) {
-          qx2 = div_view2<DIV>(v.fx, pcz2);
-          qy2 = SAMEF ? qx2 : div_view2<DIV>(v.fy, pcz2);
+          qx = div_view<DIV>(v.fx, pcz);
+          qy = SAMEF ? qx : div_view<DIV>(v.fy, pcz);
         }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int k = kp + h;
-          const float pcz = h ? pcz2.y : pcz2.x;
-          const f2 pcxy = (f2){v.t[0], v.t[1]} + ((f2){c0[2 * k], c0[2 * k + 1]} + (f2){h12x, h12y});
-          const f2 uw = is_ortho ? pcxy : (f2){h ? qx2.y : qx2.x, h ? qy2.y : qy2.x} * pcxy + (f2){v.cx, v.cy};
-          const float u = uw.x, w = uw.y;
-          bool in_tile = true;
-          if (!SURE) {
-            // orthographic: only `pc.z < 0` is skipped (voxel_carver.cc:456)
-            const bool zfast = is_ortho ? !(pcz < 0.0f) : in_fast_div_range(pcz);
-            in_tile = zfast && u >= lo_x && u <= hi_x && w >= lo_y && w <= hi_y;
-            slow[k] = !in_tile;
-            any_slow = any_slow || !in_tile;
-          }
-          const float fu = floorf(u), fw = floorf(w);
-          const float lu = u - fu, lv = w - fw;
-          const f2 P = {1.0f - lu, lu}, Q = {1.0f - lv, lv};
-          // any index is harmless when !in_tile (the sample is discarded); keep it inside the tile
-          unsigned idx = (unsigned)((int)__builtin_fmaf(fw, pitchf, fu) + base);
-          if (!SURE) idx = min(idx, (unsigned)(TQ - 1));
-          const float4 q = tile[idx];
-          const f2 ab = (P * Q.x) * (f2){q.x, q.y};   // ((1-lu)(1-lv)) s00 , (lu (1-lv)) s10
-          const f2 cd = (P * Q.y) * (f2){q.z, q.w};   // ((1-lu) lv) s01   , (lu lv) s11
-          float dist = ((ab.x + ab.y) + cd.x) + cd.y;
-          if (is_nn) {
-            // SdfInterpolationNn (voxel_carver.cc:16-38): round half away from zero == floor + (frac >= .5)
-            // for the non-negative in-ROI coordinates; the quad already holds the ROI-clamped neighbours
-            const float top = lu >= 0.5f ? q.y : q.x, bot = lu >= 0.5f ? q.w : q.z;
-            dist = lv >= 0.5f ? bot : top;
-          }
-          bool ok = in_tile;
-          if (TRUNC) ok = ok && !(dist < -1.0f);
-          if (CHECKMAX) ok = ok && !(n[k] > (NT)g.max_update_num);
-          moved = apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]) || moved;
+        const float pcx = v.t[0] + (c0[2 * k] + h12x), pcy = v.t[1] + (c0[2 * k + 1] + h12y);
+        const float u = is_ortho ? pcx : qx * pcx + v.cx;
+        const float w = is_ortho ? pcy : qy * pcy + v.cy;
+        bool in_tile = true;
+        if (!SURE) {
+          // orthographic: only `pc.z < 0` is skipped (voxel_carver.cc:456)
+          const bool zfast = is_ortho ? !(pcz < 0.0f) : in_fast_div_range(pcz);
+          in_tile = zfast && u >= lo_x && u <= hi_x && w >= lo_y && w <= hi_y;
+          slow[k] = !in_tile;
+          any_slow = any_slow || !in_tile;
         }
+        const float fu = floorf(u), fw = floorf(w);
+        const float lu = u - fu, lv = w - fw;
+        const float mu = 1.0f - lu, mv = 1.0f - lv;
+        // any index is harmless when !in_tile (the sample is discarded); keep it inside the tile
+        unsigned idx = (unsigned)((int)__builtin_fmaf(fw, pitchf, fu) + base);
+        if (!SURE) idx = min(idx, (unsigned)(TQ - 1));
+        const float4 q = tile[idx];
+        // ((1-lu)(1-lv)) s00 + (lu (1-lv)) s10 + ((1-lu) lv) s01 + (lu lv) s11, summed left to right (:69-73)
+        float dist = ((((mu * mv) * q.x) + ((lu * mv) * q.y)) + ((mu * lv) * q.z)) + ((lu * lv) * q.w);
+        if (is_nn) {
+          // SdfInterpolationNn (voxel_carver.cc:16-38): round half away from zero == floor + (frac >= .5)
+          // for the non-negative in-ROI coordinates; the quad already holds the ROI-clamped neighbours
+          const float top = lu >= 0.5f ? q.y : q.x, bot = lu >= 0.5f ? q.w : q.z;
+          dist = lv >= 0.5f ? bot : top;
+        }
+        bool ok = in_tile;
+        if (TRUNC) ok = ok && !(dist < -1.0f);
+        if (CHECKMAX) ok = ok && !(n[k] > (NT)g.max_update_num);
+        moved = apply_sample<UPDATE>(ok, dist, g.weight, s[k], n[k]) || moved;
       }
       if (!SURE && any_slow) {
 #pragma unroll
@@ -834,12 +796,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
     // A `sure` tile (every sample provably inside it and inside div_view2's depth range) whose update
     // needs no per-voxel case distinction: kMax on a brick that is touched everywhere, or the unit-weight
     // average on a state with "update_num == 0 implies sdf == lowest()".  Same operations as above, in
-    // the same order; what changes is what they cost on the SIMD (see update_max_touched):
+    // the same order; what changes is what they cost on the SIMD:
     //  - the LDS byte address of the quad comes out of the float pipeline: with K = 2^23 and every term
     //    an integer below 2^22, a = fw * (16 tw) + (fu * 16 + (K + 16 base + tile offset)) is exact and
     //    its low 23 bits ARE the address (2 fma + 1 and instead of fma, cvt, shift-add);
     //  - wave-uniform factors of per-sample fma's sit in VGPRs (a scalar operand halves the issue rate);
-    //  - the update runs under an EXEC mask.
+    //  - the update is a compare / select / carry chain through VCC (update_max_touched).
     constexpr bool kFastMax = !GEN && UPDATE == VCY_UPDATE_MAX && !TRUNC && !CHECKMAX;
     constexpr bool kFastWa = !GEN && UPDATE == kUpdateWaUnitWeight && !CHECKMAX;
     auto carve_view_fast = [&]() -> bool {
@@ -852,25 +814,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
         asm volatile("v_mov_b32_e32 %0, %1" : "=v"(pitch16) : "s"(p16));
         asm volatile("v_mov_b32_e32 %0, %1" : "=v"(cmagic) : "s"(cm));
       }
+      // Four voxels at a time.  Phase A: image coordinates, fractions and the LDS reads (in flight
+      // together); phase B: weights, sample, update.
       unsigned long long took = 0;
 #pragma unroll
-      for (int kp = 0; kp < WX; kp += 2) {
-        const f2 c0z = {c0[16 + kp], c0[16 + kp + 1]};
-        const f2 pcz2 = v.t[2] + (c0z + h12z);
-        const f2 qx2 = div_view2<DIV>(v.fx, pcz2);
-        const f2 qy2 = SAMEF ? qx2 : div_view2<DIV>(v.fy, pcz2);
+      for (int k0 = 0; k0 < WX; k0 += 4) {
+        float lu[4], lv[4];
+        f4 q[4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int k = kp + h;
-          const f2 pcxy = (f2){v.t[0], v.t[1]} + ((f2){c0[2 * k], c0[2 * k + 1]} + (f2){h12x, h12y});
-          const f2 uw = (f2){h ? qx2.y : qx2.x, h ? qy2.y : qy2.x} * pcxy + (f2){v.cx, v.cy};
-          const float fu = floorf(uw.x), fw = floorf(uw.y);
-          const float lu = uw.x - fu, lv = uw.y - fw;
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + j;
+          const float pcz = v.t[2] + (c0[16 + k] + h12z);
+          const float qx = div_view<DIV>(v.fx, pcz);
+          const float qy = SAMEF ? qx : div_view<DIV>(v.fy, pcz);
+          const float pcx = v.t[0] + (c0[2 * k] + h12x), pcy = v.t[1] + (c0[2 * k + 1] + h12y);
+          const float u = qx * pcx + v.cx, w = qy * pcy + v.cy;
+          const float fu = floorf(u), fw = floorf(w);
+          lu[j] = u - fu;
+          lv[j] = w - fw;
           const float a = __builtin_fmaf(fw, pitch16, __builtin_fmaf(fu, 16.0f, cmagic));
-          const f4 q = *(const lds_float4*)(size_t)(__float_as_uint(a) & 0x7fffffu);
-          const float mu = 1.0f - lu, mv = 1.0f - lv;
-          const float dist = ((((mu * mv) * q.x) + ((lu * mv) * q.y)) + ((mu * lv) * q.z)) + ((lu * lv) * q.w);
-          if constexpr (kFastMax) took |= update_max_touched(dist, s[k], n[k]);
+          q[j] = *(const lds_float4*)(size_t)(__float_as_uint(a) & 0x7fffffu);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + j;
+          const float mu = 1.0f - lu[j], mv = 1.0f - lv[j];
+          const float dist =
+              ((((mu * mv) * q[j].x) + ((lu[j] * mv) * q[j].y)) + ((mu * lv[j]) * q[j].z)) + ((lu[j] * lv[j]) * q[j].w);
+          if constexpr (kFastMax) update_max_touched(dist, s[k], n[k], took);
           else if constexpr (kFastWa) update_wa_unit<TRUNC>(dist, s[k], n[k]);
         }
       }
