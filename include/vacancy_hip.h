@@ -186,6 +186,10 @@ void vcy_mesh_free(vcy_mesh* mesh);
  * context's stream: classify + owner + scan + emit; the mesh download is not included).
  * This is the region the reference's MarchingCubes timer brackets, minus the copy into Mesh. */
 int vcy_last_extract_ms(const vcy_ctx* ctx, float* device_ms);
+/* Milliseconds from the entry of the last vcy_extract_iso to its return, i.e. until the mesh arrays are
+ * in host memory: the region the reference's MarchingCubes timer brackets (marching_cubes.cc:65-66,
+ * 226-227).  The arrays of a vcy_mesh are page-locked host memory from a pool owned by the library. */
+int vcy_last_extract_wall_ms(const vcy_ctx* ctx, float* wall_ms);
 
 /* ---- state access (tests, ExtractVoxel on the host, checkpoint) ---------- */
 

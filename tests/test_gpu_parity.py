@@ -252,6 +252,38 @@ def test_marching_cubes_random_state():
                               "random iso=%s interp=%s" % (iso, interp))
 
 
+def test_extract_voxel_predicates_on_adversarial_state():
+    """ExtractVoxel's keep predicates run on the device (extract_voxel.hip): both of them on uploaded state
+    with zeros of either sign, denormals, products that underflow to -0 or to the smallest denormal,
+    infinities, NaN, untouched voxels and invalid values, for every counter width and a grid whose rows are
+    not multiples of 64; and on a fresh grid (nothing kept)."""
+    rng = np.random.RandomState(11)
+    special = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-39, -1e-39, 1.1754944e-38, -1.1754944e-38, 1e-23, -1e-23,
+                        2.0**-75, -(2.0**-75), 2.0**-74, -(2.0**-74), 2.0**-76, -(2.0**-76), 1.5 * 2.0**-75,
+                        np.inf, -np.inf, np.nan, 1.0, -1.0, np.finfo(np.float32).min], dtype=np.float32)
+    for max_update in (200, 255, 70000):  # u8, u16, u32 counters
+        opt = vc.CarverOption(bb_min=(0, 0, 0), bb_max=(67, 9, 13), resolution=1.0,
+                              update_option=UpdateOption(voxel_max_update_num=max_update))
+        dev = vc.VoxelCarver(opt)
+        assert dev.Init(), vc.last_error()
+        orc = O.OracleGrid(opt)
+        for inside_empty in (False, True):  # fresh: an empty mesh
+            dv = dev.ExtractVoxel(inside_empty)
+            assert len(dv["vertices"]) == 0 and len(dv["faces"]) == 0
+        nvox = orc.n
+        sdf = rng.uniform(-1, 1, nvox).astype(np.float32)
+        pick = rng.rand(nvox) < 0.5
+        sdf[pick] = special[rng.randint(0, len(special), int(pick.sum()))]
+        cnt = rng.randint(0, 3, nvox).astype(np.int32)
+        dev.upload(sdf, cnt)
+        orc.upload(sdf, cnt)
+        for inside_empty in (False, True):
+            dv, ov = dev.ExtractVoxel(inside_empty), orc.extract_voxel(inside_empty)
+            assert len(ov["faces"]) > 0
+            assert np.array_equal(dv["faces"], ov["faces"]), (max_update, inside_empty)
+            assert np.array_equal(dv["vertices"].view(np.uint32), ov["vertices"].view(np.uint32)), (max_update, inside_empty)
+
+
 def test_degenerate_grids_and_errors():
     # 1-voxel-thick grids have no cells: empty mesh, like the reference's loops from 1
     opt = vc.CarverOption(bb_min=(0, 0, 0), bb_max=(8, 8, 1), resolution=1.0)

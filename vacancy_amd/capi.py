@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvacancy_hip.so")
+# VCY_HIP_LIB: another build of the same library (kernel variants under development, profiles/tools/build_variant.sh)
+LIB_PATH = os.environ.get("VCY_HIP_LIB") or os.path.join(_HERE, "csrc", "libvacancy_hip.so")
 
 VCY_UPDATE_MAX, VCY_UPDATE_WEIGHTED_AVERAGE = 0, 1
 VCY_INTERP_NN, VCY_INTERP_BILINEAR = 0, 1
@@ -127,6 +128,7 @@ def load():
         "vcy_extract_voxel": (C.c_int, [vp, C.c_int, P(Mesh)]),
         "vcy_mesh_free": (None, [P(Mesh)]),
         "vcy_last_extract_ms": (C.c_int, [vp, P(C.c_float)]),
+        "vcy_last_extract_wall_ms": (C.c_int, [vp, P(C.c_float)]),
         "vcy_download": (C.c_int, [vp, vp, vp]),
         "vcy_upload": (C.c_int, [vp, vp, vp]),
         "vcy_download_positions": (C.c_int, [vp, vp]),

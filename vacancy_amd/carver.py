@@ -17,6 +17,13 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _mesh_array(ptr, count, width, dtype):
+    """Copy of `count` rows of `width` from a library-owned mesh array (NULL when the mesh is empty)."""
+    if count == 0 or not ptr:
+        return np.zeros((0, width), dtype)
+    return np.ctypeslib.as_array(ptr, shape=(count * width,)).reshape(count, width).copy()
+
+
 def last_error():
     return capi.load().vcy_last_error().decode()
 
@@ -162,15 +169,17 @@ class VoxelCarver:
             raise RuntimeError(last_error())
         nv, nf = m.n_vertices, m.n_faces
         out = {
-            "vertices": np.ctypeslib.as_array(m.vertices, shape=(max(nv, 1) * 3,))[: nv * 3].reshape(nv, 3).copy(),
-            "faces": np.ctypeslib.as_array(m.faces, shape=(max(nf, 1) * 3,))[: nf * 3].reshape(nf, 3).copy(),
-            "keys": np.ctypeslib.as_array(m.edge_keys, shape=(max(nv, 1) * 2,))[: nv * 2].reshape(nv, 2).copy(),
+            "vertices": _mesh_array(m.vertices, nv, 3, np.float32),
+            "faces": _mesh_array(m.faces, nf, 3, np.int32),
+            "keys": _mesh_array(m.edge_keys, nv, 2, np.int64),
             "n_foreign": int(m.n_foreign_vertices),
         }
         self._lib.vcy_mesh_free(C.byref(m))
         ms = C.c_float()
         self._lib.vcy_last_extract_ms(self._ctx, C.byref(ms))
         out["device_ms"] = ms.value
+        self._lib.vcy_last_extract_wall_ms(self._ctx, C.byref(ms))
+        out["wall_ms"] = ms.value  # vcy_extract_iso entry -> mesh arrays in host memory
         return out
 
     # -- ExtractVoxel(mesh, inside_empty)  (voxel_carver.cc:530-538)
@@ -182,8 +191,8 @@ class VoxelCarver:
             raise RuntimeError(last_error())
         nv, nf = m.n_vertices, m.n_faces
         out = {
-            "vertices": np.ctypeslib.as_array(m.vertices, shape=(max(nv, 1) * 3,))[: nv * 3].reshape(nv, 3).copy(),
-            "faces": np.ctypeslib.as_array(m.faces, shape=(max(nf, 1) * 3,))[: nf * 3].reshape(nf, 3).copy(),
+            "vertices": _mesh_array(m.vertices, nv, 3, np.float32),
+            "faces": _mesh_array(m.faces, nf, 3, np.int32),
         }
         self._lib.vcy_mesh_free(C.byref(m))
         return out

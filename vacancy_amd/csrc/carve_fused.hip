@@ -47,6 +47,32 @@ constexpr int kTileBig = 512;            // 8 KB per wave: footprints up to ~1.4
 
 constexpr int kWmaxPlanes = 2;           // window sizes 4 and 8
 
+// Development build only (-DVCY_PHASE_TIMING, profiles/tools/phase_timing.py): s_memtime ticks of every wave,
+// accumulated per phase of the fused kernel.  Slots 0-6: prologue + state load, tile staging, select-free
+// view, sure view, checked view, re-bounding after a change, write-back; 7-9: views taken by the three
+// loops; 10: waves; 11: views that changed their brick.
+#ifdef VCY_PHASE_TIMING
+__device__ unsigned long long g_phase_ticks[256][16];
+#define VCY_PT_DECL unsigned long long pt_last = __builtin_amdgcn_s_memtime(), pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define VCY_PT(slot)                                                  \
+  do {                                                                \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
+    pt_acc[slot] += t_ - pt_last;                                     \
+    pt_last = t_;                                                     \
+  } while (0)
+#define VCY_PT_COUNT(slot) pt_acc[slot] += 1
+#define VCY_PT_FLUSH(lane_)                                                                         \
+  do {                                                                                              \
+    if ((lane_) == 0)                                                                               \
+      for (int q_ = 0; q_ < 12; ++q_) atomicAdd(&g_phase_ticks[blockIdx.x & 255][q_], pt_acc[q_]);  \
+  } while (0)
+#else
+#define VCY_PT_DECL
+#define VCY_PT(slot)
+#define VCY_PT_COUNT(slot)
+#define VCY_PT_FLUSH(lane_)
+#endif
+
 struct FusedView {
   ViewParams v;
   // Window maxima of the SDF image (built per launch by wmax_k4 / wmax_k8 below), or null:
@@ -590,6 +616,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
+  VCY_PT_DECL;
   float4* tile = fused_lds + wave * TQ;
   TileInfo* tinfo = (TileInfo*)(fused_lds + 4 * TQ) + wave * nviews;
   const int ly = lane & (BY - 1), lz = lane >> 3;
@@ -701,6 +728,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
   QuadRegs pre;
   pre.q0 = pre.q1 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (kPrefetch && vi < nviews) tile_prefetch(views[vi].v, tinfo[vi], lane, &pre);
+  VCY_PT(0);
+  VCY_PT_COUNT(10);
 
   // ---- views ------------------------------------------------------------------------------
   while (vi < nviews) {
@@ -728,6 +757,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
     // c1 + c2 of this lane's (y, z): the inner sum of pc = t + (c0 + (c1 + c2)) (voxel_carver.cc:453)
     const float h12x = v.r[0][1] * py + v.r[0][2] * pz, h12y = v.r[1][1] * py + v.r[1][2] * pz;
     const float h12z = v.r[2][1] * py + v.r[2][2] * pz;
+    VCY_PT(1);
 
     // Straight-line fast path for the 8 voxels of this thread (no divergent control flow, so
     // the eight LDS reads and the arithmetic interleave); voxels the tile does not cover are
@@ -849,9 +879,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
     };
     bool brick_moved;
     const bool sure = !GEN && __builtin_amdgcn_readfirstlane(tinfo[vi].sure) != 0;
-    if ((kFastMax && sure && all_touched) || (kFastWa && sure && implied)) brick_moved = carve_view_fast();
-    else if (sure) brick_moved = carve_view(std::true_type{});
-    else brick_moved = carve_view(std::false_type{});
+    if ((kFastMax && sure && all_touched) || (kFastWa && sure && implied)) {
+      brick_moved = carve_view_fast();
+      VCY_PT(2);
+      VCY_PT_COUNT(7);
+    } else if (sure) {
+      brick_moved = carve_view(std::true_type{});
+      VCY_PT(3);
+      VCY_PT_COUNT(8);
+    } else {
+      brick_moved = carve_view(std::false_type{});
+      VCY_PT(4);
+      VCY_PT_COUNT(9);
+    }
+    if (brick_moved) VCY_PT_COUNT(11);
     refresh_all_touched();
 
     // state moved: some of the remaining views may have become droppable (min(sdf) only grows)
@@ -865,6 +906,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
       }
     }
     vi = vnext;
+    VCY_PT(5);
   }
 
   // ---- write back what changed (update_num grows with every change) ----------------------------
@@ -897,6 +939,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
       }
     }
   }
+  VCY_PT(6);
+  VCY_PT_FLUSH(lane);
 }
 
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF>
@@ -914,11 +958,22 @@ void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const Gri
     else if (m.div_level == 1) VCY_FUSED(CM, TQ_, false, 1);                                                     \
     else VCY_FUSED(CM, TQ_, false, 0);                                                                           \
   } while (0)
+#ifdef VCY_DEV_BENCH_KERNELS_ONLY
+  // development builds (profiles/tools/build_variant.sh): only the instantiations bench.py launches,
+  // a 20x shorter compile; anything else aborts
+  if (big || checkmax || gen || m.div_level != 2 || !SAMEF || sizeof(CountT) != 2 ||
+      UPDATE == VCY_UPDATE_WEIGHTED_AVERAGE) {
+    fprintf(stderr, "VCY_DEV_BENCH_KERNELS_ONLY: kernel variant not built\n");
+    abort();
+  }
+  if constexpr (SAMEF && sizeof(CountT) == 2 && UPDATE != VCY_UPDATE_WEIGHTED_AVERAGE) VCY_FUSED(false, kTileSmall, false, 2);
+#else
   if (big) {
     if (checkmax) VCY_FUSED_G(true, kTileBig); else VCY_FUSED_G(false, kTileBig);
   } else {
     if (checkmax) VCY_FUSED_G(true, kTileSmall); else VCY_FUSED_G(false, kTileSmall);
   }
+#endif
 #undef VCY_FUSED_G
 #undef VCY_FUSED
 }
@@ -1187,6 +1242,25 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
 }
 
 int fused_max_views() { return kMaxFusedViews; }
+
+#ifdef VCY_PHASE_TIMING
+}  // namespace vcy
+// development build only: reads (and optionally clears) the phase counters of the fused kernel
+extern "C" int vcy_debug_phase_ticks(unsigned long long* out12, int reset) {
+  unsigned long long h[256][16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(vcy::g_phase_ticks), sizeof(h)) != hipSuccess) return -1;
+  for (int q = 0; q < 12; ++q) {
+    out12[q] = 0;
+    for (int b = 0; b < 256; ++b) out12[q] += h[b][q];
+  }
+  if (reset) {
+    std::memset(h, 0, sizeof(h));
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vcy::g_phase_ticks), h, sizeof(h)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+namespace vcy {
+#endif
 
 namespace {
 __global__ void selftest_rcp_count_kernel(int* n_bad) {

@@ -1,0 +1,233 @@
+// ExtractVoxel -- the cube-per-voxel visualisation mesh.
+//
+// Replaces ExtractVoxel() / UpdateOnSurface() (reference src/vacancy/extract_voxel.cc:258-317,
+// :15-79) with MakeCube (src/vacancy/mesh.cc:728-798).
+//
+// What is parallel runs on the device, on the resident state: the keep predicate of every voxel
+// (`sdf <= 0 && update_num >= 1`, or the on-surface sign tests against the -x / -y / -z neighbours) is
+// balloted into a bit plane, counted per block, scanned, and the kept voxel ids are compacted in scan
+// order.  Only that list crosses PCIe (8 B per kept voxel instead of 5-8 B per voxel of the grid).
+//
+// What is serial stays on the host, and that is not a shortcut: the reference moves ONE cube mesh to
+// every kept voxel and back (`Translate(pos)` ... `Translate(-pos)`, extract_voxel.cc:292-310), so each
+// emitted corner carries the float rounding of all earlier kept voxels -- a dependence through the whole
+// scan that has to be replayed in order to match bit for bit.  The 24 corners of the cube only hold two
+// values per axis (-h and +h), so the replay is six scalar chains, not seventy-two.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "vcy_internal.h"
+
+namespace vcy {
+namespace {
+
+typedef unsigned long long u64;
+
+// fl(a * b) < 0 for floats, whatever the denormal mode of the multiplier: the exact product (it fits a
+// double) is negative and does not round to -0, i.e. is beyond half of the smallest denormal 2^-149.
+__device__ __forceinline__ bool product_negative(float a, float b) {
+  const double p = (double)a * (double)b;
+  return p < 0.0 && fabs(p) > 0x1p-150;
+}
+
+// Keep bit of voxel i = blockIdx.x * 256 + threadIdx.x, one 64-bit word per wave, kept voxels per block.
+//   SURFACE false: !(sdf > 0 || update_num < 1)                         (extract_voxel.cc:283-286)
+//   SURFACE true : UpdateOnSurface (:15-79): the voxel and its -x, -y or -z neighbour are both touched
+//                  and (sdf * neighbour.sdf < 0 or |sdf| < FLT_MIN)
+template <typename CountT, bool SURFACE>
+__global__ __launch_bounds__(256) void xv_keep_kernel(const float* __restrict__ sdf, const CountT* __restrict__ cnt,
+                                                      int nx, int ny, int64_t n, u64* __restrict__ bits,
+                                                      u64* __restrict__ block_counts) {
+  __shared__ int sm[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool keep = false;
+  if (i < n) {
+    const float s = sdf[i];
+    const bool touched = cnt[i] >= 1;
+    if (!SURFACE) {
+      keep = !(s > 0.0f || !touched);
+    } else if (touched) {
+      const int64_t row = i / nx;
+      const int x = (int)(i - row * nx);
+      const int y = (int)(row % ny);
+      const int64_t slice = (int64_t)nx * ny;
+      const bool tiny = (__float_as_uint(s) & 0x7fffffffu) < 0x00800000u;  // |sdf| < FLT_MIN
+      if (x > 0 && cnt[i - 1] >= 1) keep = keep || tiny || product_negative(s, sdf[i - 1]);
+      if (y > 0 && cnt[i - nx] >= 1) keep = keep || tiny || product_negative(s, sdf[i - nx]);
+      if (i >= slice && cnt[i - slice] >= 1) keep = keep || tiny || product_negative(s, sdf[i - slice]);
+    }
+  }
+  const u64 word = __ballot(keep);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    bits[i >> 6] = word;  // (i of lane 0 is a multiple of 64; words beyond n are whole zero words)
+    sm[wave] = __popcll(word);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = (u64)(sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+// ids[rank] = i for every kept voxel, rank = its number in scan order
+__global__ __launch_bounds__(256) void xv_compact_kernel(const u64* __restrict__ bits, const u64* __restrict__ block_offs,
+                                                         int64_t* __restrict__ ids) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const u64* w = bits + (int64_t)blockIdx.x * 4;
+  u64 rank = block_offs[blockIdx.x];
+  for (int k = 0; k < wave; ++k) rank += (u64)__popcll(w[k]);
+  const u64 word = w[wave];
+  if (!((word >> lane) & 1ull)) return;
+  rank += (u64)__popcll(word & ((1ull << lane) - 1ull));
+  ids[rank] = (int64_t)blockIdx.x * 256 + threadIdx.x;
+}
+
+}  // namespace
+
+int device_exclusive_scan_u64(unsigned long long* d, int64_t n, unsigned long long* d_total,
+                              unsigned long long* scratch, hipStream_t stream);  // mc_kernels.hip
+
+}  // namespace vcy
+
+extern "C" int vcy_extract_voxel(vcy_ctx* c, int inside_empty, vcy_mesh* out) {
+  using namespace vcy;
+  if (!c || !out) {
+    set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  std::memset(out, 0, sizeof(*out));
+  if (c->z0 != 0 || c->z1 != c->nz) {
+    set_error("vcy_extract_voxel needs the whole grid in one context");
+    return VCY_ERR_UNSUPPORTED;
+  }
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  {
+    const int rcf = flush_pending(c);  // queued views are part of the state
+    if (rcf != VCY_OK) return rcf;
+  }
+  const int nx = c->nx, ny = c->ny, nz = c->nz;
+  const int64_t n = (int64_t)nx * ny * nz;
+  hipStream_t s = c->stream;
+
+  // ---- device: keep bits -> block counts -> scan -> kept voxel ids ---------------------------------
+  std::vector<int64_t> ids;
+  if (!c->fresh) {  // a fresh grid is untouched everywhere: nothing is kept under either predicate
+    const int64_t nblocks = (n + 255) / 256;
+    auto align = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t sz_bits = align(sizeof(u64) * (size_t)nblocks * 4);
+    const size_t sz_counts = align(sizeof(u64) * ((size_t)nblocks + 1));
+    const size_t sz_scan = align(sizeof(u64) * ((size_t)nblocks / 1024 + 64) * 2);
+    char* d_scratch = nullptr;
+    VCY_HIP_CHECK(hipMalloc((void**)&d_scratch, sz_bits + sz_counts + sz_scan + 256));
+    u64* d_bits = (u64*)d_scratch;
+    u64* d_counts = (u64*)(d_scratch + sz_bits);
+    u64* d_scan = (u64*)(d_scratch + sz_bits + sz_counts);
+    u64* d_total = (u64*)(d_scratch + sz_bits + sz_counts + sz_scan);
+    int64_t* d_ids = nullptr;
+    int rc = VCY_OK;
+#define XV_TRY(expr)                                                                                  \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess && rc == VCY_OK) {                                                           \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);           \
+      rc = VCY_ERR_HIP;                                                                               \
+    }                                                                                                 \
+  } while (0)
+    const float* sdf = c->owned_slab_sdf();
+    const void* cnt = c->owned_slab_cnt();
+#define XV_KEEP(CT, SURF)                                                                                       \
+  hipLaunchKernelGGL((xv_keep_kernel<CT, SURF>), dim3((unsigned)nblocks), dim3(256), 0, s, sdf, (const CT*)cnt, \
+                     nx, ny, n, d_bits, d_counts)
+#define XV_KEEP_S(CT)                                      \
+  do {                                                     \
+    if (inside_empty) XV_KEEP(CT, true); else XV_KEEP(CT, false); \
+  } while (0)
+    if (c->cnt_bytes == 1) XV_KEEP_S(uint8_t);
+    else if (c->cnt_bytes == 2) XV_KEEP_S(uint16_t);
+    else XV_KEEP_S(uint32_t);
+#undef XV_KEEP_S
+#undef XV_KEEP
+    XV_TRY(hipGetLastError());
+    if (rc == VCY_OK) rc = device_exclusive_scan_u64(d_counts, nblocks, d_total, d_scan, s);
+    u64 kept = 0;
+    if (rc == VCY_OK) XV_TRY(hipMemcpyAsync(&kept, d_total, sizeof(u64), hipMemcpyDeviceToHost, s));
+    if (rc == VCY_OK) XV_TRY(hipStreamSynchronize(s));
+    if (rc == VCY_OK && kept * 24 > (u64)std::numeric_limits<int32_t>::max()) {
+      set_error("voxel mesh too large for 32-bit indices");
+      rc = VCY_ERR_TOO_MANY_VOXELS;
+    }
+    if (rc == VCY_OK && kept > 0) {
+      XV_TRY(hipMalloc((void**)&d_ids, sizeof(int64_t) * (size_t)kept));
+      if (rc == VCY_OK) {
+        hipLaunchKernelGGL(xv_compact_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, d_bits, d_counts, d_ids);
+        XV_TRY(hipGetLastError());
+        ids.resize((size_t)kept);
+        XV_TRY(hipMemcpyAsync(ids.data(), d_ids, sizeof(int64_t) * (size_t)kept, hipMemcpyDeviceToHost, s));
+        XV_TRY(hipStreamSynchronize(s));
+      }
+    }
+#undef XV_TRY
+    if (d_ids) (void)hipFree(d_ids);
+    (void)hipFree(d_scratch);
+    if (rc != VCY_OK) return rc;
+  }
+  const size_t kept = ids.size();
+
+  // ---- host: the drifting cube -----------------------------------------------------------------
+  std::vector<float> py((size_t)ny);
+  VCY_HIP_CHECK(hipMemcpy(py.data(), c->d_py, sizeof(float) * (size_t)ny, hipMemcpyDeviceToHost));
+  const float* px = c->h_px;
+  const float* pz = c->h_pz;
+
+  // unit cube of MakeCube(resolution): 6 quads x 4 corners, 12 triangles
+  const float h = c->opt.resolution / 2;
+  static const int8_t sgn[24][3] = {
+      {-1, 1, -1}, {1, 1, -1},  {1, 1, 1},   {-1, 1, 1},  {-1, -1, -1}, {1, -1, -1},  {1, -1, 1},  {-1, -1, 1},
+      {1, 1, -1},  {1, 1, 1},   {1, -1, 1},  {1, -1, -1}, {-1, 1, -1},  {-1, 1, 1},   {-1, -1, 1}, {-1, -1, -1},
+      {-1, 1, -1}, {1, 1, -1},  {1, -1, -1}, {-1, -1, -1}, {-1, 1, 1},  {1, 1, 1},    {1, -1, 1},  {-1, -1, 1}};
+  static const int8_t tri[12][3] = {{0, 2, 1},    {0, 3, 2},    {4, 5, 6},    {4, 6, 7},    {8, 9, 10},   {8, 10, 11},
+                                    {12, 14, 13}, {12, 15, 14}, {16, 17, 18}, {16, 18, 19}, {20, 22, 21}, {20, 23, 22}};
+
+  out->n_vertices = (int64_t)kept * 24;
+  out->n_faces = (int64_t)kept * 12;
+  if (kept == 0) return VCY_OK;  // an empty mesh has no arrays
+  out->vertices = (float*)mesh_host_alloc(sizeof(float) * 3 * kept * 24);
+  out->faces = (int32_t*)mesh_host_alloc(sizeof(int32_t) * 3 * kept * 12);
+  if (!out->vertices || !out->faces) {
+    mesh_host_free(out->vertices);
+    mesh_host_free(out->faces);
+    std::memset(out, 0, sizeof(*out));
+    set_error("out of host memory for the voxel mesh");
+    return VCY_ERR_INTERNAL;
+  }
+  // corner value per axis and sign: every corner with the same (axis, sign) went through the same
+  // additions, so the reference's 72 running coordinates are these six
+  float lo[3] = {-h, -h, -h}, hi[3] = {h, h, h};  // (built with -ffp-contract=off like everything here)
+  float* v = out->vertices;
+  int32_t* f = out->faces;
+  int32_t base = 0;
+  const int64_t slice = (int64_t)nx * ny;
+  for (size_t t = 0; t < kept; ++t) {
+    const int64_t i = ids[t];
+    const int z = (int)(i / slice);
+    const int64_t r = i - (int64_t)z * slice;
+    const int y = (int)(r / nx), x = (int)(r - (int64_t)y * nx);
+    const float p[3] = {px[x], py[y], pz[z]};
+    float clo[3], chi[3];
+    for (int k = 0; k < 3; ++k) {  // Translate(pos)
+      clo[k] = lo[k] + p[k];
+      chi[k] = hi[k] + p[k];
+    }
+    for (int q = 0; q < 24; ++q)
+      for (int k = 0; k < 3; ++k) *v++ = sgn[q][k] < 0 ? clo[k] : chi[k];
+    for (int q = 0; q < 12; ++q)
+      for (int k = 0; k < 3; ++k) *f++ = tri[q][k] + base;
+    for (int k = 0; k < 3; ++k) {  // Translate(-pos)
+      lo[k] = clo[k] + -p[k];
+      hi[k] = chi[k] + -p[k];
+    }
+    base += 24;
+  }
+  return VCY_OK;
+}

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void mc_bits_kernel(const float* __restrict__ 
   if (lane < kBitsWordsPerWave && first + lane < nwords) {
     in[first + lane] = m_in;
     ok[first + lane] = m_ok;
-    tc[first + lane] = m_tc;
+    if (tc != nullptr) tc[first + lane] = m_tc;  // null: the TC plane is the OK plane itself (extract_iso)
   }
 }
 
@@ -269,28 +269,48 @@ __device__ __forceinline__ u64 shl1(const u64* row, int w) {
   return (row[w] << 1) | (w > 0 ? row[w - 1] >> 63 : 0ull);
 }
 
-__device__ __forceinline__ void load_cell_word(const McParams& p, int li, int cy, int w, CellWord* o) {
+// rows of the four voxel lines a cell row touches: (y-1,z-1), (y,z-1), (y-1,z), (y,z)
+struct CellRows {
+  int64_t r00, r10, r01, r11;
+};
+__device__ __forceinline__ CellRows cell_rows(const McParams& p, int li, int cy) {
   const int z = p.zc0 + li - 1;   // global z of the max corner
   const int y = cy + 1;
   const int64_t rw = (int64_t)p.Wr;
-  const int64_t r11 = ((int64_t)(z - p.zs0) * p.ny + y) * rw;        // (y,   z)
-  const int64_t r01 = r11 - rw;                                      // (y-1, z)
-  const int64_t r10 = r11 - (int64_t)p.ny * rw;                      // (y,   z-1)
-  const int64_t r00 = r10 - rw;                                      // (y-1, z-1)
-  o->c[0] = shl1(p.in + r00, w);
-  o->c[1] = p.in[r00 + w];
-  o->c[2] = p.in[r10 + w];
-  o->c[3] = shl1(p.in + r10, w);
-  o->c[4] = shl1(p.in + r01, w);
-  o->c[5] = p.in[r01 + w];
-  o->c[6] = p.in[r11 + w];
-  o->c[7] = shl1(p.in + r11, w);
-  u64 v = p.tc[r11 + w];                                             // marching_cubes.cc:88-90
-  v &= p.ok[r00 + w] & p.ok[r10 + w] & p.ok[r01 + w] & p.ok[r11 + w];   // :103-112
-  v &= shl1(p.ok + r00, w) & shl1(p.ok + r10, w) & shl1(p.ok + r01, w) & shl1(p.ok + r11, w);
+  CellRows r;
+  r.r11 = ((int64_t)(z - p.zs0) * p.ny + y) * rw;   // (y,   z)
+  r.r01 = r.r11 - rw;                               // (y-1, z)
+  r.r10 = r.r11 - (int64_t)p.ny * rw;               // (y,   z-1)
+  r.r00 = r.r10 - rw;                               // (y-1, z-1)
+  return r;
+}
+
+// the 8 corner planes (IN) of the 64 cells of word w
+__device__ __forceinline__ void load_cell_in(const McParams& p, const CellRows& r, int w, CellWord* o) {
+  o->c[0] = shl1(p.in + r.r00, w);
+  o->c[1] = p.in[r.r00 + w];
+  o->c[2] = p.in[r.r10 + w];
+  o->c[3] = shl1(p.in + r.r10, w);
+  o->c[4] = shl1(p.in + r.r01, w);
+  o->c[5] = p.in[r.r01 + w];
+  o->c[6] = p.in[r.r11 + w];
+  o->c[7] = shl1(p.in + r.r11, w);
+}
+
+// which of the 64 cells are evaluated at all: corner 6 touched (marching_cubes.cc:88-90), no corner invalid (:103-112)
+__device__ __forceinline__ u64 load_cell_valid(const McParams& p, const CellRows& r, int w) {
+  u64 v = p.tc[r.r11 + w];
+  v &= p.ok[r.r00 + w] & p.ok[r.r10 + w] & p.ok[r.r01 + w] & p.ok[r.r11 + w];
+  v &= shl1(p.ok + r.r00, w) & shl1(p.ok + r.r10, w) & shl1(p.ok + r.r01, w) & shl1(p.ok + r.r11, w);
   // x = 0 is not a cell; bits beyond nx are zero in every plane already
   if (w == 0) v &= ~1ull;
-  o->valid = v;
+  return v;
+}
+
+__device__ __forceinline__ void load_cell_word(const McParams& p, int li, int cy, int w, CellWord* o) {
+  const CellRows r = cell_rows(p, li, cy);
+  load_cell_in(p, r, w, o);
+  o->valid = load_cell_valid(p, r, w);
 }
 
 __device__ __forceinline__ u64 active_mask(const CellWord& cw) {
@@ -387,9 +407,14 @@ __global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restr
   if (cw < p.nwords) {
     int li, cy, w;
     if (decode_word(p, cw, &li, &cy, &w) && (li > 0 || p.has_ghost)) {
+      // a cell is active when its corners are neither all inside nor all outside (kEdgeTable != 0) and it
+      // is valid; the validity planes are only read for the few words that have a candidate
       CellWord c;
-      load_cell_word(p, li, cy, w, &c);
+      const CellRows r = cell_rows(p, li, cy);
+      load_cell_in(p, r, w, &c);
+      c.valid = ~0ull;
       a = active_mask(c);
+      if (a) a &= load_cell_valid(p, r, w);
     }
     act[cw] = a;
   }
@@ -400,12 +425,13 @@ __global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restr
 }
 
 // ---- pass 2: compact the active cells into a list (raster order is preserved) ------------------
-// cell_list[i] = padded cell slot (word * 64 + bit); cell_index[slot] = i for the owner lookups.
+// cell_list[i] = padded cell slot (word * 64 + bit).  The inverse map needs no array: the list index of
+// the active cell (word cw, bit b) is block_cell_offs[cw >> 8] + word_cell_off[cw] + popcount of the
+// active bits below b (list_index_of), three loads from arrays a few hundred times smaller than the grid.
 __global__ __launch_bounds__(256) void mc_compact_kernel(McParams p, const u64* __restrict__ act,
                                                          const uint32_t* __restrict__ word_cell_off,
                                                          const u64* __restrict__ block_cell_offs,
-                                                         u64* __restrict__ cell_list,
-                                                         uint32_t* __restrict__ cell_index) {
+                                                         u64* __restrict__ cell_list) {
   const int64_t cw = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (cw >= p.nwords) return;
   u64 a = act[cw];
@@ -415,9 +441,13 @@ __global__ __launch_bounds__(256) void mc_compact_kernel(McParams p, const u64* 
     const int b = __ffsll((long long)a) - 1;
     a &= a - 1;
     cell_list[i] = (u64)cell_slot(cw, b);
-    cell_index[cell_slot(cw, b)] = (uint32_t)i;
     ++i;
   }
+}
+
+__device__ __forceinline__ int64_t list_index_of(const u64* __restrict__ act, const uint32_t* __restrict__ word_cell_off,
+                                                 const u64* __restrict__ block_cell_offs, int64_t cw, int b) {
+  return (int64_t)block_cell_offs[cw >> 8] + word_cell_off[cw] + __popcll(act[cw] & ((1ull << b) - 1ull));
 }
 
 // cube index of one cell from the IN plane (marching_cubes.cc:121-128)
@@ -535,15 +565,26 @@ __device__ __forceinline__ void vertex_interp(double iso, const float pa[3], con
   for (int k = 0; k < 3; ++k) out[k] = (float)((double)pa[k] + mu * ((double)pb[k] - (double)pa[k]));
 }
 
+// Output staging of one block of 256 active cells.  A block's vertices and triangles are contiguous
+// ranges of the output arrays (cells are numbered in list order), so they are assembled in LDS and
+// written out as whole rows of dwords instead of scattered 12- and 16-byte pieces (the scattered form
+// wrote 4x the bytes it produced).  Blocks whose totals exceed the staging (dense noise) store directly.
+constexpr int kEmitMaxVerts = 512;  // 6 KB + 8 KB of keys (a smooth surface has about one vertex per active cell)
+constexpr int kEmitMaxTris = 768;   // 9 KB (about two triangles per active cell)
+
 __global__ __launch_bounds__(256) void mc_emit_kernel(McParams p, const McTables* __restrict__ T,
                                                       const u64* __restrict__ act,
                                                       const u64* __restrict__ cell_list, int64_t ncells,
-                                                      const uint32_t* __restrict__ cell_index,
+                                                      const uint32_t* __restrict__ word_cell_off,
+                                                      const u64* __restrict__ block_cell_offs,
                                                       const uint32_t* __restrict__ info,
-                                                      const u64* __restrict__ block_offs,
+                                                      const u64* __restrict__ block_offs, u64 grand_total,
                                                       float* __restrict__ verts, long long* __restrict__ keys,
                                                       int* __restrict__ faces) {
   __shared__ int sm[4];
+  __shared__ float sv[3 * kEmitMaxVerts];
+  __shared__ long long sk[2 * kEmitMaxVerts];
+  __shared__ int sf[3 * kEmitMaxTris];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   int li = 0, cy = 0, x = 0, owned = 0, code = 0, ntri = 0;
   uint32_t inf = 0;
@@ -559,68 +600,105 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(McParams p, const McTables
   }
   int tot_t;
   const int tri_off = block_exclusive_scan(ntri, &tot_t, sm);
-  if (i >= ncells) return;
-  const int y = cy + 1, z = p.zc0 + li - 1;
-  const int64_t slice = (int64_t)p.nx * p.ny;
-  const u64 boff = block_offs[i >> 8];
-  const int64_t vbase = (int64_t)(boff >> 32) + (inf >> 20);
+  // this block's ranges of the output arrays (uniform)
+  const u64 boff = block_offs[blockIdx.x];
+  const u64 bnext = (blockIdx.x + 1 < gridDim.x) ? block_offs[blockIdx.x + 1] : grand_total;
+  const int64_t vb = (int64_t)(boff >> 32), fb = (int64_t)(boff & 0xFFFFFFFFull);
+  const int tot_v = (int)((int64_t)(bnext >> 32) - vb);
+  const bool staged = tot_v <= kEmitMaxVerts && tot_t <= kEmitMaxTris;
+  if (i < ncells) {
+    const int y = cy + 1, z = p.zc0 + li - 1;
+    const int64_t slice = (int64_t)p.nx * p.ny;
+    const int vin = (int)(inf >> 20);  // first vertex of this cell inside the block
 
-  // vertices of the edges this cell owns
-  for (int e = 0; e < 12; ++e) {
-    if (!(owned & (1 << e))) continue;
-    const int ca = kEdgeA[e], cb = kEdgeB[e];
-    const int ax = x + kCornerOff[ca][0], ay = y + kCornerOff[ca][1], az = z + kCornerOff[ca][2];
-    const int bx = x + kCornerOff[cb][0], by = y + kCornerOff[cb][1], bz = z + kCornerOff[cb][2];
-    const float pa[3] = {p.px[ax], p.py[ay], p.pz[az]};
-    const float pb[3] = {p.px[bx], p.py[by], p.pz[bz]};
-    const float va = p.sdf[(int64_t)(az - p.zs0) * slice + (int64_t)ay * p.nx + ax];
-    const float vb = p.sdf[(int64_t)(bz - p.zs0) * slice + (int64_t)by * p.nx + bx];
-    float out[3];
-    vertex_interp(p.iso, pa, pb, va, vb, p.linear != 0, out);
-    const int64_t vid = vbase + __popc(owned & T->prec[code][e]);
-    verts[3 * vid + 0] = out[0];
-    verts[3 * vid + 1] = out[1];
-    verts[3 * vid + 2] = out[2];
-    const int ka = kKeyA[e], kb = kKeyB[e];
-    keys[2 * vid + 0] = (int64_t)(z + kCornerOff[ka][2]) * slice + (int64_t)(y + kCornerOff[ka][1]) * p.nx +
-                        (x + kCornerOff[ka][0]);
-    keys[2 * vid + 1] = (int64_t)(z + kCornerOff[kb][2]) * slice + (int64_t)(y + kCornerOff[kb][1]) * p.nx +
-                        (x + kCornerOff[kb][0]);
-  }
-
-  // triangles, marching_cubes.cc:199-218 (ghost cells have ntri == 0)
-  const int64_t fbase = (int64_t)(boff & 0xFFFFFFFFull) + tri_off;
-  for (int t = 0; t < ntri; ++t) {
-    for (int j = 0; j < 3; ++j) {
-      const int e = T->tri[code][3 * t + (2 - j)];
-      int64_t vid = -1;
-      if (owned & (1 << e)) {
-        vid = vbase + __popc(owned & T->prec[code][e]);
+    // vertices of the edges this cell owns
+    for (int e = 0; e < 12; ++e) {
+      if (!(owned & (1 << e))) continue;
+      const int ca = kEdgeA[e], cb = kEdgeB[e];
+      const int ax = x + kCornerOff[ca][0], ay = y + kCornerOff[ca][1], az = z + kCornerOff[ca][2];
+      const int bx = x + kCornerOff[cb][0], by = y + kCornerOff[cb][1], bz = z + kCornerOff[cb][2];
+      const float pa[3] = {p.px[ax], p.py[ay], p.pz[az]};
+      const float pb[3] = {p.px[bx], p.py[by], p.pz[bz]};
+      const float va = p.sdf[(int64_t)(az - p.zs0) * slice + (int64_t)ay * p.nx + ax];
+      const float vb_ = p.sdf[(int64_t)(bz - p.zs0) * slice + (int64_t)by * p.nx + bx];
+      float out[3];
+      vertex_interp(p.iso, pa, pb, va, vb_, p.linear != 0, out);
+      const int r = vin + __popc(owned & T->prec[code][e]);
+      const int ka = kKeyA[e], kb = kKeyB[e];
+      const long long k0 = (int64_t)(z + kCornerOff[ka][2]) * slice + (int64_t)(y + kCornerOff[ka][1]) * p.nx +
+                           (x + kCornerOff[ka][0]);
+      const long long k1 = (int64_t)(z + kCornerOff[kb][2]) * slice + (int64_t)(y + kCornerOff[kb][1]) * p.nx +
+                           (x + kCornerOff[kb][0]);
+      if (staged) {
+        sv[3 * r + 0] = out[0];
+        sv[3 * r + 1] = out[1];
+        sv[3 * r + 2] = out[2];
+        sk[2 * r + 0] = k0;
+        sk[2 * r + 1] = k1;
       } else {
-        for (int k = 0; k < kShare[e].n; ++k) {
-          const int dx = kShare[e].d[k][0], dy = kShare[e].d[k][1], dl = kShare[e].d[k][2];
-          if (neighbour_active(p, act, li, cy, x, dx, dy, dl)) {
-            const int ox = x + dx;
-            const int64_t oslot = cell_slot(word_index(p, li + dl, cy + dy, ox >> 6), ox & 63);
-            vid = vertex_id_of(T, info, block_offs, (int64_t)cell_index[oslot], kShare[e].e[k]);
-            break;
+        const int64_t vid = vb + r;
+        verts[3 * vid + 0] = out[0];
+        verts[3 * vid + 1] = out[1];
+        verts[3 * vid + 2] = out[2];
+        keys[2 * vid + 0] = k0;
+        keys[2 * vid + 1] = k1;
+      }
+    }
+
+    // triangles, marching_cubes.cc:199-218 (ghost cells have ntri == 0)
+    for (int t = 0; t < ntri; ++t) {
+      for (int j = 0; j < 3; ++j) {
+        const int e = T->tri[code][3 * t + (2 - j)];
+        int64_t vid = -1;
+        if (owned & (1 << e)) {
+          vid = vb + vin + __popc(owned & T->prec[code][e]);
+        } else {
+          for (int k = 0; k < kShare[e].n; ++k) {
+            const int dx = kShare[e].d[k][0], dy = kShare[e].d[k][1], dl = kShare[e].d[k][2];
+            const int nl = li + dl, ncy = cy + dy, ox = x + dx;
+            if (nl < 0 || ncy < 0 || ncy >= p.Y || ox < 1 || ox >= p.nx) continue;
+            const int64_t ocw = word_index(p, nl, ncy, ox >> 6);
+            const u64 aw = act[ocw];
+            if ((aw >> (ox & 63)) & 1ull) {
+              // the owner cell's number in the list, without a slot -> index array
+              const int64_t oi = (int64_t)block_cell_offs[ocw >> 8] + word_cell_off[ocw] +
+                                 __popcll(aw & ((1ull << (ox & 63)) - 1ull));
+              vid = vertex_id_of(T, info, block_offs, oi, kShare[e].e[k]);
+              break;
+            }
           }
         }
+        if (staged) sf[3 * (tri_off + t) + j] = (int)vid;
+        else faces[3 * (fb + tri_off + t) + j] = (int)vid;
       }
-      faces[3 * (fbase + t) + j] = (int)vid;
     }
   }
+  if (!staged) return;  // uniform
+  __syncthreads();
+  // whole rows of dwords: 3 floats per vertex, 2 x 8 bytes per key pair, 3 ints per triangle
+  float* gv = verts + 3 * vb;
+  for (int k = threadIdx.x; k < 3 * tot_v; k += 256) gv[k] = sv[k];
+  long long* gk = keys + 2 * vb;
+  for (int k = threadIdx.x; k < 2 * tot_v; k += 256) gk[k] = sk[k];
+  int* gf = faces + 3 * fb;
+  for (int k = threadIdx.x; k < 3 * tot_t; k += 256) gf[k] = sf[k];
 }
 
 }  // namespace
+
+// the same scan for the other compactions of the library (extract_voxel.hip)
+int device_exclusive_scan_u64(unsigned long long* d, int64_t n, unsigned long long* d_total,
+                              unsigned long long* scratch, hipStream_t stream) {
+  return exclusive_scan_u64(d, n, d_total, scratch, stream);
+}
 
 // ---- host driver ----------------------------------------------------------------------------
 
 int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   out->n_vertices = out->n_faces = out->n_foreign_vertices = 0;
-  out->vertices = (float*)std::malloc(sizeof(float) * 3);
-  out->faces = (int32_t*)std::malloc(sizeof(int32_t) * 3);
-  out->edge_keys = (int64_t*)std::malloc(sizeof(int64_t) * 2);
+  out->vertices = nullptr;  // an empty mesh has no arrays
+  out->faces = nullptr;
+  out->edge_keys = nullptr;
   if (c->halo_lo && !c->halo_valid) {
     set_error("halo slices not installed: call vcy_halo_pack / all-gather / vcy_halo_unpack first");
     return VCY_ERR_NOT_INITIALIZED;
@@ -680,16 +758,15 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   }
   const McTables* T = (const McTables*)c->d_mc_tables;
 
-  // scratch, cached in the context (grown on demand): bit planes, ACT, per-word offsets, block
-  // counts, and the dense slot -> list-index map (4 B per padded cell, touched only at active cells)
+  // scratch, cached in the context (grown on demand): bit planes, ACT, per-word offsets, block counts
+  // (3 bits per voxel + 12.5 B per 64 cells: 0.9 GB at 1024^3)
   auto align = [](size_t v) { return (v + 255) / 256 * 256; };
   const size_t sz_plane = align(sizeof(u64) * (size_t)vox_words);
   const size_t sz_act = align(sizeof(u64) * (size_t)p.nwords);
   const size_t sz_woff = align(sizeof(uint32_t) * (size_t)p.nwords);
   const size_t sz_counts = align(sizeof(u64) * ((size_t)nblocks + 1));
   const size_t sz_scan = align(sizeof(u64) * ((size_t)nblocks / 1024 + 64) * 2);
-  const size_t sz_index = align(sizeof(uint32_t) * (size_t)p.nwords * 64);
-  const size_t need = 3 * sz_plane + sz_act + sz_woff + sz_counts + sz_scan + sz_index + 256;
+  const size_t need = 3 * sz_plane + sz_act + sz_woff + sz_counts + sz_scan + 256;
   if (c->mc_scratch_bytes < need) {
     VCY_HIP_CHECK(hipStreamSynchronize(s));
     if (c->d_mc_scratch) VCY_HIP_CHECK(hipFree(c->d_mc_scratch));
@@ -706,7 +783,6 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   uint32_t* d_woff = (uint32_t*)base;         base += sz_woff;
   u64* d_wcounts = (u64*)base;                base += sz_counts;
   u64* d_scan = (u64*)base;                   base += sz_scan;
-  uint32_t* d_index = (uint32_t*)base;        base += sz_index;
   u64* d_total = (u64*)base;
   p.in = d_in;
   p.ok = d_ok;
@@ -726,7 +802,12 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
     }                                                                              \
   } while (0)
 
-  MC_TRY(hipEventRecord(c->ev_begin, s));
+  // the extraction has its own event pair: vcy_timer_begin / _end may bracket it
+  if (!c->ev_mc_begin) {
+    MC_TRY(hipEventCreate(&c->ev_mc_begin));
+    MC_TRY(hipEventCreate(&c->ev_mc_end));
+  }
+  MC_TRY(hipEventRecord(c->ev_mc_begin, s));
   const bool iso_f32 = (double)(float)iso == iso;
   // the halo slices come from another context: their update_num is read; the owned slices need it
   // only if the state was ever set from outside (vcy_upload), see mc_bits_kernel
@@ -737,7 +818,7 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
     const char* cnt0 = (const char*)c->d_cnt + word0 * 64 * c->cnt_bytes;
 #define VCY_BITS(CT, F32, TCOK)                                                                          \
   hipLaunchKernelGGL((mc_bits_kernel<CT, F32, TCOK>), dim3(blocks), dim3(256), 0, s, sdf0, (const CT*)cnt0, \
-                     c->nx, p.Wr, nw, iso, d_in + word0, d_ok + word0, d_tc + word0)
+                     c->nx, p.Wr, nw, iso, d_in + word0, d_ok + word0, d_tc ? d_tc + word0 : nullptr)
 #define VCY_BITS_F(CT, TCOK)                                                    \
   do {                                                                          \
     if (iso_f32) VCY_BITS(CT, true, TCOK); else VCY_BITS(CT, false, TCOK);      \
@@ -755,6 +836,12 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
 #undef VCY_BITS
   };
   const int64_t halo_words = (int64_t)c->halo_lo * c->ny * p.Wr;
+  // a whole grid whose state implies TC == OK: no third plane at all
+  const bool alias_tc = c->cnt_implied && c->nx == p.Wr * 64 && c->halo_lo == 0;
+  if (alias_tc) {
+    p.tc = d_ok;
+    d_tc = nullptr;
+  }
   if (c->cnt_implied && c->nx == p.Wr * 64) {
     launch_bits(0, halo_words, false);
     launch_bits(halo_words, vox_words - halo_words, true);
@@ -798,8 +885,7 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
     u64* d_scan2 = (u64*)b2;                  b2 += sz_cs;
     u64* d_total2 = (u64*)b2;
 
-    hipLaunchKernelGGL(mc_compact_kernel, dim3(nblocks), dim3(256), 0, s, p, d_act, d_woff, d_wcounts, d_list,
-                       d_index);
+    hipLaunchKernelGGL(mc_compact_kernel, dim3(nblocks), dim3(256), 0, s, p, d_act, d_woff, d_wcounts, d_list);
     hipLaunchKernelGGL(mc_owner_kernel, dim3(cblocks), dim3(256), 0, s, p, T, d_act, d_list, ncells, d_info,
                        d_counts);
     MC_TRY(hipGetLastError());
@@ -834,25 +920,30 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
     d_verts = (float*)c->d_mc_out;
     d_keys = (long long*)((char*)c->d_mc_out + sz_v);
     d_faces = (int*)((char*)c->d_mc_out + sz_v + sz_k);
-    hipLaunchKernelGGL(mc_emit_kernel, dim3(cblocks), dim3(256), 0, s, p, T, d_act, d_list, ncells, d_index, d_info,
-                       d_counts, d_verts, d_keys, d_faces);
+    hipLaunchKernelGGL(mc_emit_kernel, dim3(cblocks), dim3(256), 0, s, p, T, d_act, d_list, ncells, d_woff, d_wcounts,
+                       d_info, d_counts, h_tot, d_verts, d_keys, d_faces);
     MC_TRY(hipGetLastError());
   }
-  MC_TRY(hipEventRecord(c->ev_end, s));
-  MC_TRY(hipEventSynchronize(c->ev_end));
-  MC_TRY(hipEventElapsedTime(&c->last_extract_device_ms, c->ev_begin, c->ev_end));
+  MC_TRY(hipEventRecord(c->ev_mc_end, s));
+  MC_TRY(hipEventSynchronize(c->ev_mc_end));
+  MC_TRY(hipEventElapsedTime(&c->last_extract_device_ms, c->ev_mc_begin, c->ev_mc_end));
 
-  std::free(out->vertices);
-  std::free(out->faces);
-  std::free(out->edge_keys);
-  out->vertices = (float*)std::malloc(sizeof(float) * 3 * (size_t)std::max<int64_t>(nv, 1));
-  out->faces = (int32_t*)std::malloc(sizeof(int32_t) * 3 * (size_t)std::max<int64_t>(nf, 1));
-  out->edge_keys = (int64_t*)std::malloc(sizeof(int64_t) * 2 * (size_t)std::max<int64_t>(nv, 1));
+  // the mesh arrays: page-locked host buffers, three DMAs in flight on the context's stream
   if (nv > 0) {
-    MC_TRY(hipMemcpy(out->vertices, d_verts, sizeof(float) * 3 * (size_t)nv, hipMemcpyDeviceToHost));
-    MC_TRY(hipMemcpy(out->edge_keys, d_keys, sizeof(long long) * 2 * (size_t)nv, hipMemcpyDeviceToHost));
+    out->vertices = (float*)mesh_host_alloc(sizeof(float) * 3 * (size_t)nv);
+    out->edge_keys = (int64_t*)mesh_host_alloc(sizeof(int64_t) * 2 * (size_t)nv);
   }
-  if (nf > 0) MC_TRY(hipMemcpy(out->faces, d_faces, sizeof(int) * 3 * (size_t)nf, hipMemcpyDeviceToHost));
+  if (nf > 0) out->faces = (int32_t*)mesh_host_alloc(sizeof(int32_t) * 3 * (size_t)nf);
+  if ((nv > 0 && (!out->vertices || !out->edge_keys)) || (nf > 0 && !out->faces)) {
+    set_error("out of host memory for the mesh");
+    return VCY_ERR_INTERNAL;
+  }
+  if (nv > 0) {
+    MC_TRY(hipMemcpyAsync(out->vertices, d_verts, sizeof(float) * 3 * (size_t)nv, hipMemcpyDeviceToHost, s));
+    MC_TRY(hipMemcpyAsync(out->edge_keys, d_keys, sizeof(long long) * 2 * (size_t)nv, hipMemcpyDeviceToHost, s));
+  }
+  if (nf > 0) MC_TRY(hipMemcpyAsync(out->faces, d_faces, sizeof(int) * 3 * (size_t)nf, hipMemcpyDeviceToHost, s));
+  MC_TRY(hipStreamSynchronize(s));
   out->n_vertices = nv;
   out->n_faces = nf;
 #undef MC_TRY

@@ -2,7 +2,9 @@
 // The carving and extraction kernels live in carve_kernels.hip / mc_kernels.hip.
 #include <cstdarg>
 #include <cstring>
+#include <chrono>
 #include <limits>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -19,6 +21,65 @@ void set_error(const char* fmt, ...) {
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
   g_last_error = buf;
+}
+
+// ---- host buffers of returned meshes ---------------------------------------------------------
+// The arrays of a vcy_mesh are page-locked host memory from a small process-wide pool: the mesh download
+// (130 MB at 1024^3) is then one DMA at PCIe rate instead of a staged copy into freshly faulted pages, and
+// vcy_mesh_free hands the buffers back for the next extraction.  Pageable memory is the fallback when
+// pinning fails.
+namespace {
+struct HostBuf { void* p; size_t bytes; bool pinned; };
+std::mutex g_mesh_mutex;
+std::vector<HostBuf> g_mesh_live, g_mesh_idle;
+constexpr size_t kMeshIdleCap = (size_t)3 << 30;  // idle bytes kept for reuse
+}  // namespace
+
+void* mesh_host_alloc(size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  std::lock_guard<std::mutex> lock(g_mesh_mutex);
+  size_t best = g_mesh_idle.size();
+  for (size_t i = 0; i < g_mesh_idle.size(); ++i)
+    if (g_mesh_idle[i].bytes >= bytes && g_mesh_idle[i].bytes <= 2 * bytes + 4096 &&
+        (best == g_mesh_idle.size() || g_mesh_idle[i].bytes < g_mesh_idle[best].bytes))
+      best = i;
+  HostBuf b;
+  if (best < g_mesh_idle.size()) {
+    b = g_mesh_idle[best];
+    g_mesh_idle.erase(g_mesh_idle.begin() + (long)best);
+  } else {
+    b.bytes = bytes + bytes / 8 + 4096;  // headroom: the next view's mesh is usually a little different
+    b.p = nullptr;
+    b.pinned = hipHostMalloc(&b.p, b.bytes, hipHostMallocDefault) == hipSuccess && b.p != nullptr;
+    if (!b.pinned) {
+      (void)hipGetLastError();
+      b.p = std::malloc(b.bytes);
+      if (!b.p) return nullptr;
+    }
+  }
+  g_mesh_live.push_back(b);
+  return b.p;
+}
+
+void mesh_host_free(void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lock(g_mesh_mutex);
+  for (size_t i = 0; i < g_mesh_live.size(); ++i) {
+    if (g_mesh_live[i].p != p) continue;
+    const HostBuf b = g_mesh_live[i];
+    g_mesh_live.erase(g_mesh_live.begin() + (long)i);
+    size_t idle = 0;
+    for (const HostBuf& q : g_mesh_idle) idle += q.bytes;
+    if (b.pinned && idle + b.bytes <= kMeshIdleCap) {
+      g_mesh_idle.push_back(b);
+    } else if (b.pinned) {
+      (void)hipHostFree(b.p);
+    } else {
+      std::free(b.p);
+    }
+    return;
+  }
+  std::free(p);  // not ours (never happens for meshes this library returned)
 }
 
 // sdf = lowest(), update_num = 0 over slab + halo (reference voxel_carver.cc:339, Voxel ctor)
@@ -260,6 +321,8 @@ void vcy_destroy(vcy_ctx* c) {
   (void)hipFree(c->d_sil_scratch);
   delete[] c->h_pz;
   delete[] c->h_px;
+  if (c->ev_mc_begin) (void)hipEventDestroy(c->ev_mc_begin);
+  if (c->ev_mc_end) (void)hipEventDestroy(c->ev_mc_end);
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1087,8 +1150,17 @@ int vcy_extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   if (!out) return VCY_ERR_INVALID_ARG;
   std::memset(out, 0, sizeof(*out));
   VCY_HIP_CHECK(hipSetDevice(c->device));
+  const auto t0 = std::chrono::steady_clock::now();
   { int rcm = materialize(c); if (rcm != VCY_OK) return rcm; }
-  return extract_iso(c, iso, linear_interp, out);
+  const int rc = extract_iso(c, iso, linear_interp, out);
+  c->last_extract_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
+}
+
+int vcy_last_extract_wall_ms(const vcy_ctx* c, float* wall_ms) {
+  if (!c || !wall_ms) return VCY_ERR_INVALID_ARG;
+  *wall_ms = c->last_extract_wall_ms;
+  return VCY_OK;
 }
 
 int vcy_last_extract_ms(const vcy_ctx* c, float* device_ms) {
@@ -1099,9 +1171,9 @@ int vcy_last_extract_ms(const vcy_ctx* c, float* device_ms) {
 
 void vcy_mesh_free(vcy_mesh* m) {
   if (!m) return;
-  std::free(m->vertices);
-  std::free(m->faces);
-  std::free(m->edge_keys);
+  mesh_host_free(m->vertices);
+  mesh_host_free(m->faces);
+  mesh_host_free(m->edge_keys);
   std::memset(m, 0, sizeof(*m));
 }
 

@@ -114,6 +114,8 @@ struct vcy_ctx {
   void* d_mc_out = nullptr;           // device staging of the extracted mesh
   size_t mc_out_bytes = 0;
   float last_extract_device_ms = 0.0f;
+  float last_extract_wall_ms = 0.0f;  // call entry -> mesh arrays in host memory
+  hipEvent_t ev_mc_begin = nullptr, ev_mc_end = nullptr;  // the extraction's own timer
 
   // upper bound on any voxel's update_num (each carved view adds at most one)
   int64_t views_carved = 0;
@@ -150,6 +152,9 @@ size_t device_make_sdf_scratch_bytes(int w, int h);
 int device_make_sdf_batch(hipStream_t stream, int n, const uint8_t* const* masks_dev, const vcy_view* views,
                           bool normalize, bool truncate, float band, char* scratch, size_t scratch_stride,
                           float* const* sdf_dev);
+// host arrays of returned meshes (page-locked pool, vcy_api.hip); released by vcy_mesh_free
+void* mesh_host_alloc(size_t bytes);
+void mesh_host_free(void* p);
 // utility kernels (vcy_api.hip)
 int fill_state(vcy_ctx* ctx);   // marks the slab fresh (lazy)
 int materialize(vcy_ctx* ctx);  // writes the fresh state to HBM if it is still pending
