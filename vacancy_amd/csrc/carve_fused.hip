@@ -43,9 +43,31 @@ constexpr int BX = 32, BY = 8, BZ = 8;  // voxels per workgroup: four 8x8x8 wave
 constexpr int WX = 8;                    // wave brick is WX x BY x BZ, lane = (y & 7) | (z << 3), WX voxels per lane
 constexpr int kMaxFusedViews = 64;         // one prologue lane per view
 constexpr int kTileSmall = 128;          // quads per wave tile (2 KB): <= 2 per lane, prefetched in registers
+// Raw-pixel tile (the default for footprints up to 15 x 15 quads): 16 x 16 pixels of the image, pitch 16, 1 KB.
+// The pixels go from global memory straight into LDS (global_load_lds_dword: lane L of the r-th load
+// writes dword 64 r + L, i.e. pixel (L & 15, 4 r + (L >> 4))), two tiles per wave so that the next live
+// view's footprint arrives while the current one is sampled -- no staging registers, no LDS stores, one
+// address per PIXEL instead of four per quad.  A sample reads its four taps as two ds_read2_b32
+// (offsets 0, 1 and 16, 17); columns / rows beyond the ROI repeat the edge pixel, which is the
+// reference's clamp of x + 1 and y + 1 (voxel_carver.cc:51-66).
+constexpr int kTileRaw = 16;
+constexpr int kRawBuffers = 2;
+#ifndef VCY_SMALL_TILE
+#define VCY_SMALL_TILE kTileRaw          // development builds: kTileSmall = the register-staged quad tile
+#endif
+template <int TQ>
+constexpr int tile_f4_per_wave() { return TQ == kTileRaw ? kRawBuffers * 64 : TQ; }  // LDS of one wave, in float4
 constexpr int kTileBig = 512;            // 8 KB per wave: footprints up to ~1.4 px per voxel, filled in place
 
 constexpr int kWmaxPlanes = 2;           // window sizes 4 and 8
+
+// tuning knobs of the select-free view loop (development builds override them, profiles/tools/build_variant.sh)
+#ifndef VCY_FAST_GROUP
+#define VCY_FAST_GROUP 4   // voxels whose LDS reads are in flight together
+#endif
+#ifndef VCY_WAVES
+#define VCY_WAVES 5        // waves per SIMD the kernel is compiled for (register budget 512 / VCY_WAVES)
+#endif
 
 // Development build only (-DVCY_PHASE_TIMING, profiles/tools/phase_timing.py): s_memtime ticks of every wave,
 // accumulated per phase of the fused kernel.  Slots 0-6: prologue + state load, tile staging, select-free
@@ -100,6 +122,7 @@ struct TileInfo {
   float pitchf;
   int base;                      // -(ty0*tw + tx0)
   int tx0, ty0, tw, nq;          // nq = tw*th quads; 0: no tile for this view
+  int th;
   float inv_tw;                  // 1 / tw: q / tw == (int)((q + 0.5f) * inv_tw) for q < 2^12
   float ub;                      // upper bound of any sample taken from this tile (+inf: unknown)
   int sure;                      // 1: every voxel of the brick provably samples inside this tile
@@ -316,6 +339,33 @@ __device__ __forceinline__ void tile_prefetch(const ViewParams& v, const TileInf
   }
 }
 
+typedef float __attribute__((address_space(3))) lds_float;
+
+// Raw tile of view `v` into the wave-private LDS buffer `buf` (256 floats): pixel (i, j) of the tile =
+// image pixel (min(tx0 + i, roi_max.x), min(ty0 + j, roi_max.y)), for the th + 1 <= 16 rows the taps reach.
+// Asynchronous: the data is in LDS once the wave's vmcnt has drained (raw_tile_wait).
+__device__ __forceinline__ void raw_prefetch(const ViewParams& v, const TileInfo& ti, int lane, float* buf) {
+  const int nq = __builtin_amdgcn_readfirstlane(ti.nq);
+  if (nq == 0) return;
+  const int th = __builtin_amdgcn_readfirstlane(ti.th);
+  const int tx0 = __builtin_amdgcn_readfirstlane(ti.tx0);
+  const int ty0 = __builtin_amdgcn_readfirstlane(ti.ty0);
+  gfloat_ptr img = (gfloat_ptr)v.sdf;
+  const unsigned width = (unsigned)v.width;
+  const unsigned xx = (unsigned)min(tx0 + (lane & 15), v.roi_max_xi);
+  const int yl = ty0 + (lane >> 4);
+  lds_float* dst = (lds_float*)buf;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (4 * r <= th) {  // uniform: rows 4 r .. 4 r + 3 hold a tap row (taps reach rows 0 .. th)
+      const unsigned yy = (unsigned)min(yl + 4 * r, v.roi_max_yi);
+      __builtin_amdgcn_global_load_lds(img + (__umul24(width, yy) + xx), dst + 64 * r, 4, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void raw_tile_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // min over the wave (NaN operands are ignored, like the `dist > s` test ignores them): six DPP
 // v_min_f32 (row reduction, then row_bcast 15 / 31) and one readlane.  Written in assembly because
 // the compiler expands a DPP move + canonicalise + min per step; the s_nop covers the VALU-write ->
@@ -511,7 +561,7 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
     ti.hi_x = ti.hi_y = -INFINITY;
     ti.pitchf = 0.0f;
     ti.base = 0;
-    ti.tx0 = ti.ty0 = ti.tw = ti.nq = 0;
+    ti.tx0 = ti.ty0 = ti.tw = ti.nq = ti.th = 0;
     ti.inv_tw = 1.0f;
     ti.ub = INFINITY;  // never dropped
     ti.sure = 0;
@@ -521,7 +571,8 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
       const int tx1 = min((int)floorf(umax + margin), v.roi_max_xi);
       const int ty1 = min((int)floorf(wmax_ + margin), v.roi_max_yi);
       const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
-      if (tw > 0 && th > 0 && tw <= TQ && th <= TQ && tw * th <= TQ) {
+      constexpr bool kRaw = TQ == kTileRaw;
+      if (tw > 0 && th > 0 && (kRaw ? (tw <= 15 && th <= 15) : (tw <= TQ && th <= TQ && tw * th <= TQ))) {
         // Every computed (u, w) of the brick is within corner error + voxel error < margin of the corner
         // hull, so when the ROI clipped nothing it lies in [tx0, tx1 + 1) x [ty0, ty1 + 1); the depth
         // guard keeps every computed pc.z within a factor 2 of the corner range, inside div_fast's.
@@ -529,15 +580,17 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
                                (int)floorf(umax + margin) < v.roi_max_xi && (int)floorf(wmax_ + margin) < v.roi_max_yi;
         const bool depth_ok = 0x1p-20f * mag[2] <= 0.25f * zmin && zmin >= 0x1p-58f && zmax <= 0x1p58f;
         // (|16 base| < 2^22: the fast path forms LDS addresses in the float pipeline, carve_view_fast)
-        const bool small_base = ty0 * tw + tx0 < (1 << 18);
+        const int pitch = kRaw ? 16 : tw;  // elements per tile row (raw: pixels, pitch 16; else quads)
+        const bool small_base = ty0 * pitch + tx0 < (1 << 18);
         ti.sure = (!ortho && unclipped && depth_ok && small_base) ? 1 : 0;
         ti.tx0 = tx0;
         ti.ty0 = ty0;
         ti.tw = tw;
+        ti.th = th;
         ti.nq = tw * th;
         ti.inv_tw = 1.0f / (float)tw;
-        ti.pitchf = (float)tw;
-        ti.base = -(ty0 * tw + tx0);
+        ti.pitchf = (float)pitch;
+        ti.base = -(ty0 * pitch + tx0);
         ti.lo_x = (float)tx0;
         ti.lo_y = (float)ty0;
         // taps exist for floor(u) in [tx0, tx1]; at the ROI edge u == roi_max is still inside
@@ -591,7 +644,7 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
 // GEN: nearest-neighbour sampling and/or an orthographic camera, selected at run time from `mode`
 // (compiled out of the default bilinear + pinhole kernels, where the extra branches cost 16 %).
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX, int TQ, bool GEN, int DIV>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void carve_fused_kernel(GridParams g,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCY_WAVES))) void carve_fused_kernel(GridParams g,
                                                           const FusedView* __restrict__ views,
                                                           const float* __restrict__ c0_all,
                                                           int nviews, ModeParams mode, int nbx,
@@ -602,7 +655,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
   const bool implied = (state_flags & 2) != 0;
   // dynamic LDS: [4 waves][TQ] quads, then [4 waves][nviews] TileInfo (sized by the launch)
   extern __shared__ float4 fused_lds[];
-  constexpr bool kPrefetch = TQ <= 128;  // two quads per lane fit in registers
+  constexpr bool kRaw = TQ == kTileRaw;                  // raw-pixel tiles, loaded straight into LDS
+  constexpr bool kPrefetch = !kRaw && TQ <= 128;         // quad tile staged through registers (two quads per lane)
+  constexpr int kTileF4 = tile_f4_per_wave<TQ>();
   // A view can be dropped for a whole wave brick when no voxel of the brick can change:
   //   - use_truncation and every sample is provably < -1 (voxel_carver.cc:478), or
   //   - kMax, every voxel already touched, and every sample is provably <= min(sdf) of the
@@ -615,10 +670,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
   constexpr bool kNeedBound = TRUNC || UPDATE == VCY_UPDATE_MAX;
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  // (the wave index is uniform, which the compiler cannot see: keeps the LDS bases of the wave in SGPRs)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   VCY_PT_DECL;
-  float4* tile = fused_lds + wave * TQ;
-  TileInfo* tinfo = (TileInfo*)(fused_lds + 4 * TQ) + wave * nviews;
+  float4* tile = fused_lds + wave * kTileF4;
+  TileInfo* tinfo = (TileInfo*)(fused_lds + 4 * kTileF4) + wave * nviews;
+  int cur = 0;  // raw tiles: which of the wave's buffers holds the view being carved
+  auto raw_buf = [&](int b) -> float* { return (float*)tile + 256 * b; };
   const int ly = lane & (BY - 1), lz = lane >> 3;
   // XCD-aware order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, so
   // workgroup b runs on XCD b % 8.  Give every XCD one contiguous eighth of the brick list: bricks
@@ -728,6 +786,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
   QuadRegs pre;
   pre.q0 = pre.q1 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (kPrefetch && vi < nviews) tile_prefetch(views[vi].v, tinfo[vi], lane, &pre);
+  if (kRaw && vi < nviews) raw_prefetch(views[vi].v, tinfo[vi], lane, raw_buf(0));
   VCY_PT(0);
   VCY_PT_COUNT(10);
 
@@ -738,7 +797,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
     cfloat_ptr c0 = (cfloat_ptr)(c0_all + ((size_t)vi * (nxp / WX) + (x_first / WX)) * kC0Stride);
     // stage this view's tile (wave-private: program order is enough)
     wave_lds_fence();
-    if (kPrefetch) {
+    if (kRaw) {
+      raw_tile_wait();  // this view's pixels have landed in raw_buf(cur)
+    } else if (kPrefetch) {
       tile[lane] = pre.q0;
       tile[lane + 64] = pre.q1;
     } else {
@@ -748,6 +809,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
     // the next live view's tile is fetched while this one is computed
     int vnext = next_view(live, vi);
     if (kPrefetch && vnext < nviews) tile_prefetch(views[vnext].v, tinfo[vnext], lane, &pre);
+    if (kRaw && vnext < nviews) raw_prefetch(views[vnext].v, tinfo[vnext], lane, raw_buf(cur ^ 1));
+    // the four taps of tile element idx (a quad, or the 2 x 2 pixels at idx of a raw tile)
+    const lds_float* rawcur = (const lds_float*)raw_buf(cur);
+    auto quad_at = [&](unsigned idx) -> float4 {
+      if constexpr (kRaw) {
+        const lds_float* p = rawcur + idx;
+        return make_float4(p[0], p[1], p[16], p[17]);
+      } else {
+        return tile[idx];
+      }
+    };
 
     const float lo_x = tinfo[vi].lo_x, hi_x = tinfo[vi].hi_x;
     const float lo_y = tinfo[vi].lo_y, hi_y = tinfo[vi].hi_y;
@@ -794,8 +866,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
         const float mu = 1.0f - lu, mv = 1.0f - lv;
         // any index is harmless when !in_tile (the sample is discarded); keep it inside the tile
         unsigned idx = (unsigned)((int)__builtin_fmaf(fw, pitchf, fu) + base);
-        if (!SURE) idx = min(idx, (unsigned)(TQ - 1));
-        const float4 q = tile[idx];
+        if (!SURE) idx = min(idx, (unsigned)(kRaw ? 256 - 18 : TQ - 1));
+        const float4 q = quad_at(idx);
         // ((1-lu)(1-lv)) s00 + (lu (1-lv)) s10 + ((1-lu) lv) s01 + (lu lv) s11, summed left to right (:69-73)
         float dist = ((((mu * mv) * q.x) + ((lu * mv) * q.y)) + ((mu * lv) * q.z)) + ((lu * lv) * q.w);
         if (is_nn) {
@@ -837,10 +909,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
     auto carve_view_fast = [&]() -> bool {
       // uniform -> VGPR (opaque to the compiler, which would otherwise fold them back into SGPR operands)
       float pitch16, cmagic;
+      constexpr int kElemB = kRaw ? 4 : 16;     // bytes per tile element (pixel or quad)
       {
-        const float p16 = pitchf * 16.0f;  // tw <= 512: exact
-        const unsigned lds_off = (unsigned)(size_t)(lds_float4*)tile;
-        const float cm = 8388608.0f + (float)(16 * base + (int)lds_off);  // |16 base| < 2^22 (TileInfo::sure)
+        const float p16 = pitchf * (float)kElemB;  // bytes per tile row; pitch <= 512: exact
+        const unsigned lds_off = kRaw ? (unsigned)(size_t)rawcur : (unsigned)(size_t)(lds_float4*)tile;
+        const float cm = 8388608.0f + (float)(kElemB * base + (int)lds_off);  // |16 base| < 2^22 (TileInfo::sure)
         asm volatile("v_mov_b32_e32 %0, %1" : "=v"(pitch16) : "s"(p16));
         asm volatile("v_mov_b32_e32 %0, %1" : "=v"(cmagic) : "s"(cm));
       }
@@ -848,11 +921,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
       // together); phase B: weights, sample, update.
       unsigned long long took = 0;
 #pragma unroll
-      for (int k0 = 0; k0 < WX; k0 += 4) {
-        float lu[4], lv[4];
-        f4 q[4];
+      for (int k0 = 0; k0 < WX; k0 += VCY_FAST_GROUP) {
+        float lu[VCY_FAST_GROUP], lv[VCY_FAST_GROUP];
+        f4 q[VCY_FAST_GROUP];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < VCY_FAST_GROUP; ++j) {
           const int k = k0 + j;
           const float pcz = v.t[2] + (c0[16 + k] + h12z);
           const float qx = div_view<DIV>(v.fx, pcz);
@@ -862,11 +935,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
           const float fu = floorf(u), fw = floorf(w);
           lu[j] = u - fu;
           lv[j] = w - fw;
-          const float a = __builtin_fmaf(fw, pitch16, __builtin_fmaf(fu, 16.0f, cmagic));
-          q[j] = *(const lds_float4*)(size_t)(__float_as_uint(a) & 0x7fffffu);
+          const float a = __builtin_fmaf(fw, pitch16, __builtin_fmaf(fu, (float)kElemB, cmagic));
+          if constexpr (kRaw) {
+            const lds_float* tp = (const lds_float*)(size_t)(__float_as_uint(a) & 0x7fffffu);
+            q[j] = f4{tp[0], tp[1], tp[16], tp[17]};
+          } else {
+            q[j] = *(const lds_float4*)(size_t)(__float_as_uint(a) & 0x7fffffu);
+          }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < VCY_FAST_GROUP; ++j) {
           const int k = k0 + j;
           const float mu = 1.0f - lu[j], mv = 1.0f - lv[j];
           const float dist =
@@ -903,9 +981,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
       if (v2 != vnext) {
         vnext = v2;
         if (kPrefetch && vnext < nviews) tile_prefetch(views[vnext].v, tinfo[vnext], lane, &pre);
+        // (the dropped view's pixels may still be arriving in that buffer: loads complete in order)
+        if (kRaw && vnext < nviews) raw_prefetch(views[vnext].v, tinfo[vnext], lane, raw_buf(cur ^ 1));
       }
     }
     vi = vnext;
+    cur ^= 1;
     VCY_PT(5);
   }
 
@@ -949,7 +1030,7 @@ void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const Gri
   const bool gen = m.ortho != 0 || m.interp == VCY_INTERP_NN;
 #define VCY_FUSED(CM, TQ_, GEN_, DIV_)                                                                           \
   hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, CM, TQ_, GEN_, DIV_>), grid, dim3(256),     \
-                     (size_t)4 * TQ_ * sizeof(float4) + (size_t)4 * nv * sizeof(TileInfo), s,                    \
+                     (size_t)4 * tile_f4_per_wave<TQ_>() * sizeof(float4) + (size_t)4 * nv * sizeof(TileInfo), s, \
                      g, dv, c2, nv, m, nbx, nby, cull, fresh)
 #define VCY_FUSED_G(CM, TQ_)                                                                                     \
   do {                                                                                                           \
@@ -966,12 +1047,12 @@ void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const Gri
     fprintf(stderr, "VCY_DEV_BENCH_KERNELS_ONLY: kernel variant not built\n");
     abort();
   }
-  if constexpr (SAMEF && sizeof(CountT) == 2 && UPDATE != VCY_UPDATE_WEIGHTED_AVERAGE) VCY_FUSED(false, kTileSmall, false, 2);
+  if constexpr (SAMEF && sizeof(CountT) == 2 && UPDATE != VCY_UPDATE_WEIGHTED_AVERAGE) VCY_FUSED(false, VCY_SMALL_TILE, false, 2);
 #else
   if (big) {
     if (checkmax) VCY_FUSED_G(true, kTileBig); else VCY_FUSED_G(false, kTileBig);
   } else {
-    if (checkmax) VCY_FUSED_G(true, kTileSmall); else VCY_FUSED_G(false, kTileSmall);
+    if (checkmax) VCY_FUSED_G(true, VCY_SMALL_TILE); else VCY_FUSED_G(false, VCY_SMALL_TILE);
   }
 #endif
 #undef VCY_FUSED_G
@@ -1225,7 +1306,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
       worst = std::max(worst, c->fused_ortho ? res : (pz > 0.0f ? f * res / pz : INFINITY));
     }
     const float side = 8.0f * 1.7320508f * worst + 3.0f;
-    big = side * side > (float)kTileSmall;
+    big = VCY_SMALL_TILE == kTileRaw ? side > 15.0f : side * side > (float)kTileSmall;
     if (c->tile_mode == 1) big = false;
     if (c->tile_mode == 2) big = true;
   }
