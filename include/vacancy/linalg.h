@@ -86,6 +86,16 @@ struct Mat3 {
   }
 };
 
+// 4 x 4 homogeneous matrix: only what the look-at helper c2w(position, target, up, Matrix4*) fills
+template <typename T>
+struct Mat4 {
+  T m[4][4];
+  Mat4() { for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) m[i][j] = T(0); }
+  static Mat4 Identity() { Mat4 r; for (int i = 0; i < 4; ++i) r.m[i][i] = T(1); return r; }
+  T& operator()(int i, int j) { return m[i][j]; }
+  const T& operator()(int i, int j) const { return m[i][j]; }
+};
+
 template <typename T>
 struct Affine3 {
   Mat3<T> R;
@@ -145,6 +155,8 @@ typedef Vec<int, 3> Vector3i;
 typedef Vec<double, 3> Vector3d;
 typedef Mat3<float> Matrix3f;
 typedef Mat3<double> Matrix3d;
+typedef Mat4<float> Matrix4f;
+typedef Mat4<double> Matrix4d;
 typedef Affine3<double> Affine3d;
 typedef Affine3<float> Affine3f;
 

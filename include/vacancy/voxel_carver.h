@@ -39,6 +39,44 @@ struct VoxelCarverOption {
   VoxelUpdateOption update_option;
 };
 
+// One voxel as the reference stores it (include/vacancy/voxel_carver.h:62-72).  On the device the grid is
+// a structure of arrays (vacancy_hip.h); this is the host-side view a VoxelGrid snapshot hands out.
+struct Voxel {
+  Eigen::Vector3i index{-1, -1, -1};      // voxel index
+  int id{-1};
+  Eigen::Vector3f pos{0.0f, 0.0f, 0.0f};  // center of voxel
+  float sdf{0.0f};                        // Signed Distance Function (SDF) value
+  int update_num{0};
+  bool outside{false};
+  bool on_surface{false};
+  Voxel();
+  ~Voxel();
+};
+
+// The reference's VoxelGrid (:74-93) as a HOST container: Init() lays out the voxels exactly like
+// VoxelGrid::Init (voxel_carver.cc:276-345); VoxelCarver::Download(VoxelGrid*) fills sdf / update_num
+// from the device-resident grid.  Carving never touches it.
+class VoxelGrid {
+ public:
+  VoxelGrid();
+  ~VoxelGrid();
+  bool Init(const Eigen::Vector3f& bb_max, const Eigen::Vector3f& bb_min, float resolution);
+  const Eigen::Vector3i& voxel_num() const;
+  const Voxel& get(int x, int y, int z) const;
+  Voxel* get_ptr(int x, int y, int z);
+  float resolution() const;
+  void ResetOnSurface();
+  bool initialized() const;
+
+ private:
+  std::vector<Voxel> voxels_;
+  Eigen::Vector3f bb_max_;
+  Eigen::Vector3f bb_min_;
+  float resolution_{-1.0f};
+  Eigen::Vector3i voxel_num_{0, 0, 0};
+  int xy_slice_num_{0};
+};
+
 class VoxelCarver {
  public:
   VoxelCarver();
@@ -57,8 +95,11 @@ class VoxelCarver {
   bool Carve(const Camera& camera, const Image1b& silhouette, Image1f* sdf);
   bool Carve(const Camera& camera, const Image1b& silhouette);
   bool Carve(const Camera& camera, const Image1f& sdf);
-  // All views in one fused pass over the grid (the reference's signature takes
-  // std::vector<Camera>, which cannot hold the abstract Camera; pointers are the usable form).
+  // All views in one fused pass over the grid.  The first form is the reference's signature
+  // (voxel_carver.h:113); Camera is abstract there as here, so callers hold cameras by pointer --
+  // examples.cc:108-128 keeps std::shared_ptr<Camera> -- and the other two forms take those directly.
+  bool Carve(const std::vector<Camera>& cameras, const std::vector<Image1b>& silhouettes);
+  bool Carve(const std::vector<std::shared_ptr<Camera>>& cameras, const std::vector<Image1b>& silhouettes);
   bool Carve(const std::vector<const Camera*>& cameras, const std::vector<Image1b>& silhouettes);
   void ExtractVoxel(Mesh* mesh, bool inside_empty = false);
   void ExtractIsoSurface(Mesh* mesh, double iso_level = 0.0, bool linear_interp = true);
@@ -66,6 +107,8 @@ class VoxelCarver {
   // grid access for host-side consumers: global dims and the voxel state in id order
   Eigen::Vector3i voxel_num() const;
   bool Download(std::vector<float>* sdf, std::vector<int>* update_num) const;
+  // host snapshot of the grid in the reference's own types: grid->Init(option) + sdf / update_num of every voxel
+  bool Download(VoxelGrid* grid) const;
 
  private:
   struct Impl;

@@ -47,7 +47,7 @@ def main():
         batch = vc.VoxelCarver.prepare_batch(views, d)
         for it in range(2):
             c.reset()
-            buf = (C.c_ulonglong * 12)()
+            buf = (C.c_ulonglong * 16)()
             assert ticks(buf, 1) == 0  # clear
             c.timer_begin()
             assert c.CarveBatchDevice(batch), vc.last_error()
@@ -65,6 +65,9 @@ def main():
                "ticks_per_pair": {"select-free": round(t[2] / max(1, t[7]), 1), "sure": round(t[3] / max(1, t[8]), 1),
                                   "checked": round(t[4] / max(1, t[9]), 1),
                                   "staging": round(t[1] / max(1, pairs), 1), "re-bound": round(t[5] / max(1, pairs), 1)}}
+        rec["prologue_ticks_per_wave"] = {"arguments + axis tables": round(t[12] / max(1, t[10]), 1),
+                                          "brick_footprints": round((t[13] - t[12]) / max(1, t[10]), 1),
+                                          "state, live set, first tile request": round((t[0] - t[13]) / max(1, t[10]), 1)}
         out[name] = rec
         print(name, json.dumps(rec))
         del c

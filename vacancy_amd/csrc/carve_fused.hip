@@ -65,6 +65,12 @@ constexpr int kWmaxPlanes = 2;           // window sizes 4 and 8
 #ifndef VCY_FAST_GROUP
 #define VCY_FAST_GROUP 4   // voxels whose LDS reads are in flight together
 #endif
+#ifndef VCY_DENORM_ADDR
+#define VCY_DENORM_ADDR 1  // LDS addresses of the select-free loop as denormal sums (see carve_view_fast)
+#endif
+#ifndef VCY_UNIFORM_VGPR
+#define VCY_UNIFORM_VGPR 0  // 1: fx, t[2]; 2: also t[0], t[1], cx, cy of the select-free loop in VGPRs
+#endif
 #ifndef VCY_WAVES
 #define VCY_WAVES 5        // waves per SIMD the kernel is compiled for (register budget 512 / VCY_WAVES)
 #endif
@@ -72,10 +78,11 @@ constexpr int kWmaxPlanes = 2;           // window sizes 4 and 8
 // Development build only (-DVCY_PHASE_TIMING, profiles/tools/phase_timing.py): s_memtime ticks of every wave,
 // accumulated per phase of the fused kernel.  Slots 0-6: prologue + state load, tile staging, select-free
 // view, sure view, checked view, re-bounding after a change, write-back; 7-9: views taken by the three
-// loops; 10: waves; 11: views that changed their brick.
+// loops; 10: waves; 11: views that changed their brick; 12-14: parts of slot 0 (until the kernel arguments
+// and axis tables are there, brick_footprints, state + first live set).
 #ifdef VCY_PHASE_TIMING
 __device__ unsigned long long g_phase_ticks[256][16];
-#define VCY_PT_DECL unsigned long long pt_last = __builtin_amdgcn_s_memtime(), pt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define VCY_PT_DECL unsigned long long pt_last = __builtin_amdgcn_s_memtime(), pt_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define VCY_PT(slot)                                                  \
   do {                                                                \
     const unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
@@ -86,7 +93,7 @@ __device__ unsigned long long g_phase_ticks[256][16];
 #define VCY_PT_FLUSH(lane_)                                                                         \
   do {                                                                                              \
     if ((lane_) == 0)                                                                               \
-      for (int q_ = 0; q_ < 12; ++q_) atomicAdd(&g_phase_ticks[blockIdx.x & 255][q_], pt_acc[q_]);  \
+      for (int q_ = 0; q_ < 16; ++q_) atomicAdd(&g_phase_ticks[blockIdx.x & 255][q_], pt_acc[q_]);  \
   } while (0)
 #else
 #define VCY_PT_DECL
@@ -340,6 +347,7 @@ __device__ __forceinline__ void tile_prefetch(const ViewParams& v, const TileInf
 }
 
 typedef float __attribute__((address_space(3))) lds_float;
+typedef uint32_t __attribute__((address_space(3))) lds_u32;
 
 // Raw tile of view `v` into the wave-private LDS buffer `buf` (256 floats): pixel (i, j) of the tile =
 // image pixel (min(tx0 + i, roi_max.x), min(ty0 + j, roi_max.y)), for the th + 1 <= 16 rows the taps reach.
@@ -352,12 +360,25 @@ __device__ __forceinline__ void raw_prefetch(const ViewParams& v, const TileInfo
   const int ty0 = __builtin_amdgcn_readfirstlane(ti.ty0);
   gfloat_ptr img = (gfloat_ptr)v.sdf;
   const unsigned width = (unsigned)v.width;
+  lds_float* dst = (lds_float*)buf;
+  if (tx0 + 15 <= v.roi_max_xi && ty0 + 15 <= v.roi_max_yi) {
+    // The usual case (uniform test): the whole 16 x 16 window lies inside the ROI, nothing is clamped.  The
+    // address is a scalar base per group of four rows plus one per-lane offset that only depends on the
+    // image width: one vector instruction per load.
+    const unsigned lane_off = __umul24(width, (unsigned)lane >> 4) + ((unsigned)lane & 15u);
+    gfloat_ptr base = img + (__umul24(width, (unsigned)ty0) + (unsigned)tx0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (4 * r <= th)  // uniform: rows 4 r .. 4 r + 3 hold a tap row (taps reach rows 0 .. th)
+        __builtin_amdgcn_global_load_lds(base + (size_t)(4 * r) * width + lane_off, dst + 64 * r, 4, 0, 0);
+    }
+    return;
+  }
   const unsigned xx = (unsigned)min(tx0 + (lane & 15), v.roi_max_xi);
   const int yl = ty0 + (lane >> 4);
-  lds_float* dst = (lds_float*)buf;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    if (4 * r <= th) {  // uniform: rows 4 r .. 4 r + 3 hold a tap row (taps reach rows 0 .. th)
+    if (4 * r <= th) {
       const unsigned yy = (unsigned)min(yl + 4 * r, v.roi_max_yi);
       __builtin_amdgcn_global_load_lds(img + (__umul24(width, yy) + xx), dst + 64 * r, 4, 0, 0);
     }
@@ -489,11 +510,25 @@ template <bool SAMEF, int TQ, bool GEN>
 __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __restrict__ views, int nviews, int lane,
                                                             float xl, float xh, float yl, float yh, float zl_, float zh,
                                                             bool is_ortho, bool outside_max, bool want_bound,
-                                                            TileInfo* tinfo) {
+                                                            lds_u32* tinfo_lds) {
   float ub_lane = INFINITY;
   if (lane < nviews) {
     const int vi = lane;
-    const ViewParams& v = views[vi].v;
+    // The whole record at once (ten 16-byte loads in flight, one wait): fields fetched where they are first
+    // needed cost a memory round trip each, behind every branch of this function.
+    // (Pinned by the empty asm: the compiler would otherwise sink every load to its first use again.)
+    static_assert(sizeof(FusedView) % 4 == 0, "FusedView is fetched dword by dword");
+    constexpr int kViewDwords = (int)(sizeof(FusedView) / 4);
+    typedef const uint32_t __attribute__((address_space(1))) * gu32_ptr;
+    gu32_ptr src = (gu32_ptr)views + (size_t)vi * kViewDwords;
+    uint32_t raw[kViewDwords];
+#pragma unroll
+    for (int q = 0; q < kViewDwords; ++q) raw[q] = src[q];
+#pragma unroll
+    for (int q = 0; q < kViewDwords; ++q) asm volatile("" : "+v"(raw[q]));
+    FusedView fv;
+    __builtin_memcpy(&fv, raw, sizeof(FusedView));
+    const ViewParams& v = fv.v;
     const float xa = fmaxf(fabsf(xl), fabsf(xh)), ya = fmaxf(fabsf(yl), fabsf(yh)), za = fmaxf(fabsf(zl_), fabsf(zh));
     const bool ortho = GEN && is_ortho;
     float p0[3], ax[3], ay[3], az[3], mag[3];
@@ -604,16 +639,30 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
           const int ph = min(ty1 + 1, v.roi_max_yi) - ty0 + 1;
           float m = -INFINITY;
           int has_nan = 0;
-          gfloat_ptr wm = (gfloat_ptr)views[vi].wmax;
+          gfloat_ptr wm = (gfloat_ptr)fv.wmax;
           if (wm != nullptr && min(pw, ph) >= 4) {
             // window maxima: k = 8 or 4 <= min(pw, ph), nxw x nyw windows inside the rectangle
             const int L = min(pw, ph) >= 8 ? 3 : 2;
             const int k = 1 << L;
             const int nxw = (pw + k - 1) >> L, nyw = (ph + k - 1) >> L;
-            gfloat_ptr lvl = wm + (L == 3 ? (size_t)views[vi].wmax_plane : (size_t)0);
-            for (int bq = 0; bq < nyw; ++bq) {
-              gfloat_ptr row = lvl + (unsigned)v.width * (unsigned)(ty0 + min(bq << L, ph - k));
-              for (int aq = 0; aq < nxw; ++aq) m = fmaxf(m, row[tx0 + min(aq << L, pw - k)]);
+            gfloat_ptr lvl = wm + (L == 3 ? (size_t)fv.wmax_plane : (size_t)0);
+            if (nxw <= 3 && nyw <= 3) {
+              // the usual case (footprints up to 24 pixels wide): all nine lookups in flight together; window
+              // positions beyond nxw / nyw clamp onto the last one
+              float t[9];
+#pragma unroll
+              for (int bq = 0; bq < 3; ++bq) {
+                const unsigned ro = (unsigned)v.width * (unsigned)(ty0 + min(bq << L, ph - k)) + (unsigned)tx0;
+#pragma unroll
+                for (int aq = 0; aq < 3; ++aq) t[3 * bq + aq] = lvl[ro + (unsigned)min(aq << L, pw - k)];
+              }
+#pragma unroll
+              for (int q = 0; q < 9; ++q) m = fmaxf(m, t[q]);
+            } else {
+              for (int bq = 0; bq < nyw; ++bq) {
+                gfloat_ptr row = lvl + (unsigned)v.width * (unsigned)(ty0 + min(bq << L, ph - k));
+                for (int aq = 0; aq < nxw; ++aq) m = fmaxf(m, row[tx0 + min(aq << L, pw - k)]);
+              }
             }
           } else {  // thin rectangle, or no planes (out of memory for them): scan it
             gfloat_ptr img = (gfloat_ptr)v.sdf;
@@ -635,7 +684,13 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
         }
       }
     }
-    tinfo[vi] = ti;
+    // (through an LDS-typed pointer: ds_write_b128, not flat stores)
+    static_assert(sizeof(TileInfo) % 4 == 0, "TileInfo is stored dword by dword");
+    uint32_t w32[sizeof(TileInfo) / 4];
+    __builtin_memcpy(w32, &ti, sizeof(TileInfo));
+    lds_u32* dst = tinfo_lds + vi * (int)(sizeof(TileInfo) / 4);
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(TileInfo) / 4); ++q) dst[q] = w32[q];
     ub_lane = ti.ub;
   }
   return ub_lane;
@@ -706,15 +761,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCY_WAVES))
 
   // ---- prologue: lane vi bounds the footprint of the wave brick in view vi (brick_footprints) -------
   float ub_lane;
+#ifdef VCY_PHASE_TIMING
+  {
+    asm volatile("" ::"v"(py), "v"(pz));  // the axis tables have arrived
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();
+    pt_acc[12] += t_ - pt_last;
+  }
+#endif
   {
     const int x_lo = min(x_first, g.nx - 1), x_hi = min(x_first + WX - 1, g.nx - 1);
     const int y_hi = min(by * BY + BY - 1, g.ny - 1);
     const int z_hi = min(zl0 + BZ - 1, g.nz_local - 1);
     ub_lane = brick_footprints<SAMEF, TQ, GEN>(views, nviews, lane, g.px[x_lo], g.px[x_hi], g.py[by * BY], g.py[y_hi],
                                                g.pz[g.z0 + zl0], g.pz[g.z0 + z_hi], mode.ortho != 0,
-                                               mode.outside == VCY_OUTSIDE_MAX, want_bound, tinfo);
+                                               mode.outside == VCY_OUTSIDE_MAX, want_bound, (lds_u32*)tinfo);
   }
   wave_lds_fence();
+#ifdef VCY_PHASE_TIMING
+  {
+    asm volatile("" ::"v"(ub_lane));
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();
+    pt_acc[13] += t_ - pt_last;  // (includes slot 12)
+  }
+#endif
   const unsigned long long view_mask = (nviews >= 64) ? ~0ull : ((1ull << nviews) - 1ull);
 
   // ---- load the wave brick's state ----------------------------------------------------------
@@ -761,6 +830,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCY_WAVES))
     all_touched = __all(nmin >= (NT)1);
   };
   if (!fresh) refresh_all_touched();
+  // No voxel of the brick touched yet?  (Wave-uniform; true for every brick of a fresh slab.)  The first `sure`
+  // view of such a brick is a plain store of the samples (carve_view_fast<FIRST>).
+  bool none_touched = fresh != 0;
+  if (!fresh && UPDATE == VCY_UPDATE_MAX && !all_touched) {
+    NT nmax = n[0];
+#pragma unroll
+    for (int k = 1; k < WX; ++k) nmax = max(nmax, n[k]);
+    none_touched = __all(nmax < (NT)1);
+  }
   // views that may still change something, as a wave-uniform bit mask
   auto live_views = [&]() -> unsigned long long {
     bool drop = false;
@@ -906,17 +984,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCY_WAVES))
     //  - the update is a compare / select / carry chain through VCC (update_max_touched).
     constexpr bool kFastMax = !GEN && UPDATE == VCY_UPDATE_MAX && !TRUNC && !CHECKMAX;
     constexpr bool kFastWa = !GEN && UPDATE == kUpdateWaUnitWeight && !CHECKMAX;
-    auto carve_view_fast = [&]() -> bool {
+    // FIRST: no voxel of the brick has been touched yet (a fresh slab): the update is `sdf = dist, update_num = 1`
+    // for every voxel (voxel_carver.cc:482-486), whatever the old value.
+    auto carve_view_fast = [&](auto first_tag) -> bool {
+      constexpr bool FIRST = decltype(first_tag)::value;
       // uniform -> VGPR (opaque to the compiler, which would otherwise fold them back into SGPR operands)
       float pitch16, cmagic;
       constexpr int kElemB = kRaw ? 4 : 16;     // bytes per tile element (pixel or quad)
+      // VCY_DENORM_ADDR: the same sum scaled by 2^-149, i.e. carried out in denormals (fp32 denormals are on
+      // for this library and v_fma_f32 handles them at full rate): the bit pattern of the result IS the
+      // integer, no mask needed.  The constant may be negative (base < 0); the final sum never is.
+      constexpr float kAddrUnit = VCY_DENORM_ADDR ? 0x1p-149f : 1.0f;
       {
-        const float p16 = pitchf * (float)kElemB;  // bytes per tile row; pitch <= 512: exact
+        const float p16 = pitchf * ((float)kElemB * kAddrUnit);  // bytes per tile row; pitch <= 512: exact
         const unsigned lds_off = kRaw ? (unsigned)(size_t)rawcur : (unsigned)(size_t)(lds_float4*)tile;
-        const float cm = 8388608.0f + (float)(kElemB * base + (int)lds_off);  // |16 base| < 2^22 (TileInfo::sure)
+        const int ci = kElemB * base + (int)lds_off;  // |16 base| < 2^22 (TileInfo::sure)
+        const float cm = VCY_DENORM_ADDR ? (ci < 0 ? -__int_as_float(-ci) : __int_as_float(ci)) : 8388608.0f + (float)ci;
         asm volatile("v_mov_b32_e32 %0, %1" : "=v"(pitch16) : "s"(p16));
         asm volatile("v_mov_b32_e32 %0, %1" : "=v"(cmagic) : "s"(cm));
       }
+      float t0 = v.t[0], t1 = v.t[1], t2 = v.t[2], fxv = v.fx, fyv = v.fy, cxv = v.cx, cyv = v.cy;
+#if VCY_UNIFORM_VGPR >= 1
+      asm volatile("v_mov_b32_e32 %0, %1" : "=v"(fxv) : "s"(v.fx));
+      asm volatile("v_mov_b32_e32 %0, %1" : "=v"(t2) : "s"(v.t[2]));
+#endif
+#if VCY_UNIFORM_VGPR >= 2
+      asm volatile("v_mov_b32_e32 %0, %1" : "=v"(t0) : "s"(v.t[0]));
+      asm volatile("v_mov_b32_e32 %0, %1" : "=v"(t1) : "s"(v.t[1]));
+      asm volatile("v_mov_b32_e32 %0, %1" : "=v"(cxv) : "s"(v.cx));
+      asm volatile("v_mov_b32_e32 %0, %1" : "=v"(cyv) : "s"(v.cy));
+#endif
       // Four voxels at a time.  Phase A: image coordinates, fractions and the LDS reads (in flight
       // together); phase B: weights, sample, update.
       unsigned long long took = 0;
@@ -927,20 +1024,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCY_WAVES))
 #pragma unroll
         for (int j = 0; j < VCY_FAST_GROUP; ++j) {
           const int k = k0 + j;
-          const float pcz = v.t[2] + (c0[16 + k] + h12z);
-          const float qx = div_view<DIV>(v.fx, pcz);
-          const float qy = SAMEF ? qx : div_view<DIV>(v.fy, pcz);
-          const float pcx = v.t[0] + (c0[2 * k] + h12x), pcy = v.t[1] + (c0[2 * k + 1] + h12y);
-          const float u = qx * pcx + v.cx, w = qy * pcy + v.cy;
+          const float pcz = t2 + (c0[16 + k] + h12z);
+          const float qx = div_view<DIV>(fxv, pcz);
+          const float qy = SAMEF ? qx : div_view<DIV>(fyv, pcz);
+          const float pcx = t0 + (c0[2 * k] + h12x), pcy = t1 + (c0[2 * k + 1] + h12y);
+          const float u = qx * pcx + cxv, w = qy * pcy + cyv;
           const float fu = floorf(u), fw = floorf(w);
           lu[j] = u - fu;
           lv[j] = w - fw;
-          const float a = __builtin_fmaf(fw, pitch16, __builtin_fmaf(fu, (float)kElemB, cmagic));
+          const float a = __builtin_fmaf(fw, pitch16, __builtin_fmaf(fu, (float)kElemB * kAddrUnit, cmagic));
+          const unsigned addr = VCY_DENORM_ADDR ? __float_as_uint(a) : (__float_as_uint(a) & 0x7fffffu);
           if constexpr (kRaw) {
-            const lds_float* tp = (const lds_float*)(size_t)(__float_as_uint(a) & 0x7fffffu);
+            const lds_float* tp = (const lds_float*)(size_t)addr;
             q[j] = f4{tp[0], tp[1], tp[16], tp[17]};
           } else {
-            q[j] = *(const lds_float4*)(size_t)(__float_as_uint(a) & 0x7fffffu);
+            q[j] = *(const lds_float4*)(size_t)addr;
           }
         }
 #pragma unroll
@@ -949,16 +1047,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCY_WAVES))
           const float mu = 1.0f - lu[j], mv = 1.0f - lv[j];
           const float dist =
               ((((mu * mv) * q[j].x) + ((lu[j] * mv) * q[j].y)) + ((mu * lv[j]) * q[j].z)) + ((lu[j] * lv[j]) * q[j].w);
-          if constexpr (kFastMax) update_max_touched(dist, s[k], n[k], took);
-          else if constexpr (kFastWa) update_wa_unit<TRUNC>(dist, s[k], n[k]);
+          if constexpr (FIRST) {
+            s[k] = dist;
+            n[k] = (NT)1;
+          } else if constexpr (kFastMax) {
+            update_max_touched(dist, s[k], n[k], took);
+          } else if constexpr (kFastWa) {
+            update_wa_unit<TRUNC>(dist, s[k], n[k]);
+          }
         }
       }
-      return kFastMax ? took != 0ull : true;
+      return (kFastMax && !FIRST) ? took != 0ull : true;
     };
     bool brick_moved;
     const bool sure = !GEN && __builtin_amdgcn_readfirstlane(tinfo[vi].sure) != 0;
-    if ((kFastMax && sure && all_touched) || (kFastWa && sure && implied)) {
-      brick_moved = carve_view_fast();
+    if (kFastMax && sure && none_touched) {
+      brick_moved = carve_view_fast(std::true_type{});
+      none_touched = false;
+      VCY_PT(2);
+      VCY_PT_COUNT(7);
+    } else if ((kFastMax && sure && all_touched) || (kFastWa && sure && implied)) {
+      brick_moved = carve_view_fast(std::false_type{});
       VCY_PT(2);
       VCY_PT_COUNT(7);
     } else if (sure) {
@@ -1330,7 +1439,7 @@ int fused_max_views() { return kMaxFusedViews; }
 extern "C" int vcy_debug_phase_ticks(unsigned long long* out12, int reset) {
   unsigned long long h[256][16];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(vcy::g_phase_ticks), sizeof(h)) != hipSuccess) return -1;
-  for (int q = 0; q < 12; ++q) {
+  for (int q = 0; q < 16; ++q) {
     out12[q] = 0;
     for (int b = 0; b < 256; ++b) out12[q] += h[b][q];
   }

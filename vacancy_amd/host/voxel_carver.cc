@@ -43,6 +43,67 @@ vcy_view ToView(const Camera& camera, const Eigen::Vector2i& roi_min, const Eige
 }
 }  // namespace
 
+Voxel::Voxel() {}
+Voxel::~Voxel() {}
+
+VoxelGrid::VoxelGrid() {}
+VoxelGrid::~VoxelGrid() {}
+
+// reference voxel_carver.cc:276-345, expression for expression (the device builds the same three axis
+// tables: vcy_download_positions returns these positions bit for bit)
+bool VoxelGrid::Init(const Eigen::Vector3f& bb_max, const Eigen::Vector3f& bb_min, float resolution) {
+  if (resolution < std::numeric_limits<float>::min()) {
+    LOGE("resolution must be positive %f\n", resolution);
+    return false;
+  }
+  if (bb_max.x() <= bb_min.x() || bb_max.y() <= bb_min.y() || bb_max.z() <= bb_min.z()) {
+    LOGE("input bounding box is invalid\n");
+    return false;
+  }
+  bb_max_ = bb_max;
+  bb_min_ = bb_min;
+  resolution_ = resolution;
+  const Eigen::Vector3f diff = bb_max_ - bb_min_;
+  for (int i = 0; i < 3; i++) voxel_num_[i] = static_cast<int>(diff[i] / resolution_);
+  if (static_cast<long long>(voxel_num_.x()) * voxel_num_.y() * voxel_num_.z() > std::numeric_limits<int>::max()) {
+    LOGE("too many voxels\n");
+    return false;
+  }
+  xy_slice_num_ = voxel_num_[0] * voxel_num_[1];
+  voxels_.clear();
+  voxels_.resize(static_cast<size_t>(voxel_num_.x()) * voxel_num_.y() * voxel_num_.z());
+  const float offset = resolution_ * 0.5f;
+  for (int z = 0; z < voxel_num_.z(); z++) {
+    const float z_pos = diff.z() * (static_cast<float>(z) / static_cast<float>(voxel_num_.z())) + bb_min_.z() + offset;
+    for (int y = 0; y < voxel_num_.y(); y++) {
+      const float y_pos =
+          diff.y() * (static_cast<float>(y) / static_cast<float>(voxel_num_.y())) + bb_min_.y() + offset;
+      for (int x = 0; x < voxel_num_.x(); x++) {
+        const float x_pos =
+            diff.x() * (static_cast<float>(x) / static_cast<float>(voxel_num_.x())) + bb_min_.x() + offset;
+        Voxel* voxel = get_ptr(x, y, z);
+        voxel->index = Eigen::Vector3i(x, y, z);
+        voxel->id = z * xy_slice_num_ + (y * voxel_num_.x() + x);
+        voxel->pos = Eigen::Vector3f(x_pos, y_pos, z_pos);
+        voxel->sdf = InvalidSdf::kVal;
+      }
+    }
+  }
+  return true;
+}
+const Eigen::Vector3i& VoxelGrid::voxel_num() const { return voxel_num_; }
+const Voxel& VoxelGrid::get(int x, int y, int z) const {
+  return voxels_[static_cast<size_t>(z) * xy_slice_num_ + (static_cast<size_t>(y) * voxel_num_.x() + x)];
+}
+Voxel* VoxelGrid::get_ptr(int x, int y, int z) {
+  return &voxels_[static_cast<size_t>(z) * xy_slice_num_ + (static_cast<size_t>(y) * voxel_num_.x() + x)];
+}
+float VoxelGrid::resolution() const { return resolution_; }
+void VoxelGrid::ResetOnSurface() {
+  for (Voxel& v : voxels_) v.on_surface = false;
+}
+bool VoxelGrid::initialized() const { return !voxels_.empty(); }
+
 struct VoxelCarver::Impl {
   VoxelCarverOption option;
   vcy_ctx* ctx = nullptr;
@@ -130,6 +191,18 @@ bool VoxelCarver::Carve(const Camera& camera, const Image1f& sdf) {
   return Carve(camera, Eigen::Vector2i(0, 0), Eigen::Vector2i(sdf.width() - 1, sdf.height() - 1), sdf);
 }
 
+bool VoxelCarver::Carve(const std::vector<Camera>& cameras, const std::vector<Image1b>& silhouettes) {
+  std::vector<const Camera*> ptrs(cameras.size());
+  for (size_t i = 0; i < cameras.size(); ++i) ptrs[i] = &cameras[i];
+  return Carve(ptrs, silhouettes);
+}
+
+bool VoxelCarver::Carve(const std::vector<std::shared_ptr<Camera>>& cameras, const std::vector<Image1b>& silhouettes) {
+  std::vector<const Camera*> ptrs(cameras.size());
+  for (size_t i = 0; i < cameras.size(); ++i) ptrs[i] = cameras[i].get();
+  return Carve(ptrs, silhouettes);
+}
+
 bool VoxelCarver::Carve(const std::vector<const Camera*>& cameras, const std::vector<Image1b>& silhouettes) {
   if (!impl_->ctx || cameras.size() != silhouettes.size() || cameras.empty()) return false;
   const int n = static_cast<int>(cameras.size());
@@ -202,6 +275,26 @@ bool VoxelCarver::Download(std::vector<float>* sdf, std::vector<int>* update_num
   if (sdf) sdf->resize(total);
   if (update_num) update_num->resize(total);
   return vcy_download(impl_->ctx, sdf ? sdf->data() : nullptr, update_num ? update_num->data() : nullptr) == VCY_OK;
+}
+
+bool VoxelCarver::Download(VoxelGrid* grid) const {
+  if (!impl_->ctx || !grid) return false;
+  const VoxelCarverOption& o = impl_->option;
+  if (!grid->Init(o.bb_max, o.bb_min, o.resolution)) return false;
+  const Eigen::Vector3i n = grid->voxel_num();
+  if (n[0] != voxel_num()[0] || n[1] != voxel_num()[1] || n[2] != voxel_num()[2]) return false;
+  std::vector<float> sdf;
+  std::vector<int> update_num;
+  if (!Download(&sdf, &update_num)) return false;
+  size_t i = 0;
+  for (int z = 0; z < n[2]; ++z)
+    for (int y = 0; y < n[1]; ++y)
+      for (int x = 0; x < n[0]; ++x, ++i) {
+        Voxel* v = grid->get_ptr(x, y, z);
+        v->sdf = sdf[i];
+        v->update_num = update_num[i];
+      }
+  return true;
 }
 
 void DistanceTransformL1(const Image1b& mask, const Eigen::Vector2i& roi_min, const Eigen::Vector2i& roi_max,
