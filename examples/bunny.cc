@@ -111,5 +111,33 @@ int main(int argc, char* argv[]) {
                 "voxel_verts %zu\n",
                 i, nv, nf, mesh.vertices().size(), mesh.vertex_indices().size(), sum[0], sum[1], sum[2], voxel_verts);
   }
+
+  // The same six views through the batch overload (cameras held by shared_ptr, as examples.cc does) on a
+  // second carver, read back as the reference's VoxelGrid: touched voxels, negative voxels, sum of update_num.
+  {
+    std::vector<std::shared_ptr<vacancy::Camera>> cameras;
+    std::vector<vacancy::Image1b> silhouettes(6);
+    for (size_t i = 0; i < 6 && i < poses.size(); ++i) {
+      cameras.push_back(std::make_shared<vacancy::PinholeCamera>(width, height, poses[i], Eigen::Vector2f(159.3f, 127.65f),
+                                                                 Eigen::Vector2f(258.65f, 258.25f)));
+      if (!silhouettes[i].Load(data_dir + "/mask_" + vacancy::zfill(i) + ".png")) return 3;
+    }
+    silhouettes.resize(cameras.size());
+    vacancy::VoxelCarver batch(option);
+    vacancy::VoxelGrid grid;
+    if (!batch.Init() || !batch.Carve(cameras, silhouettes) || !batch.Download(&grid)) return 7;
+    const Eigen::Vector3i n = grid.voxel_num();
+    long long touched = 0, negative = 0, updates = 0;
+    for (int z = 0; z < n[2]; ++z)
+      for (int y = 0; y < n[1]; ++y)
+        for (int x = 0; x < n[0]; ++x) {
+          const vacancy::Voxel& v = grid.get(x, y, z);
+          if (v.update_num < 1) continue;
+          ++touched;
+          negative += v.sdf < 0 ? 1 : 0;
+          updates += v.update_num;
+        }
+    std::printf("GRID touched %lld negative %lld updates %lld\n", touched, negative, updates);
+  }
   return 0;
 }

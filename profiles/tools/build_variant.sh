@@ -1,18 +1,22 @@
 #!/bin/bash
-# Development aid: builds libvacancy_hip.so with extra compiler flags for carve_fused.hip into
-# build/variants/<name>/ (A/B runs of kernel variants in one GPU session: VCY_HIP_LIB=<path> python bench.py).
-#   profiles/tools/build_variant.sh <name> [extra hipcc flags...]
+# Development aid: builds libvacancy_hip.so with extra compiler flags for one source file (carve_fused.hip, or
+# $VARIANT_SRC) into build/variants/<name>/ (A/B runs of kernel variants in one GPU session:
+# VCY_HIP_LIB=<path> python bench.py).
+#   [VARIANT_SRC=mc_kernels.hip] profiles/tools/build_variant.sh <name> [extra hipcc flags...]
 set -eu
 NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 SRC=$ROOT/vacancy_amd/csrc
 OUT=$ROOT/build/variants/$NAME
+VSRC=${VARIANT_SRC:-carve_fused.hip}
+VOBJ=${VSRC%.hip}.o
 mkdir -p "$OUT"
-make -C "$SRC" -s all
+# every object but the variant's own
+make -C "$SRC" -s $(cd "$SRC" && ls *.hip | grep -v "^$VSRC\$" | sed 's/\.hip$/.o/')
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
  -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function -I$ROOT/include -I$SRC -fno-slp-vectorize"
-/opt/rocm/bin/hipcc $FLAGS "$@" -c "$SRC/carve_fused.hip" -o "$OUT/carve_fused.o"
-OBJS=$(cd "$SRC" && ls *.o | grep -v '^carve_fused.o$' | sed "s#^#$SRC/#")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libvacancy_hip.so" $OBJS "$OUT/carve_fused.o" -ldl -Wl,-rpath,/opt/rocm/lib
-rm -f "$OUT/carve_fused.o"
+/opt/rocm/bin/hipcc $FLAGS "$@" -c "$SRC/$VSRC" -o "$OUT/$VOBJ"
+OBJS=$(cd "$SRC" && ls *.o | grep -v "^$VOBJ\$" | sed "s#^#$SRC/#")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libvacancy_hip.so" $OBJS "$OUT/$VOBJ" -ldl -Wl,-rpath,/opt/rocm/lib
+rm -f "$OUT/$VOBJ"
 echo "$OUT/libvacancy_hip.so"

@@ -321,6 +321,10 @@ def test_cpp_bunny_example(tmp_path):
         assert (int(r[4]), int(r[6])) == (exp[5], exp[6]), (i, r)
     assert (int(rows[5][8]), int(rows[5][10])) == tuple(gold["final_nointerp"])
     assert int(rows[5][16]) == 683400  # ExtractVoxel, SURVEY Appendix C
+    grid = [l.split() for l in out.splitlines() if l.startswith("GRID")]
+    # batch overload + VoxelGrid read-back: touched / negative / sum(update_num) after the six views
+    final = gold["modes"]["default"][5]
+    assert [int(grid[0][2]), int(grid[0][4]), int(grid[0][6])] == [final[0], final[1], final[3]]
     vsum = [float(x) for x in rows[5][12:15]]
     assert np.allclose(vsum, gold["final_vertex_sums"], rtol=0, atol=1e-4)
     # ASCII PLY byte for byte what the reference's Mesh::WritePly (mesh.cc:583-631) writes for the

@@ -121,6 +121,10 @@ def test_cpp_facade_host_utilities():
     got = w2c.reshape(3, 4)
     assert np.array_equal(got[:, :3].reshape(-1), np.array(ref["R"], np.float32))
     assert np.array_equal(got[:, 3], np.array(ref["t"], np.float32))
+    grid = [l for l in out if l.startswith("GRID")][0].split()
+    assert [int(x) for x in grid[1:4]] == GOLD["dims"]["10"]          # VoxelGrid::Init, voxel_carver.cc:276-345
+    assert grid[4] == GOLD["fnv1a64"]["res10_pos"] and grid[5] == "1"  # voxel centres, ids, reset, error returns
+    assert [l for l in out if l.startswith("C2W")][0].split()[1] == "1"  # common.h:51-75 forms agree
     focal = [np.float32(x) for x in [l for l in out if l.startswith("FOCAL")][0].split()[1:]]
     assert focal[0] == synth.focal_from_fov_y(720, 60.0) and focal[1] == np.float32(639.5)
 

@@ -71,8 +71,19 @@ constexpr int kWmaxPlanes = 2;           // window sizes 4 and 8
 #ifndef VCY_UNIFORM_VGPR
 #define VCY_UNIFORM_VGPR 0  // 1: fx, t[2]; 2: also t[0], t[1], cx, cy of the select-free loop in VGPRs
 #endif
+// Waves per SIMD the kernels are compiled for (register budget 512 / waves).  The kernels whose work is done by
+// the select-free loop (raw tiles, pinhole + bilinear, no update_num limit in reach) need 57-59 VGPRs there; what
+// wants more is the checked loop with its call of the generic sampler, which those kernels rarely enter.  They
+// are compiled for 7 waves (72 VGPRs: a handful of spills, placed in the rare blocks by the branch weights at
+// the loop selection; 8 waves spill in the tile staging as well and lose 15 %).  The others keep 5.
 #ifndef VCY_WAVES
-#define VCY_WAVES 5        // waves per SIMD the kernel is compiled for (register budget 512 / VCY_WAVES)
+#define VCY_WAVES 7
+#endif
+#ifndef VCY_WAVES_CHECKED
+#define VCY_WAVES_CHECKED 5
+#endif
+#ifndef VCY_WA_GROUP
+#define VCY_WA_GROUP VCY_FAST_GROUP  // voxels in flight together in the weighted-average kernels
 #endif
 
 // Development build only (-DVCY_PHASE_TIMING, profiles/tools/phase_timing.py): s_memtime ticks of every wave,
@@ -640,8 +651,10 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
           float m = -INFINITY;
           int has_nan = 0;
           gfloat_ptr wm = (gfloat_ptr)fv.wmax;
-          if (wm != nullptr && min(pw, ph) >= 4) {
-            // window maxima: k = 8 or 4 <= min(pw, ph), nxw x nyw windows inside the rectangle
+          if (wm != nullptr) {
+            // window maxima: k = 8 when both sides reach 8, else 4; nxw x nyw windows placed inside the rectangle
+            // (a side shorter than k gets one window that sticks out of it: a maximum over more pixels is still
+            // an upper bound, and the planes are filled well beyond any footprint, FusedView::wrect)
             const int L = min(pw, ph) >= 8 ? 3 : 2;
             const int k = 1 << L;
             const int nxw = (pw + k - 1) >> L, nyw = (ph + k - 1) >> L;
@@ -652,19 +665,19 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
               float t[9];
 #pragma unroll
               for (int bq = 0; bq < 3; ++bq) {
-                const unsigned ro = (unsigned)v.width * (unsigned)(ty0 + min(bq << L, ph - k)) + (unsigned)tx0;
+                const unsigned ro = (unsigned)v.width * (unsigned)(ty0 + min(bq << L, max(ph - k, 0))) + (unsigned)tx0;
 #pragma unroll
-                for (int aq = 0; aq < 3; ++aq) t[3 * bq + aq] = lvl[ro + (unsigned)min(aq << L, pw - k)];
+                for (int aq = 0; aq < 3; ++aq) t[3 * bq + aq] = lvl[ro + (unsigned)min(aq << L, max(pw - k, 0))];
               }
 #pragma unroll
               for (int q = 0; q < 9; ++q) m = fmaxf(m, t[q]);
             } else {
               for (int bq = 0; bq < nyw; ++bq) {
-                gfloat_ptr row = lvl + (unsigned)v.width * (unsigned)(ty0 + min(bq << L, ph - k));
-                for (int aq = 0; aq < nxw; ++aq) m = fmaxf(m, row[tx0 + min(aq << L, pw - k)]);
+                gfloat_ptr row = lvl + (unsigned)v.width * (unsigned)(ty0 + min(bq << L, max(ph - k, 0)));
+                for (int aq = 0; aq < nxw; ++aq) m = fmaxf(m, row[tx0 + min(aq << L, max(pw - k, 0))]);
               }
             }
-          } else {  // thin rectangle, or no planes (out of memory for them): scan it
+          } else {  // no planes (out of memory for them): scan the rectangle
             gfloat_ptr img = (gfloat_ptr)v.sdf;
             for (int j = 0; j < ph; ++j) {
               gfloat_ptr row = img + ((unsigned)v.width * (unsigned)(ty0 + j) + (unsigned)tx0);
@@ -699,7 +712,9 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
 // GEN: nearest-neighbour sampling and/or an orthographic camera, selected at run time from `mode`
 // (compiled out of the default bilinear + pinhole kernels, where the extra branches cost 16 %).
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX, int TQ, bool GEN, int DIV>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCY_WAVES))) void carve_fused_kernel(GridParams g,
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDATE != VCY_UPDATE_WEIGHTED_AVERAGE)
+                                       ? VCY_WAVES : VCY_WAVES_CHECKED))) void carve_fused_kernel(GridParams g,
                                                           const FusedView* __restrict__ views,
                                                           const float* __restrict__ c0_all,
                                                           int nviews, ModeParams mode, int nbx,
@@ -1017,12 +1032,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCY_WAVES))
       // Four voxels at a time.  Phase A: image coordinates, fractions and the LDS reads (in flight
       // together); phase B: weights, sample, update.
       unsigned long long took = 0;
+      constexpr int kGroup = UPDATE == VCY_UPDATE_MAX ? VCY_FAST_GROUP : VCY_WA_GROUP;
 #pragma unroll
-      for (int k0 = 0; k0 < WX; k0 += VCY_FAST_GROUP) {
-        float lu[VCY_FAST_GROUP], lv[VCY_FAST_GROUP];
-        f4 q[VCY_FAST_GROUP];
+      for (int k0 = 0; k0 < WX; k0 += kGroup) {
+        float lu[kGroup], lv[kGroup];
+        f4 q[kGroup];
 #pragma unroll
-        for (int j = 0; j < VCY_FAST_GROUP; ++j) {
+        for (int j = 0; j < kGroup; ++j) {
           const int k = k0 + j;
           const float pcz = t2 + (c0[16 + k] + h12z);
           const float qx = div_view<DIV>(fxv, pcz);
@@ -1042,7 +1058,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCY_WAVES))
           }
         }
 #pragma unroll
-        for (int j = 0; j < VCY_FAST_GROUP; ++j) {
+        for (int j = 0; j < kGroup; ++j) {
           const int k = k0 + j;
           const float mu = 1.0f - lu[j], mv = 1.0f - lv[j];
           const float dist =
@@ -1061,13 +1077,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCY_WAVES))
     };
     bool brick_moved;
     const bool sure = !GEN && __builtin_amdgcn_readfirstlane(tinfo[vi].sure) != 0;
-    if (kFastMax && sure && none_touched) {
-      brick_moved = carve_view_fast(std::true_type{});
-      none_touched = false;
+    // (Branch weights: the checked loops below are the rare ones in the kernels that have a select-free loop;
+    // the register allocator then spills there, if anywhere, and not in the loops that do the work.)
+    constexpr bool kHasFast = kFastMax || kFastWa;
+    const bool fast_first = kFastMax && sure && none_touched;
+    const bool fast_next = (kFastMax && sure && all_touched) || (kFastWa && sure && implied);
+    if (__builtin_expect_with_probability(fast_next, kHasFast, 0.9)) {
+      brick_moved = carve_view_fast(std::false_type{});
       VCY_PT(2);
       VCY_PT_COUNT(7);
-    } else if ((kFastMax && sure && all_touched) || (kFastWa && sure && implied)) {
-      brick_moved = carve_view_fast(std::false_type{});
+    } else if (__builtin_expect_with_probability(fast_first, kHasFast, 0.99)) {
+      brick_moved = carve_view_fast(std::true_type{});
       VCY_PT(2);
       VCY_PT_COUNT(7);
     } else if (sure) {
@@ -1080,6 +1100,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCY_WAVES))
       VCY_PT_COUNT(9);
     }
     if (brick_moved) VCY_PT_COUNT(11);
+    none_touched = false;  // (a checked view may have touched only some voxels)
     refresh_all_touched();
 
     // state moved: some of the remaining views may have become droppable (min(sdf) only grows)

@@ -100,6 +100,13 @@ __device__ const Share kShare[12] = {
     {1, {{-1, 0, 0}, {0, 0, 0}, {0, 0, 0}}, {10, 0, 0}},      // e11
 };
 
+// The nine distinct neighbour cells kShare refers to, and kShare[e].d[k] as an index into them.
+constexpr int kNbrCount = 9;
+__device__ const int8_t kNbr[kNbrCount][3] = {{0, -1, -1}, {0, 0, -1}, {0, -1, 0}, {1, 0, -1}, {0, 1, -1},
+                                              {-1, 0, -1}, {-1, 0, 0}, {-1, -1, 0}, {1, -1, 0}};
+__device__ const int8_t kShareNbr[12][3] = {{0, 1, 2}, {1, 3, 0}, {1, 4, 0}, {5, 1, 6}, {2, 0, 0}, {0, 0, 0},
+                                            {0, 0, 0}, {6, 0, 0}, {7, 2, 6}, {2, 8, 0}, {0, 0, 0}, {6, 0, 0}};
+
 // Cell (x, y, z) is named by its max corner; bit b of word w of a row is x = 64*w + b.
 // Cell rows: layer li = 0 is the ghost layer (z = zc0-1), li = l+1 the slab's own layer l;
 // word index of (li, cy = y-1, w):  li == 0 ? cy*Wr + w : G + ((li-1)*Y + cy)*Wr + w,
@@ -140,7 +147,10 @@ constexpr int kWordsPerBlock = 256;
 // ---- pass 0: bit planes ----------------------------------------------------------------------
 // One wave turns kBitsWordsPerWave consecutive 64-voxel words into plane words; all loads of a
 // wave are issued before the first ballot so that a wave keeps ~3 KB in flight.
-constexpr int kBitsWordsPerWave = 8;
+#ifndef VCY_BITS_WORDS
+#define VCY_BITS_WORDS 8
+#endif
+constexpr int kBitsWordsPerWave = VCY_BITS_WORDS;
 
 // TC_FROM_OK: the state has only ever been written by the grid fill and the carve kernels, where
 // update_num == 0 implies sdf == lowest(); then OK(corner 6) already implies TC(corner 6) and the TC
@@ -610,20 +620,75 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(McParams p, const McTables
     const int y = cy + 1, z = p.zc0 + li - 1;
     const int64_t slice = (int64_t)p.nx * p.ny;
     const int vin = (int)(inf >> 20);  // first vertex of this cell inside the block
+    const int cut = cut_edges(code);
 
-    // vertices of the edges this cell owns
+    // ---- gather phase: everything this cell reads from memory, requested before anything is used ----
+    // (a) its 8 corner values and the 6 axis coordinates
+    float cval[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      cval[c] = p.sdf[(int64_t)(z + kCornerOff[c][2] - p.zs0) * slice + (int64_t)(y + kCornerOff[c][1]) * p.nx +
+                      (x + kCornerOff[c][0])];
+    const float ax2[2] = {p.px[x - 1], p.px[x]}, ay2[2] = {p.py[y - 1], p.py[y]}, az2[2] = {p.pz[z - 1], p.pz[z]};
+    // (b) rank tables of this case: prec[code][e] for the 12 edges
+    uint16_t prec[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) prec[e] = T->prec[code][e];
+    // (c) the neighbour cells that own the cut edges this cell does not: which of the nine exist and are
+    //     active, their number in the cell list, their info word and their block's vertex offset.  Loads of
+    //     neighbours that are not needed go to element 0 instead of being branched around, so that the three
+    //     dependent rounds (ACT word -> list offsets -> info) are each issued for all nine at once.
+    const int foreign = cut & ~owned;
+    int need = 0;
+#pragma unroll
+    for (int e = 0; e < 12; ++e)
+      if (foreign & (1 << e))
+#pragma unroll
+        for (int k = 0; k < kShare[e].n; ++k) need |= 1 << kShareNbr[e][k];
+    int64_t ocw[kNbrCount];
+    int obit[kNbrCount];
+    u64 aw[kNbrCount];
+#pragma unroll
+    for (int q = 0; q < kNbrCount; ++q) {
+      const int nl = li + kNbr[q][2], ncy = cy + kNbr[q][1], ox = x + kNbr[q][0];
+      const bool there = ((need >> q) & 1) && nl >= 0 && ncy >= 0 && ncy < p.Y && ox >= 1 && ox < p.nx;
+      ocw[q] = there ? word_index(p, nl, ncy, ox >> 6) : 0;
+      obit[q] = there ? (ox & 63) : -1;
+      aw[q] = act[ocw[q]];
+    }
+    uint32_t wco[kNbrCount];
+    u64 bco[kNbrCount];
+    int nactive = 0;  // bit q: neighbour q is an active cell
+#pragma unroll
+    for (int q = 0; q < kNbrCount; ++q) {
+      const bool on = obit[q] >= 0 && ((aw[q] >> obit[q]) & 1ull);
+      nactive |= on ? (1 << q) : 0;
+      const int64_t w = on ? ocw[q] : 0;
+      wco[q] = word_cell_off[w];
+      bco[q] = block_cell_offs[w >> 8];
+    }
+    uint32_t oinf[kNbrCount];
+    u64 oboff[kNbrCount];
+#pragma unroll
+    for (int q = 0; q < kNbrCount; ++q) {
+      // the owner cell's number in the list, without a slot -> index array
+      const int64_t oi = ((nactive >> q) & 1)
+                             ? (int64_t)bco[q] + wco[q] + __popcll(aw[q] & ((1ull << obit[q]) - 1ull))
+                             : 0;
+      oinf[q] = info[oi];
+      oboff[q] = block_offs[oi >> 8];
+    }
+
+    // ---- vertices of the edges this cell owns ----------------------------------------------------
+#pragma unroll
     for (int e = 0; e < 12; ++e) {
       if (!(owned & (1 << e))) continue;
       const int ca = kEdgeA[e], cb = kEdgeB[e];
-      const int ax = x + kCornerOff[ca][0], ay = y + kCornerOff[ca][1], az = z + kCornerOff[ca][2];
-      const int bx = x + kCornerOff[cb][0], by = y + kCornerOff[cb][1], bz = z + kCornerOff[cb][2];
-      const float pa[3] = {p.px[ax], p.py[ay], p.pz[az]};
-      const float pb[3] = {p.px[bx], p.py[by], p.pz[bz]};
-      const float va = p.sdf[(int64_t)(az - p.zs0) * slice + (int64_t)ay * p.nx + ax];
-      const float vb_ = p.sdf[(int64_t)(bz - p.zs0) * slice + (int64_t)by * p.nx + bx];
+      const float pa[3] = {ax2[kCornerOff[ca][0] + 1], ay2[kCornerOff[ca][1] + 1], az2[kCornerOff[ca][2] + 1]};
+      const float pb[3] = {ax2[kCornerOff[cb][0] + 1], ay2[kCornerOff[cb][1] + 1], az2[kCornerOff[cb][2] + 1]};
       float out[3];
-      vertex_interp(p.iso, pa, pb, va, vb_, p.linear != 0, out);
-      const int r = vin + __popc(owned & T->prec[code][e]);
+      vertex_interp(p.iso, pa, pb, cval[ca], cval[cb], p.linear != 0, out);
+      const int r = vin + __popc(owned & prec[e]);
       const int ka = kKeyA[e], kb = kKeyB[e];
       const long long k0 = (int64_t)(z + kCornerOff[ka][2]) * slice + (int64_t)(y + kCornerOff[ka][1]) * p.nx +
                            (x + kCornerOff[ka][0]);
@@ -645,31 +710,40 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(McParams p, const McTables
       }
     }
 
-    // triangles, marching_cubes.cc:199-218 (ghost cells have ntri == 0)
-    for (int t = 0; t < ntri; ++t) {
-      for (int j = 0; j < 3; ++j) {
-        const int e = T->tri[code][3 * t + (2 - j)];
-        int64_t vid = -1;
+    // ---- the vertex of every cut edge: this cell's, or the first active sharer's (scan order) -------
+    int evid[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+      int vid = -1;
+      if (cut & (1 << e)) {
         if (owned & (1 << e)) {
-          vid = vb + vin + __popc(owned & T->prec[code][e]);
+          vid = (int)(vb + vin + __popc(owned & prec[e]));
         } else {
+          bool found = false;
+#pragma unroll
           for (int k = 0; k < kShare[e].n; ++k) {
-            const int dx = kShare[e].d[k][0], dy = kShare[e].d[k][1], dl = kShare[e].d[k][2];
-            const int nl = li + dl, ncy = cy + dy, ox = x + dx;
-            if (nl < 0 || ncy < 0 || ncy >= p.Y || ox < 1 || ox >= p.nx) continue;
-            const int64_t ocw = word_index(p, nl, ncy, ox >> 6);
-            const u64 aw = act[ocw];
-            if ((aw >> (ox & 63)) & 1ull) {
-              // the owner cell's number in the list, without a slot -> index array
-              const int64_t oi = (int64_t)block_cell_offs[ocw >> 8] + word_cell_off[ocw] +
-                                 __popcll(aw & ((1ull << (ox & 63)) - 1ull));
-              vid = vertex_id_of(T, info, block_offs, oi, kShare[e].e[k]);
-              break;
+            const int q = kShareNbr[e][k];
+            if (!found && ((nactive >> q) & 1)) {
+              found = true;
+              const uint32_t oi_inf = oinf[q];
+              const int o_owned = oi_inf & 0xFFF, o_code = (oi_inf >> 12) & 0xFF, o_in_block = oi_inf >> 20;
+              vid = (int)((int64_t)(oboff[q] >> 32) + o_in_block + __popc(o_owned & T->prec[o_code][kShare[e].e[k]]));
             }
           }
         }
-        if (staged) sf[3 * (tri_off + t) + j] = (int)vid;
-        else faces[3 * (fb + tri_off + t) + j] = (int)vid;
+      }
+      evid[e] = vid;
+    }
+
+    // ---- triangles, marching_cubes.cc:199-218 (ghost cells have ntri == 0) -------------------------
+    for (int t = 0; t < ntri; ++t) {
+      for (int j = 0; j < 3; ++j) {
+        const int e = T->tri[code][3 * t + (2 - j)];
+        int vid = -1;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) vid = (e == q) ? evid[q] : vid;
+        if (staged) sf[3 * (tri_off + t) + j] = vid;
+        else faces[3 * (fb + tri_off + t) + j] = vid;
       }
     }
   }

@@ -5,6 +5,7 @@
 
 #include "vacancy/camera.h"
 #include "vacancy/image.h"
+#include "vacancy/voxel_carver.h"
 
 int main(int argc, char* argv[]) {
   const std::string dir = argc > 1 ? argv[1] : ".";
@@ -28,6 +29,54 @@ int main(int argc, char* argv[]) {
     std::printf(" %.9g", w2c.translation()[i]);
   }
   std::printf("\n");
+  // VoxelGrid::Init on the bunny bounding box (examples.cc:91-99) at resolution 10: dims and an FNV-1a-64
+  // hash of the voxel centres in id order (res10_pos)
+  {
+    Eigen::Vector3f bb_min(-250.000000f, -344.586151f, -129.982697f), bb_max(250.000000f, 150.542343f, 257.329224f);
+    for (int i = 0; i < 3; ++i) {
+      bb_min[i] -= 20.0f;
+      bb_max[i] += 20.0f;
+    }
+    vacancy::VoxelGrid grid;
+    if (grid.initialized() || !grid.Init(bb_max, bb_min, 10.0f) || !grid.initialized()) return 2;
+    const Eigen::Vector3i n = grid.voxel_num();
+    unsigned long long h = 1469598103934665603ull;
+    bool ok = true;
+    int id = 0;
+    for (int z = 0; z < n[2]; ++z)
+      for (int y = 0; y < n[1]; ++y)
+        for (int x = 0; x < n[0]; ++x, ++id) {
+          const vacancy::Voxel& v = grid.get(x, y, z);
+          ok = ok && v.id == id && v.index[0] == x && v.index[1] == y && v.index[2] == z && v.update_num == 0 &&
+               v.sdf == vacancy::InvalidSdf::kVal && !v.on_surface && !v.outside;
+          for (int k = 0; k < 3; ++k) {
+            const float f = v.pos[k];
+            const unsigned char* b = reinterpret_cast<const unsigned char*>(&f);
+            for (int q = 0; q < 4; ++q) h = (h ^ b[q]) * 1099511628211ull;
+          }
+        }
+    grid.get_ptr(1, 2, 3)->on_surface = true;
+    grid.ResetOnSurface();
+    ok = ok && !grid.get(1, 2, 3).on_surface && grid.resolution() == 10.0f;
+    vacancy::VoxelGrid bad;
+    ok = ok && !bad.Init(bb_min, bb_max, 10.0f) && !bad.Init(bb_max, bb_min, 0.0f);  // inverted box, zero resolution
+    std::printf("GRID %d %d %d %016llx %d\n", n[0], n[1], n[2], h, ok ? 1 : 0);
+  }
+  // the reference's look-at forms (common.h:51-75) against the Affine one
+  {
+    const Eigen::Vector3d pos(0.3, -1.2, 2.5), target(0.1, 0.2, -0.4), up(0.0, -1.0, 0.0);
+    const Eigen::Affine3d pose = vacancy::c2w(pos, target, up);
+    Eigen::Matrix3d R;
+    vacancy::c2w(pos, target, up, &R);
+    Eigen::Matrix4d T;
+    vacancy::c2w(pos, target, up, &T);
+    bool same = T(3, 0) == 0.0 && T(3, 1) == 0.0 && T(3, 2) == 0.0 && T(3, 3) == 1.0;
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) same = same && R(i, j) == pose.linear()(i, j) && T(i, j) == R(i, j);
+      same = same && T(i, 3) == pos[i];
+    }
+    std::printf("C2W %d\n", same ? 1 : 0);
+  }
   vacancy::PinholeCamera fov(1280, 720, 60.0f);
   std::printf("FOCAL %.9g %.9g %.9g\n", fov.focal_length()[0], fov.principal_point()[0], fov.principal_point()[1]);
   return 0;
