@@ -175,17 +175,23 @@ def load_counters(key):
 
 def valu_issue_cycles(ctr):
     """SIMD issue cycles of the VALU work of one launch: dynamic wave-instruction counts by class
-    (SQ_INSTS_VALU_*) x cycles per wave64 instruction on a SIMD-32 (MI355X_MICROARCH.md: 2 cycles
-    full rate; transcendentals quarter rate = 8; 64-bit integer and packed-fp32 pairs two passes = 4).
-    Instructions outside the measured classes count as full rate."""
+    (SQ_INSTS_VALU_*) x the cycles per wave64 instruction MEASURED on this GPU (profiles/r02/valu_ubench.txt):
+    fp32 add / mul / fma 1.95; transcendentals 7.55; conversions, 64-bit integer and every VALU instruction
+    outside the counted classes (compares, selects, min / max, floor, DPP, readlane ...) 3.5; 32-bit integer
+    2.7 (adds and logic 1.9, shifts and multiplies 3.5).  An SGPR source makes a full-rate instruction half
+    rate when it follows another half-rate one; the counters cannot see that, so this is a lower bound of the
+    issue time (the static per-opcode count is in profiles/r02/isa_histogram_carve_fused.txt)."""
     if not ctr or "SQ_INSTS_VALU" not in ctr:
         return None
     total = ctr["SQ_INSTS_VALU"]
+    fp = sum(ctr.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"))
     trans = ctr.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
-    int64 = ctr.get("SQ_INSTS_VALU_INT64", 0.0)
-    packed = ctr.get("packed_f32_fraction", 0.0) * total   # static share of v_pk_*_f32 in the run loop
-    rest = max(0.0, total - trans - int64 - packed)
-    return 2.0 * rest + 8.0 * trans + 4.0 * int64 + 4.0 * packed
+    half = ctr.get("SQ_INSTS_VALU_CVT", 0.0) + ctr.get("SQ_INSTS_VALU_INT64", 0.0)
+    int32 = ctr.get("SQ_INSTS_VALU_INT32", 0.0)
+    if fp <= 0.0:  # class counters not collected: everything but the transcendentals at full rate
+        return 1.95 * (total - trans) + 7.55 * trans
+    other = max(0.0, total - fp - trans - half - int32)
+    return 1.95 * fp + 7.55 * trans + 3.5 * (half + other) + 2.7 * int32
 
 
 def plumbing_check(args, rank, world, dist, backend):
@@ -376,6 +382,12 @@ def main():
     if vcyc:
         roofline["bound_actual"] = "valu"
         roofline["valu_issue_frac"] = round(vcyc / (N_SIMD * CLOCK_HZ * avg_launch_ms * 1e-3), 4)
+        # the same against the shader clock the profiled launch really ran at (GRBM_GUI_ACTIVE counts the busy
+        # cycles of each of the 8 XCDs over the launch; the 2.4 GHz above is the boost clock)
+        if ctr.get("GRBM_GUI_ACTIVE") and ctr.get("trace_avg_ns"):
+            clk = ctr["GRBM_GUI_ACTIVE"] / 8.0 / (ctr["trace_avg_ns"] * 1e-9)
+            roofline["shader_clock_ghz_profiled"] = round(clk / 1e9, 3)
+            roofline["valu_issue_frac_at_profiled_clock"] = round(vcyc / (N_SIMD * clk * avg_launch_ms * 1e-3), 4)
         roofline["valu_wave_insts_per_launch"] = ctr["SQ_INSTS_VALU"]
         roofline["valu_insts_per_voxel_view"] = round(ctr["SQ_INSTS_VALU"] * 64.0 / (slab_vox * views_per_launch), 3)
         roofline["counters_source"] = ctr.get("source")

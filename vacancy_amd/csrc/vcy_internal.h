@@ -113,6 +113,7 @@ struct vcy_ctx {
   size_t mc_cells_bytes = 0;
   void* d_mc_out = nullptr;           // device staging of the extracted mesh
   size_t mc_out_bytes = 0;
+  int64_t mc_hint_cells = 0, mc_hint_verts = 0, mc_hint_faces = 0;  // sizes of the last extraction (extract_iso)
   float last_extract_device_ms = 0.0f;
   float last_extract_wall_ms = 0.0f;  // call entry -> mesh arrays in host memory
   hipEvent_t ev_mc_begin = nullptr, ev_mc_end = nullptr;  // the extraction's own timer
