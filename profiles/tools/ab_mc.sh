@@ -20,10 +20,12 @@ assert c.Init()
 d = [c.upload_sdf(sdf0)] * nv
 assert c.CarveBatchDevice(vc.VoxelCarver.prepare_batch(views, d))
 best = (1e9, 1e9)
-for it in range(5):
+every = []
+for it in range(6):
     m = c.ExtractIsoSurface(0.0, True)
     best = min(best, (m["device_ms"], m["wall_ms"]))
+    every.append("%.3f/%.2f" % (m["device_ms"], m["wall_ms"]))
 h = hashlib.sha1(m["vertices"].tobytes() + m["faces"].tobytes() + m["keys"].tobytes()).hexdigest()[:12]
-print("%-10s mc device %.3f ms  wall %.3f ms  verts %d faces %d  mesh %s" % (sys.argv[1], best[0], best[1], len(m["vertices"]), len(m["faces"]), h))
+print("%-10s mc device %.3f ms  wall %.3f ms  verts %d faces %d  mesh %s  (every call, device/wall: %s)" % (sys.argv[1], best[0], best[1], len(m["vertices"]), len(m["faces"]), h, " ".join(every)))
 PY
 done

@@ -1,0 +1,45 @@
+#!/bin/bash
+# Runs ON the GPU box (through gpurun): everything profiles/rNN/ is built from.
+#   profiles/tools/run_round_profiles.sh <round dir name, e.g. r02>
+# Leaves under gpurun_out/<round>/: the rocprofv3 kernel trace + PMC passes of the three carve workloads
+# (default, view dropping off, TSDF) and of marching cubes, their summaries, the phase breakdown of the fused
+# kernel, the 2-rank run of bench.py on one device, and the bench lines themselves.
+set -u
+RND=$1
+R=$(pwd -P)
+O=$R/gpurun_out/$RND
+mkdir -p "$O"
+export TMPDIR=/tmp
+CTR=$O/counters.json
+rm -f "$CTR"
+# carve workloads: trace + counters (no marching cubes inside these runs)
+bash profiles/tools/profile_gpu.sh gpurun_out/$RND/default --no-mc
+python profiles/tools/summarize_pmc.py "$O/default" "$O/pmc_1024x32_default.json" --key default_1024_32_b1_c1 --counters "$CTR"
+bash profiles/tools/profile_gpu.sh gpurun_out/$RND/cull0 --no-mc --cull 0
+python profiles/tools/summarize_pmc.py "$O/cull0" "$O/pmc_1024x32_cull0.json" --key default_1024_32_b1_c0 --counters "$CTR"
+bash profiles/tools/profile_gpu.sh gpurun_out/$RND/tsdf --no-mc --mode tsdf
+python profiles/tools/summarize_pmc.py "$O/tsdf" "$O/pmc_1024x32_tsdf.json" --key tsdf_1024_32_b1_c1 --counters "$CTR"
+# marching cubes: trace with the extraction inside, HBM bytes of its kernels
+( cd /tmp && rocprofv3 --kernel-trace --stats -d "$O/mc" -o trace --output-format csv -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-variants ) > "$O/mc_trace.log" 2>&1
+( cd /tmp && rocprofv3 --pmc FETCH_SIZE -d "$O/mc" -o fetch --output-format csv -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-variants ) > "$O/mc_fetch.log" 2>&1
+( cd /tmp && rocprofv3 --pmc WRITE_SIZE -d "$O/mc" -o write --output-format csv -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-variants ) > "$O/mc_write.log" 2>&1
+python profiles/tools/summarize_pmc.py "$O/mc" "$O/pmc_1024_marching_cubes.json"
+profiles/tools/ab_mc.sh prod > "$O/mc_unprofiled.txt" 2>&1
+# phase breakdown of the fused kernel (development build with s_memtime marks)
+if [ -f build/variants/phase/libvacancy_hip.so ]; then
+  VCY_HIP_LIB=build/variants/phase/libvacancy_hip.so python profiles/tools/phase_timing.py > "$O/phase_timing.log" 2>&1
+  cp gpurun_out/phase_timing.json "$O/phase_timing.json"
+fi
+# the multi-rank path of bench.py on this one device: 2 ranks, 2 slabs each, halo exchange over gloo (RCCL refuses
+# two ranks on one device; --allow-gloo is the documented escape for exactly this check)
+python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-variants --allow-gloo > "$O/bench_2ranks_one_device_gloo.json" 2> "$O/bench_2ranks_one_device_gloo.err"
+echo "2 ranks (gloo) rc=$?" > "$O/status.txt"
+python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-variants > "$O/bench_2ranks_one_device_rccl.json" 2> "$O/bench_2ranks_one_device_rccl.err"
+echo "2 ranks (rccl on one device, expected to be refused) rc=$?" >> "$O/status.txt"
+# the bench lines: with the counters of this session next to them
+mkdir -p profiles && cp "$CTR" profiles/counters.json
+python bench.py > "$O/bench_1024x32_default.json" 2> "$O/bench_default.err"; echo "bench default rc=$?" >> "$O/status.txt"
+python bench.py --config 1 --no-variants > "$O/bench_512x16_tsdf_config1.json" 2> "$O/bench_config1.err"; echo "bench config1 rc=$?" >> "$O/status.txt"
+python bench.py --config 4 --steps 5 --warmup 1 --no-variants --no-cpu-baseline --no-mc > "$O/bench_2048x64_config4.json" 2> "$O/bench_config4.err"; echo "bench config4 rc=$?" >> "$O/status.txt"
+cat "$O/status.txt"
+ls "$O"

@@ -174,6 +174,47 @@ def test_batch_equals_sequential():
             a.free_device(d)
 
 
+@pytest.mark.parametrize("kw", [dict(voxel_update=1, use_truncation=True), dict(voxel_update=1),
+                                dict(voxel_update=1, use_truncation=True, truncation_band=0.02), dict()])
+def test_select_free_loops_at_benchmark_footprints(kw):
+    """The loops the benchmark runs in -- raw 16 x 16 tiles, first-touch stores, the update chains, the
+    truncation test compiled out where the tile's lower bound allows it, brick-wide weights of the average
+    while all counts of a brick agree -- on a scene with the benchmark's sub-pixel voxel footprints
+    (160^3 in 200 x 150 images), in two launches (the second starts from a carved, non-fresh state) and
+    after an upload (update_num no longer implied by sdf), with view dropping on and off and with the quad
+    tile instead of the raw one: state bit-identical to the oracle every time."""
+    n, nv, w, h = 160, 16, 200, 150
+    uo = UpdateOption(**kw)
+    opt = synth.sphere_option(n, uo)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    sdfs = [vc.make_sdf(m, use_truncation=bool(uo.use_truncation), band=uo.truncation_band) for m in masks]
+    sdfs[5] = np.ascontiguousarray(np.round(sdfs[5] * 8) / 8).astype(np.float32)  # plateaus: ties with the state
+    orc = O.OracleGrid(opt)
+    half = []
+    for i in range(nv):
+        orc.carve(views[i], sdfs[i])
+        if i == nv // 2 - 1:
+            half = orc.download()
+    os_, ou = orc.download()
+    for cull, tile, reupload in ((1, 0, False), (0, 0, False), (1, 2, False), (1, 0, True)):
+        dev = vc.VoxelCarver(opt)
+        assert dev.Init()
+        dev.set_param("cull", cull)
+        dev.set_param("tile", tile)
+        devs = [dev.upload_sdf(s_) for s_ in sdfs]
+        assert dev.CarveBatchDevice(views[:nv // 2], devs[:nv // 2]), vc.last_error()
+        if reupload:
+            hs, hu = dev.download()
+            assert np.array_equal(hu, half[1]) and np.array_equal(hs.view(np.uint32), half[0].view(np.uint32))
+            dev.upload(hs, hu)
+        assert dev.CarveBatchDevice(views[nv // 2:], devs[nv // 2:]), vc.last_error()
+        ds, du = dev.download()
+        for d in devs:
+            dev.free_device(d)
+        assert np.array_equal(du, ou), (kw, cull, tile, reupload, int((du != ou).sum()))
+        assert np.array_equal(ds.view(np.uint32), os_.view(np.uint32)), (kw, cull, tile, reupload)
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(use_truncation=True, truncation_band=0.2),
                                 dict(update_outside=1), dict(voxel_update=1, use_truncation=True)])
 def test_view_dropping_is_exact(kw):

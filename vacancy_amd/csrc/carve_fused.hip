@@ -8,14 +8,13 @@
 // what changed.  The four wave bricks of a workgroup are adjacent in x, so together they read
 // 128-byte row segments.
 //
-// Per view the wave stages the image footprint of its brick in a wave-private LDS tile of *quads*
-//   tile[j][i] = { s(x,y), s(x1,y), s(x,y1), s(x1,y1) },  x1 = min(x+1, roi_max.x) ...
-// i.e. the four bilinear taps of pixel (x,y) with the reference's ROI clamps already applied
-// (voxel_carver.cc:51-66), so a sample is ONE ds_read_b128 and no clamp arithmetic.  No
-// workgroup barrier anywhere; with the small tile the global loads of the next live view's quads
-// fly while the current view is computed.  A voxel whose projection falls outside the staged
-// tile (brick near the camera plane, footprint larger than the tile, outside the ROI) takes the
-// generic global-memory path of carve_common.h, so SAMPLING never depends on the footprint
+// Per view the wave keeps the image footprint of its brick in a wave-private LDS tile: 16 x 16 raw pixels
+// (kTileRaw: global memory -> LDS directly, double buffered, a sample = two ds_read2_b32), or for footprints
+// beyond 15 x 15 pixels a tile of *quads* { s(x,y), s(x1,y), s(x,y1), s(x1,y1) } filled in place (kTileBig).
+// Either way the reference's ROI clamps of x + 1 and y + 1 (voxel_carver.cc:51-66) are applied when the
+// tile is filled, never per sample.  No workgroup barrier anywhere.  A voxel whose projection falls
+// outside the staged tile (brick near the camera plane, footprint larger than the tile, outside the ROI)
+// takes the generic global-memory path of carve_common.h, so SAMPLING never depends on the footprint
 // estimate.  DROPPING a view for a brick does (see the kernel): it is only done when the
 // footprint rectangle is provably a superset of every sample, with an explicit error margin.
 //
@@ -42,7 +41,6 @@ namespace {
 constexpr int BX = 32, BY = 8, BZ = 8;  // voxels per workgroup: four 8x8x8 wave bricks along x
 constexpr int WX = 8;                    // wave brick is WX x BY x BZ, lane = (y & 7) | (z << 3), WX voxels per lane
 constexpr int kMaxFusedViews = 64;         // one prologue lane per view
-constexpr int kTileSmall = 128;          // quads per wave tile (2 KB): <= 2 per lane, prefetched in registers
 // Raw-pixel tile (the default for footprints up to 15 x 15 quads): 16 x 16 pixels of the image, pitch 16, 1 KB.
 // The pixels go from global memory straight into LDS (global_load_lds_dword: lane L of the r-th load
 // writes dword 64 r + L, i.e. pixel (L & 15, 4 r + (L >> 4))), two tiles per wave so that the next live
@@ -52,9 +50,6 @@ constexpr int kTileSmall = 128;          // quads per wave tile (2 KB): <= 2 per
 // reference's clamp of x + 1 and y + 1 (voxel_carver.cc:51-66).
 constexpr int kTileRaw = 16;
 constexpr int kRawBuffers = 2;
-#ifndef VCY_SMALL_TILE
-#define VCY_SMALL_TILE kTileRaw          // development builds: kTileSmall = the register-staged quad tile
-#endif
 template <int TQ>
 constexpr int tile_f4_per_wave() { return TQ == kTileRaw ? kRawBuffers * 64 : TQ; }  // LDS of one wave, in float4
 constexpr int kTileBig = 512;            // 8 KB per wave: footprints up to ~1.4 px per voxel, filled in place
@@ -64,12 +59,6 @@ constexpr int kWmaxPlanes = 2;           // window sizes 4 and 8
 // tuning knobs of the select-free view loop (development builds override them, profiles/tools/build_variant.sh)
 #ifndef VCY_FAST_GROUP
 #define VCY_FAST_GROUP 4   // voxels whose LDS reads are in flight together
-#endif
-#ifndef VCY_DENORM_ADDR
-#define VCY_DENORM_ADDR 1  // LDS addresses of the select-free loop as denormal sums (see carve_view_fast)
-#endif
-#ifndef VCY_UNIFORM_VGPR
-#define VCY_UNIFORM_VGPR 0  // 1: fx, t[2]; 2: also t[0], t[1], cx, cy of the select-free loop in VGPRs
 #endif
 // Waves per SIMD the kernels are compiled for (register budget 512 / waves).  The kernels whose work is done by
 // the select-free loop (raw tiles, pinhole + bilinear, no update_num limit in reach) need 57-59 VGPRs there; what
@@ -82,9 +71,7 @@ constexpr int kWmaxPlanes = 2;           // window sizes 4 and 8
 #ifndef VCY_WAVES_CHECKED
 #define VCY_WAVES_CHECKED 5
 #endif
-#ifndef VCY_WA_GROUP
-#define VCY_WA_GROUP VCY_FAST_GROUP  // voxels in flight together in the weighted-average kernels
-#endif
+
 
 // Development build only (-DVCY_PHASE_TIMING, profiles/tools/phase_timing.py): s_memtime ticks of every wave,
 // accumulated per phase of the fused kernel.  Slots 0-6: prologue + state load, tile staging, select-free
@@ -123,6 +110,10 @@ struct FusedView {
   // edges): the prologue bounds a footprint with a handful of loads instead of scanning it.
   const float* wmax;
   int wmax_plane;
+  // Planes 2 and 3, when has_lower != 0: the same window maxima of -g, i.e. window MINIMA of the image
+  // negated.  Only built for the truncating weighted average, where a tile whose every tap is provably
+  // >= -1 needs no `dist < -1` test per sample (TileInfo::sure bit 1).
+  int has_lower;
   // The planes are only filled inside wrect = {x0, y0, x1, y1} (x0, x1 multiples of 4), the image-space
   // bounding box of this context's slab plus a border wider than anything a footprint lookup reaches;
   // a z-slab of a sharded grid often sees a narrow band of the image.
@@ -143,7 +134,8 @@ struct TileInfo {
   int th;
   float inv_tw;                  // 1 / tw: q / tw == (int)((q + 0.5f) * inv_tw) for q < 2^12
   float ub;                      // upper bound of any sample taken from this tile (+inf: unknown)
-  int sure;                      // 1: every voxel of the brick provably samples inside this tile
+  int sure;                      // bit 0: every voxel of the brick provably samples inside this tile;
+                                 // bit 1: and every sample is provably >= -1 (no truncation skip possible)
 };
 
 // Correctly rounded n/d for normal operands away from the exponent limits: v_rcp_f32 plus the
@@ -323,40 +315,6 @@ __device__ __forceinline__ bool apply_sample(bool ok, float dist, float wgt, flo
 // 0.5 / d of an integer, far more than the float rounding of the product.
 __device__ __forceinline__ int div_small(int q, float inv) { return (int)(((float)q + 0.5f) * inv); }
 
-struct QuadRegs {
-  float4 q0, q1;
-};
-
-// Issues the global loads of this lane's (up to two) quads of view vi's tile.  Lanes without a quad
-// keep whatever the registers held: tile entries >= nq are never read.  Offsets are 32-bit (images
-// are at most 8192 x 8192, fused_eligible) on a wave-uniform base, 24-bit multiplies (full rate).
-__device__ __forceinline__ void tile_prefetch(const ViewParams& v, const TileInfo& ti, int lane,
-                                              QuadRegs* r) {
-  const int nq = __builtin_amdgcn_readfirstlane(ti.nq);
-  if (nq == 0) return;
-  const int tw = __builtin_amdgcn_readfirstlane(ti.tw);
-  const int tx0 = __builtin_amdgcn_readfirstlane(ti.tx0);
-  const int ty0 = __builtin_amdgcn_readfirstlane(ti.ty0);
-  const float inv_tw = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ti.inv_tw)));
-  gfloat_ptr img = (gfloat_ptr)v.sdf;
-  const unsigned width = (unsigned)v.width;
-  if (lane < nq) {
-    const int j = div_small(lane, inv_tw), i = lane - __mul24(j, tw);
-    const unsigned xx = tx0 + i, yy = ty0 + j;
-    const unsigned xx1 = min((int)xx + 1, v.roi_max_xi), yy1 = min((int)yy + 1, v.roi_max_yi);
-    const unsigned r0 = __umul24(width, yy), r1 = __umul24(width, yy1);
-    r->q0 = make_float4(img[r0 + xx], img[r0 + xx1], img[r1 + xx], img[r1 + xx1]);
-  }
-  if (nq > 64 && lane + 64 < nq) {
-    const int q = lane + 64;
-    const int j = div_small(q, inv_tw), i = q - __mul24(j, tw);
-    const unsigned xx = tx0 + i, yy = ty0 + j;
-    const unsigned xx1 = min((int)xx + 1, v.roi_max_xi), yy1 = min((int)yy + 1, v.roi_max_yi);
-    const unsigned r0 = __umul24(width, yy), r1 = __umul24(width, yy1);
-    r->q1 = make_float4(img[r0 + xx], img[r0 + xx1], img[r1 + xx], img[r1 + xx1]);
-  }
-}
-
 typedef float __attribute__((address_space(3))) lds_float;
 typedef uint32_t __attribute__((address_space(3))) lds_u32;
 
@@ -467,7 +425,8 @@ __device__ __forceinline__ void wmax_store4(float* __restrict__ row, int x0, int
 }
 
 // Plane 0: maxima of 4 x 4 windows of the image, non-finite pixels counted as +inf (a footprint
-// holding one gives no bound: 0 * inf = NaN samples).
+// holding one gives no bound: 0 * inf = NaN samples).  NEG: of the negated image, into plane 2.
+template <bool NEG>
 __global__ __launch_bounds__(256) void wmax_k4_kernel(const FusedView* __restrict__ views) {
   const FusedView& fv = views[blockIdx.y];
   const int w = fv.v.width, h = fv.v.height, wq = (fv.wrect[2] - fv.wrect[0]) >> 2;
@@ -483,31 +442,32 @@ __global__ __launch_bounds__(256) void wmax_k4_kernel(const FusedView* __restric
     wmax_load8(y + r < h ? img + (size_t)(y + r) * w : nullptr, x0, w, vec, a);
 #pragma unroll
     for (int j = 0; j < 8; ++j)  // NaN, +inf, -inf -> +inf; the -inf padding beyond the border stays
-      if (x0 + j < w && y + r < h) a[j] = (fabsf(a[j]) <= 3.402823466e+38f) ? a[j] : INFINITY;
+      if (x0 + j < w && y + r < h) a[j] = (fabsf(a[j]) <= 3.402823466e+38f) ? (NEG ? -a[j] : a[j]) : INFINITY;
     float p[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) p[j] = fmaxf(a[j], a[j + 1]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], fmaxf(p[j], p[j + 2]));
   }
-  wmax_store4(const_cast<float*>(fv.wmax) + (size_t)y * w, x0, w, vec, o);
+  wmax_store4(const_cast<float*>(fv.wmax) + (NEG ? 2 * (size_t)fv.wmax_plane : (size_t)0) + (size_t)y * w, x0, w, vec, o);
 }
 
 // Plane 1: maxima of 8 x 8 windows = the four 4 x 4 windows at offsets 0 / 4 of plane 0.
+template <bool NEG>
 __global__ __launch_bounds__(256) void wmax_k8_kernel(const FusedView* __restrict__ views) {
   const FusedView& fv = views[blockIdx.y];
   const int w = fv.v.width, h = fv.v.height, wq = (fv.wrect[2] - fv.wrect[0]) >> 2;
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (fv.wmax == nullptr || wq <= 0 || t >= wq * (fv.wrect[3] - fv.wrect[1])) return;
   const int yr = t / wq, y = fv.wrect[1] + yr, x0 = fv.wrect[0] + ((t - yr * wq) << 2);
-  const float* in = fv.wmax;
+  const float* in = fv.wmax + (NEG ? 2 * (size_t)fv.wmax_plane : (size_t)0);  // (planes are multiples of 4 floats or vec is off)
   const bool vec = (w & 3) == 0 && ((uintptr_t)in & 15) == 0;
   float a[8], b[8], o[4];
   wmax_load8(in + (size_t)y * w, x0, w, vec, a);
   wmax_load8(y + 4 < h ? in + (size_t)(y + 4) * w : nullptr, x0, w, vec, b);
 #pragma unroll
   for (int j = 0; j < 4; ++j) o[j] = fmaxf(fmaxf(a[j], a[j + 4]), fmaxf(b[j], b[j + 4]));
-  wmax_store4(const_cast<float*>(fv.wmax) + (size_t)fv.wmax_plane + (size_t)y * w, x0, w, vec, o);
+  wmax_store4(const_cast<float*>(in) + (size_t)fv.wmax_plane + (size_t)y * w, x0, w, vec, o);
 }
 
 // Prologue of the fused kernel, out of line so that its registers do not add to the main loop's:
@@ -521,7 +481,7 @@ template <bool SAMEF, int TQ, bool GEN>
 __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __restrict__ views, int nviews, int lane,
                                                             float xl, float xh, float yl, float yh, float zl_, float zh,
                                                             bool is_ortho, bool outside_max, bool want_bound,
-                                                            lds_u32* tinfo_lds) {
+                                                            bool want_lower, lds_u32* tinfo_lds) {
   float ub_lane = INFINITY;
   if (lane < nviews) {
     const int vi = lane;
@@ -651,23 +611,33 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
           float m = -INFINITY;
           int has_nan = 0;
           gfloat_ptr wm = (gfloat_ptr)fv.wmax;
+          // window maxima: k = 8 when both sides reach 8, else 4; nxw x nyw windows placed inside the rectangle
+          // (a side shorter than k gets one window that sticks out of it: a maximum over more pixels is still
+          // an upper bound, and the planes are filled well beyond any footprint, FusedView::wrect)
+          const int L = min(pw, ph) >= 8 ? 3 : 2;
+          const int k = 1 << L;
+          const int nxw = (pw + k - 1) >> L, nyw = (ph + k - 1) >> L;
+          // the largest window counts (up to 3) among the lanes that take the 3 x 3 path below: wave-uniform
+          const bool small = nxw <= 3 && nyw <= 3;
+          const int ux = __any(small && nxw >= 3) ? 3 : (__any(small && nxw >= 2) ? 2 : 1);
+          const int uy = __any(small && nyw >= 3) ? 3 : (__any(small && nyw >= 2) ? 2 : 1);
           if (wm != nullptr) {
-            // window maxima: k = 8 when both sides reach 8, else 4; nxw x nyw windows placed inside the rectangle
-            // (a side shorter than k gets one window that sticks out of it: a maximum over more pixels is still
-            // an upper bound, and the planes are filled well beyond any footprint, FusedView::wrect)
-            const int L = min(pw, ph) >= 8 ? 3 : 2;
-            const int k = 1 << L;
-            const int nxw = (pw + k - 1) >> L, nyw = (ph + k - 1) >> L;
             gfloat_ptr lvl = wm + (L == 3 ? (size_t)fv.wmax_plane : (size_t)0);
             if (nxw <= 3 && nyw <= 3) {
-              // the usual case (footprints up to 24 pixels wide): all nine lookups in flight together; window
-              // positions beyond nxw / nyw clamp onto the last one
+              // the usual case (footprints up to 24 pixels wide): as many lookups as the widest footprint among
+              // the wave's views needs (uniform counts ux x uy, typically 2 x 2; narrower ones repeat their last
+              // window), all requested before the first is used.  As a per-lane loop each load waited for the one
+              // before; nine unconditional ones cost the memory system twice what is needed (measured at
+              // 2048^3 x 64: 157 ms instead of 108).
               float t[9];
 #pragma unroll
               for (int bq = 0; bq < 3; ++bq) {
                 const unsigned ro = (unsigned)v.width * (unsigned)(ty0 + min(bq << L, max(ph - k, 0))) + (unsigned)tx0;
 #pragma unroll
-                for (int aq = 0; aq < 3; ++aq) t[3 * bq + aq] = lvl[ro + (unsigned)min(aq << L, max(pw - k, 0))];
+                for (int aq = 0; aq < 3; ++aq) {
+                  t[3 * bq + aq] = -INFINITY;
+                  if (aq < ux && bq < uy) t[3 * bq + aq] = lvl[ro + (unsigned)min(aq << L, max(pw - k, 0))];
+                }
               }
 #pragma unroll
               for (int q = 0; q < 9; ++q) m = fmaxf(m, t[q]);
@@ -694,6 +664,27 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
             m = fmaxf(m, v.max_sdf);
           }
           ti.ub = has_nan ? INFINITY : (__builtin_fmaf(fabsf(m), 0x1p-20f, m) + 1.0e-30f);
+          // Lower bound of the samples, by the mirrored argument: with every tap >= mn the sample is
+          // >= mn - 2^-22 |mn|.  If that is >= -1 no voxel of this tile is skipped by the truncation test
+          // (`dist < -1`, voxel_carver.cc:478) and the test is compiled out of the run over it (sure bit 1).
+          // Voxels outside the ROI are not an issue: a `sure` tile has none.
+          if (want_lower && ti.sure && wm != nullptr && fv.has_lower && nxw <= 3 && nyw <= 3) {
+            gfloat_ptr lvl = wm + 2 * (size_t)fv.wmax_plane + (L == 3 ? (size_t)fv.wmax_plane : (size_t)0);
+            float t[9], mneg = -INFINITY;  // max of -g = -(min of g)
+#pragma unroll
+            for (int bq = 0; bq < 3; ++bq) {
+              const unsigned ro = (unsigned)v.width * (unsigned)(ty0 + min(bq << L, max(ph - k, 0))) + (unsigned)tx0;
+#pragma unroll
+              for (int aq = 0; aq < 3; ++aq) {
+                t[3 * bq + aq] = -INFINITY;
+                if (aq < ux && bq < uy) t[3 * bq + aq] = lvl[ro + (unsigned)min(aq << L, max(pw - k, 0))];
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q) mneg = fmaxf(mneg, t[q]);
+            const float neg_lb = __builtin_fmaf(fabsf(mneg), 0x1p-20f, mneg);  // -(lower bound); +inf: none
+            if (neg_lb <= 1.0f) ti.sure |= 2;
+          }
         }
       }
     }
@@ -726,7 +717,6 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   // dynamic LDS: [4 waves][TQ] quads, then [4 waves][nviews] TileInfo (sized by the launch)
   extern __shared__ float4 fused_lds[];
   constexpr bool kRaw = TQ == kTileRaw;                  // raw-pixel tiles, loaded straight into LDS
-  constexpr bool kPrefetch = !kRaw && TQ <= 128;         // quad tile staged through registers (two quads per lane)
   constexpr int kTileF4 = tile_f4_per_wave<TQ>();
   // A view can be dropped for a whole wave brick when no voxel of the brick can change:
   //   - use_truncation and every sample is provably < -1 (voxel_carver.cc:478), or
@@ -789,7 +779,8 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     const int z_hi = min(zl0 + BZ - 1, g.nz_local - 1);
     ub_lane = brick_footprints<SAMEF, TQ, GEN>(views, nviews, lane, g.px[x_lo], g.px[x_hi], g.py[by * BY], g.py[y_hi],
                                                g.pz[g.z0 + zl0], g.pz[g.z0 + z_hi], mode.ortho != 0,
-                                               mode.outside == VCY_OUTSIDE_MAX, want_bound, (lds_u32*)tinfo);
+                                               mode.outside == VCY_OUTSIDE_MAX, want_bound,
+                                               want_bound && TRUNC && UPDATE == kUpdateWaUnitWeight, (lds_u32*)tinfo);
   }
   wave_lds_fence();
 #ifdef VCY_PHASE_TIMING
@@ -854,6 +845,31 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     for (int k = 1; k < WX; ++k) nmax = max(nmax, n[k]);
     none_touched = __all(nmax < (NT)1);
   }
+  // Weighted average: does every voxel of the brick carry the same update_num?  (Wave-uniform; true for a
+  // fresh slab, and it stays true while every processed view updates every voxel -- the views whose tile
+  // provably holds no sample below -1.)  Then the weights of the average, fn and 1 / (fn + 1), are the same
+  // for the whole brick and are formed once per view instead of once per sample (carve_view_fast<UNIFORM>);
+  // n[] is only brought up to date when the brick leaves this state, and at the write-back.
+  bool uniform_cnt = false;
+  float fnu = 0.0f;  // the common update_num (as a float, like n[])
+  if (UPDATE == kUpdateWaUnitWeight) {
+    if (fresh) {
+      uniform_cnt = true;
+    } else {
+      const float f0 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)n[0])));
+      bool same = true;
+#pragma unroll
+      for (int k = 0; k < WX; ++k) same = same && (float)n[k] == f0;
+      uniform_cnt = __all(same);
+      fnu = f0;
+    }
+  }
+  auto leave_uniform = [&]() {
+    if (!uniform_cnt) return;
+    uniform_cnt = false;
+#pragma unroll
+    for (int k = 0; k < WX; ++k) n[k] = (NT)fnu;
+  };
   // views that may still change something, as a wave-uniform bit mask
   auto live_views = [&]() -> unsigned long long {
     bool drop = false;
@@ -876,9 +892,6 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
 
   unsigned long long live = live_views();
   int vi = live ? (__ffsll((long long)live) - 1) : nviews;
-  QuadRegs pre;
-  pre.q0 = pre.q1 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (kPrefetch && vi < nviews) tile_prefetch(views[vi].v, tinfo[vi], lane, &pre);
   if (kRaw && vi < nviews) raw_prefetch(views[vi].v, tinfo[vi], lane, raw_buf(0));
   VCY_PT(0);
   VCY_PT_COUNT(10);
@@ -892,16 +905,12 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     wave_lds_fence();
     if (kRaw) {
       raw_tile_wait();  // this view's pixels have landed in raw_buf(cur)
-    } else if (kPrefetch) {
-      tile[lane] = pre.q0;
-      tile[lane + 64] = pre.q1;
     } else {
       tile_fill(v, tinfo[vi], lane, tile);
     }
     wave_lds_fence();
     // the next live view's tile is fetched while this one is computed
     int vnext = next_view(live, vi);
-    if (kPrefetch && vnext < nviews) tile_prefetch(views[vnext].v, tinfo[vnext], lane, &pre);
     if (kRaw && vnext < nviews) raw_prefetch(views[vnext].v, tinfo[vnext], lane, raw_buf(cur ^ 1));
     // the four taps of tile element idx (a quad, or the 2 x 2 pixels at idx of a raw tile)
     const lds_float* rawcur = (const lds_float*)raw_buf(cur);
@@ -992,47 +1001,52 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     // needs no per-voxel case distinction: kMax on a brick that is touched everywhere, or the unit-weight
     // average on a state with "update_num == 0 implies sdf == lowest()".  Same operations as above, in
     // the same order; what changes is what they cost on the SIMD:
-    //  - the LDS byte address of the quad comes out of the float pipeline: with K = 2^23 and every term
-    //    an integer below 2^22, a = fw * (16 tw) + (fu * 16 + (K + 16 base + tile offset)) is exact and
-    //    its low 23 bits ARE the address (2 fma + 1 and instead of fma, cvt, shift-add);
-    //  - wave-uniform factors of per-sample fma's sit in VGPRs (a scalar operand halves the issue rate);
-    //  - the update is a compare / select / carry chain through VCC (update_max_touched).
+    //  - the LDS byte address of the taps comes out of the float pipeline: a = fw * (bytes per tile row) +
+    //    (fu * (bytes per element) + (element size * base + tile offset)), every term an integer below 2^22,
+    //    evaluated in units of 2^-149 so that the bits of the result ARE the address (2 fma instead of fma,
+    //    cvt, shift-add);
+    //  - the two wave-uniform terms of that sum sit in VGPRs (back-to-back scalar operands halve the issue rate);
+    //  - the update is a compare / select / carry chain through VCC (update_max_touched), or a plain store for
+    //    a brick that has not been touched at all (FIRST).
     constexpr bool kFastMax = !GEN && UPDATE == VCY_UPDATE_MAX && !TRUNC && !CHECKMAX;
     constexpr bool kFastWa = !GEN && UPDATE == kUpdateWaUnitWeight && !CHECKMAX;
     // FIRST: no voxel of the brick has been touched yet (a fresh slab): the update is `sdf = dist, update_num = 1`
     // for every voxel (voxel_carver.cc:482-486), whatever the old value.
-    auto carve_view_fast = [&](auto first_tag) -> bool {
+    // NOTRUNC: the prologue has proved that no sample of this tile is below -1 (TileInfo::sure bit 1): the
+    // truncation test of the weighted average and its two selects are compiled out.
+    // UNIFORM (implies NOTRUNC): every voxel has update_num == fnu before this view and is updated by it.
+    auto carve_view_fast = [&](auto first_tag, auto notrunc_tag, auto uniform_tag) -> bool {
       constexpr bool FIRST = decltype(first_tag)::value;
+      constexpr bool NOTRUNC = decltype(notrunc_tag)::value;
+      constexpr bool UNIFORM = decltype(uniform_tag)::value;
+      // the brick's common weights, in VGPRs (uniform values; opaque to the compiler so that they are not
+      // folded back into scalar operands): (fn * sdf + dist) * (1 / (fn + 1)), voxel_carver.cc:88-95
+      float fn_v = 0.0f, inv_v = 0.0f;
+      if constexpr (UNIFORM) {
+        const float f1 = fnu + 1.0f;
+        asm volatile("v_mov_b32_e32 %0, %1" : "=v"(fn_v) : "s"(fnu));
+        inv_v = rcp_count(fn_v + 1.0f);
+        fnu = f1;
+      }
       // uniform -> VGPR (opaque to the compiler, which would otherwise fold them back into SGPR operands)
       float pitch16, cmagic;
       constexpr int kElemB = kRaw ? 4 : 16;     // bytes per tile element (pixel or quad)
-      // VCY_DENORM_ADDR: the same sum scaled by 2^-149, i.e. carried out in denormals (fp32 denormals are on
-      // for this library and v_fma_f32 handles them at full rate): the bit pattern of the result IS the
-      // integer, no mask needed.  The constant may be negative (base < 0); the final sum never is.
-      constexpr float kAddrUnit = VCY_DENORM_ADDR ? 0x1p-149f : 1.0f;
+      // The address sum is carried out in units of 2^-149, i.e. in denormals (fp32 denormals are on for this
+      // library and v_fma_f32 handles them at full rate): the bit pattern of the result IS the integer, no
+      // mask or conversion needed.  The constant may be negative (base < 0); the final sum never is.
+      constexpr float kAddrUnit = 0x1p-149f;
       {
         const float p16 = pitchf * ((float)kElemB * kAddrUnit);  // bytes per tile row; pitch <= 512: exact
         const unsigned lds_off = kRaw ? (unsigned)(size_t)rawcur : (unsigned)(size_t)(lds_float4*)tile;
         const int ci = kElemB * base + (int)lds_off;  // |16 base| < 2^22 (TileInfo::sure)
-        const float cm = VCY_DENORM_ADDR ? (ci < 0 ? -__int_as_float(-ci) : __int_as_float(ci)) : 8388608.0f + (float)ci;
+        const float cm = ci < 0 ? -__int_as_float(-ci) : __int_as_float(ci);
         asm volatile("v_mov_b32_e32 %0, %1" : "=v"(pitch16) : "s"(p16));
         asm volatile("v_mov_b32_e32 %0, %1" : "=v"(cmagic) : "s"(cm));
       }
-      float t0 = v.t[0], t1 = v.t[1], t2 = v.t[2], fxv = v.fx, fyv = v.fy, cxv = v.cx, cyv = v.cy;
-#if VCY_UNIFORM_VGPR >= 1
-      asm volatile("v_mov_b32_e32 %0, %1" : "=v"(fxv) : "s"(v.fx));
-      asm volatile("v_mov_b32_e32 %0, %1" : "=v"(t2) : "s"(v.t[2]));
-#endif
-#if VCY_UNIFORM_VGPR >= 2
-      asm volatile("v_mov_b32_e32 %0, %1" : "=v"(t0) : "s"(v.t[0]));
-      asm volatile("v_mov_b32_e32 %0, %1" : "=v"(t1) : "s"(v.t[1]));
-      asm volatile("v_mov_b32_e32 %0, %1" : "=v"(cxv) : "s"(v.cx));
-      asm volatile("v_mov_b32_e32 %0, %1" : "=v"(cyv) : "s"(v.cy));
-#endif
       // Four voxels at a time.  Phase A: image coordinates, fractions and the LDS reads (in flight
       // together); phase B: weights, sample, update.
       unsigned long long took = 0;
-      constexpr int kGroup = UPDATE == VCY_UPDATE_MAX ? VCY_FAST_GROUP : VCY_WA_GROUP;
+      constexpr int kGroup = VCY_FAST_GROUP;
 #pragma unroll
       for (int k0 = 0; k0 < WX; k0 += kGroup) {
         float lu[kGroup], lv[kGroup];
@@ -1040,16 +1054,16 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
 #pragma unroll
         for (int j = 0; j < kGroup; ++j) {
           const int k = k0 + j;
-          const float pcz = t2 + (c0[16 + k] + h12z);
-          const float qx = div_view<DIV>(fxv, pcz);
-          const float qy = SAMEF ? qx : div_view<DIV>(fyv, pcz);
-          const float pcx = t0 + (c0[2 * k] + h12x), pcy = t1 + (c0[2 * k + 1] + h12y);
-          const float u = qx * pcx + cxv, w = qy * pcy + cyv;
+          const float pcz = v.t[2] + (c0[16 + k] + h12z);
+          const float qx = div_view<DIV>(v.fx, pcz);
+          const float qy = SAMEF ? qx : div_view<DIV>(v.fy, pcz);
+          const float pcx = v.t[0] + (c0[2 * k] + h12x), pcy = v.t[1] + (c0[2 * k + 1] + h12y);
+          const float u = qx * pcx + v.cx, w = qy * pcy + v.cy;
           const float fu = floorf(u), fw = floorf(w);
           lu[j] = u - fu;
           lv[j] = w - fw;
           const float a = __builtin_fmaf(fw, pitch16, __builtin_fmaf(fu, (float)kElemB * kAddrUnit, cmagic));
-          const unsigned addr = VCY_DENORM_ADDR ? __float_as_uint(a) : (__float_as_uint(a) & 0x7fffffu);
+          const unsigned addr = __float_as_uint(a);
           if constexpr (kRaw) {
             const lds_float* tp = (const lds_float*)(size_t)addr;
             q[j] = f4{tp[0], tp[1], tp[16], tp[17]};
@@ -1068,33 +1082,47 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
             n[k] = (NT)1;
           } else if constexpr (kFastMax) {
             update_max_touched(dist, s[k], n[k], took);
+          } else if constexpr (UNIFORM) {
+            s[k] = (fn_v * s[k] + dist) * inv_v;
           } else if constexpr (kFastWa) {
-            update_wa_unit<TRUNC>(dist, s[k], n[k]);
+            update_wa_unit<TRUNC && !NOTRUNC>(dist, s[k], n[k]);
           }
         }
       }
       return (kFastMax && !FIRST) ? took != 0ull : true;
     };
     bool brick_moved;
-    const bool sure = !GEN && __builtin_amdgcn_readfirstlane(tinfo[vi].sure) != 0;
+    const int sure_bits = GEN ? 0 : __builtin_amdgcn_readfirstlane(tinfo[vi].sure);
+    const bool sure = (sure_bits & 1) != 0, never_truncated = (sure_bits & 2) != 0;
     // (Branch weights: the checked loops below are the rare ones in the kernels that have a select-free loop;
     // the register allocator then spills there, if anywhere, and not in the loops that do the work.)
     constexpr bool kHasFast = kFastMax || kFastWa;
     const bool fast_first = kFastMax && sure && none_touched;
     const bool fast_next = (kFastMax && sure && all_touched) || (kFastWa && sure && implied);
     if (__builtin_expect_with_probability(fast_next, kHasFast, 0.9)) {
-      brick_moved = carve_view_fast(std::false_type{});
+      // weighted average: no truncation test when it cannot fire, and brick-wide weights while the counts agree
+      const bool all_updated = kFastWa && (!TRUNC || never_truncated);
+      if (kFastWa && all_updated && uniform_cnt) {
+        brick_moved = carve_view_fast(std::false_type{}, std::true_type{}, std::true_type{});
+      } else if (kFastWa && all_updated) {
+        brick_moved = carve_view_fast(std::false_type{}, std::true_type{}, std::false_type{});
+      } else {
+        if (kFastWa) leave_uniform();
+        brick_moved = carve_view_fast(std::false_type{}, std::false_type{}, std::false_type{});
+      }
       VCY_PT(2);
       VCY_PT_COUNT(7);
     } else if (__builtin_expect_with_probability(fast_first, kHasFast, 0.99)) {
-      brick_moved = carve_view_fast(std::true_type{});
+      brick_moved = carve_view_fast(std::true_type{}, std::false_type{}, std::false_type{});
       VCY_PT(2);
       VCY_PT_COUNT(7);
     } else if (sure) {
+      leave_uniform();
       brick_moved = carve_view(std::true_type{});
       VCY_PT(3);
       VCY_PT_COUNT(8);
     } else {
+      leave_uniform();
       brick_moved = carve_view(std::false_type{});
       VCY_PT(4);
       VCY_PT_COUNT(9);
@@ -1110,7 +1138,6 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
       const int v2 = next_view(live, vi);
       if (v2 != vnext) {
         vnext = v2;
-        if (kPrefetch && vnext < nviews) tile_prefetch(views[vnext].v, tinfo[vnext], lane, &pre);
         // (the dropped view's pixels may still be arriving in that buffer: loads complete in order)
         if (kRaw && vnext < nviews) raw_prefetch(views[vnext].v, tinfo[vnext], lane, raw_buf(cur ^ 1));
       }
@@ -1121,6 +1148,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   }
 
   // ---- write back what changed (update_num grows with every change) ----------------------------
+  leave_uniform();
   if (lane_valid) {
     if (vec_io) {
       bool changed = fresh != 0;  // (a fresh slab has never been written: every voxel is stored)
@@ -1177,12 +1205,12 @@ void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const Gri
     fprintf(stderr, "VCY_DEV_BENCH_KERNELS_ONLY: kernel variant not built\n");
     abort();
   }
-  if constexpr (SAMEF && sizeof(CountT) == 2 && UPDATE != VCY_UPDATE_WEIGHTED_AVERAGE) VCY_FUSED(false, VCY_SMALL_TILE, false, 2);
+  if constexpr (SAMEF && sizeof(CountT) == 2 && UPDATE != VCY_UPDATE_WEIGHTED_AVERAGE) VCY_FUSED(false, kTileRaw, false, 2);
 #else
   if (big) {
     if (checkmax) VCY_FUSED_G(true, kTileBig); else VCY_FUSED_G(false, kTileBig);
   } else {
-    if (checkmax) VCY_FUSED_G(true, VCY_SMALL_TILE); else VCY_FUSED_G(false, VCY_SMALL_TILE);
+    if (checkmax) VCY_FUSED_G(true, kTileRaw); else VCY_FUSED_G(false, kTileRaw);
   }
 #endif
 #undef VCY_FUSED_G
@@ -1319,7 +1347,10 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   int max_px = 0, max_quads = 0;  // per view: pixels, and threads of the window-maximum kernels
   if (need_bound) {
     size_t total = 0;
-    for (int vi = 0; vi < n_views; ++vi) total += ((size_t)kWmaxPlanes * vp[vi].width * vp[vi].height + 3) & ~(size_t)3;
+    // (two more planes, of the negated image, for the truncating unit-weight average: FusedView::has_lower)
+    const bool need_lower = u.use_truncation && u.voxel_update == VCY_UPDATE_WEIGHTED_AVERAGE && g.weight == 1.0f;
+    const int planes = need_lower ? 2 * kWmaxPlanes : kWmaxPlanes;
+    for (int vi = 0; vi < n_views; ++vi) total += ((size_t)planes * vp[vi].width * vp[vi].height + 3) & ~(size_t)3;
     if (c->wmax_bytes < total * sizeof(float)) {
       VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
       if (c->d_wmax) (void)hipFree(c->d_wmax);
@@ -1334,7 +1365,8 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
         const int npx = vp[vi].width * vp[vi].height;
         fv[vi].wmax = c->d_wmax + off;
         fv[vi].wmax_plane = npx;
-        off += ((size_t)kWmaxPlanes * npx + 3) & ~(size_t)3;  // every view 16-byte aligned
+        fv[vi].has_lower = need_lower ? 1 : 0;
+        off += ((size_t)planes * npx + 3) & ~(size_t)3;  // every view 16-byte aligned
         max_px = std::max(max_px, npx);
         // image-space bounding box of the slab (double precision, 16 px border; the footprints the
         // kernel looks up lie within a fraction of a pixel of the exact hull, their windows inside them)
@@ -1395,8 +1427,12 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
 
   if (max_quads > 0) {  // the images may have changed since the last call: rebuild every time
     const dim3 wgrid((unsigned)((max_quads + 255) / 256), (unsigned)n_views);
-    hipLaunchKernelGGL(wmax_k4_kernel, wgrid, dim3(256), 0, c->stream, d_views);
-    hipLaunchKernelGGL(wmax_k8_kernel, wgrid, dim3(256), 0, c->stream, d_views);
+    hipLaunchKernelGGL(wmax_k4_kernel<false>, wgrid, dim3(256), 0, c->stream, d_views);
+    hipLaunchKernelGGL(wmax_k8_kernel<false>, wgrid, dim3(256), 0, c->stream, d_views);
+    if (fv[0].has_lower) {
+      hipLaunchKernelGGL(wmax_k4_kernel<true>, wgrid, dim3(256), 0, c->stream, d_views);
+      hipLaunchKernelGGL(wmax_k8_kernel<true>, wgrid, dim3(256), 0, c->stream, d_views);
+    }
   }
   const int nbx = (c->nx + BX - 1) / BX, nby = (c->ny + BY - 1) / BY, nbz = (nzl + BZ - 1) / BZ;
   const int64_t nblocks = (int64_t)nbx * nby * nbz;
@@ -1418,8 +1454,8 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   // update_num can only exceed voxel_max_update_num after more than that many views
   const bool checkmax = c->views_carved + n_views > (int64_t)u.voxel_max_update_num;
   const dim3 grid((unsigned)nblocks);
-  // Tile size: footprint of an 8x8x8 wave brick in pixels ~ (8*sqrt(3)*pixels_per_voxel + 3)^2.  The
-  // small tile (register prefetch) covers sub-pixel voxels; the big one up to ~1.4 px per voxel; wider
+  // Tile kind: footprint of an 8x8x8 wave brick in pixels ~ (8*sqrt(3)*pixels_per_voxel + 3)^2.  The raw
+  // 16 x 16 pixel tile covers voxels up to ~0.85 px; the quad tile filled in place up to ~1.4 px; wider
   // footprints take the generic path inside the kernel either way.
   bool big = false;
   {
@@ -1436,7 +1472,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
       worst = std::max(worst, c->fused_ortho ? res : (pz > 0.0f ? f * res / pz : INFINITY));
     }
     const float side = 8.0f * 1.7320508f * worst + 3.0f;
-    big = VCY_SMALL_TILE == kTileRaw ? side > 15.0f : side * side > (float)kTileSmall;
+    big = side > 15.0f;
     if (c->tile_mode == 1) big = false;
     if (c->tile_mode == 2) big = true;
   }

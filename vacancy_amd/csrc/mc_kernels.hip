@@ -1002,10 +1002,10 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   int64_t ncells = 0, nghost = 0, nv = 0, nf = 0;
   CellBuffers cb{};
   bool done = false;
+  auto with_headroom = [](int64_t v) { return v + v / 4 + 4096; };  // the next view's mesh is a little different
   if (c->mc_hint_cells > 0) {
-    const int64_t cap_cells = c->mc_hint_cells + c->mc_hint_cells / 4 + 4096;
-    const int64_t cap_v = c->mc_hint_verts + c->mc_hint_verts / 4 + 4096;
-    const int64_t cap_f = c->mc_hint_faces + c->mc_hint_faces / 4 + 4096;
+    const int64_t cap_cells = with_headroom(c->mc_hint_cells);
+    const int64_t cap_v = with_headroom(c->mc_hint_verts), cap_f = with_headroom(c->mc_hint_faces);
     rc = cell_buffers(cap_cells, &cb);
     if (rc == VCY_OK) rc = enqueue_owners(cb, cap_cells);
     if (rc == VCY_OK) rc = enqueue_emit(cb, cap_cells, cap_v, cap_f);
@@ -1033,14 +1033,16 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
       return VCY_ERR_TOO_MANY_VOXELS;
     }
     if (ncells > 0) {
-      rc = cell_buffers(ncells, &cb);
-      if (rc == VCY_OK) rc = enqueue_owners(cb, ncells);
+      // (buffers sized with the same headroom as the guesses, so that the next extraction does not reallocate)
+      const int64_t cap_cells = with_headroom(ncells);
+      rc = cell_buffers(cap_cells, &cb);
+      if (rc == VCY_OK) rc = enqueue_owners(cb, cap_cells);
       if (rc != VCY_OK) return rc;
       MC_TRY(hipMemcpyAsync(&h_tot, cb.total, sizeof(u64), hipMemcpyDeviceToHost, s));
       MC_TRY(hipStreamSynchronize(s));
       nv = (int64_t)(h_tot >> 32);
       nf = (int64_t)(h_tot & 0xFFFFFFFFull);
-      rc = enqueue_emit(cb, ncells, nv, nf);
+      rc = enqueue_emit(cb, cap_cells, with_headroom(nv), with_headroom(nf));
       if (rc != VCY_OK) return rc;
     }
   }
