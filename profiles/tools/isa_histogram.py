@@ -7,9 +7,9 @@ costs measured on MI355X (profiles/r02/valu_ubench.txt).
 Compiles vacancy_amd/csrc/carve_fused.hip to assembly (device only, the instantiations bench.py launches),
 takes carve_fused_kernel<unsigned short, MODE, TRUNC, true, false, 16, false, 2> and prints
   * every opcode with its static count and issue class,
-  * the same for ONE view of the select-free path: from the top of the view loop (tile wait, request of the
-    next tile, per-view constants) through the straight-line run over a lane's eight voxels to the last
-    update, i.e. instructions and issue cycles per 8 voxel*views of a wave.
+  * the same for every flavour of the select-free run: the straight-line code over a lane's eight voxels in
+    one view (eight exact divisions, sixteen tap reads), i.e. instructions and issue cycles per 8 voxel*views
+    of a wave, without the per-view overhead at the top of the view loop.
 Classes: full = 2 cycles per wave64 instruction (1.95 measured), half = 4 (3.5 measured; also ANY VALU
 instruction with an SGPR source when it follows another half-rate one), trans = 8 (7.55 measured).
 """
@@ -67,30 +67,36 @@ def main():
         return valu, cyc
 
     histogram(body, "whole kernel %s (static counts, %d lines)" % (tag, len(body)))
-    # select-free loop: the longest stretch that holds eight update chains (kMax: v_cmp_gt_f32_e32 vcc;
-    # average: v_cmp_ngt_f32_e32 vcc) -- from the first v_rcp_f32 before the first of them to the last one
-    pat = "v_cmp_gt_f32_e32 vcc" if mode == "0" else "v_cmp_ngt_f32_e32 vcc"
-    idx = [i for i, l in enumerate(body) if pat in l]
-    groups, cur = [], []
-    for i in idx:
-        if cur and i - cur[-1] > 400:
-            groups.append(cur)
+    # the straight-line runs over a lane's eight voxels: basic blocks (no label inside) with eight exact
+    # divisions (v_rcp_f32) and sixteen tap reads (ds_read2_b32): one per flavour of the select-free loop
+    blocks, cur = [], []
+    for l in body:
+        t = l.strip()
+        if re.match(r"^\.?[A-Za-z_][\w.$]*:", t):  # a label (possibly followed by a comment): a new basic block
+            blocks.append(cur)
             cur = []
-        cur.append(i)
-    if cur:
-        groups.append(cur)
-    g = next(x for x in groups if len(x) >= 8)[:8]
-    first = max(i for i in range(g[0]) if "v_rcp_f32" in body[i] and sum("v_rcp_f32" in body[j] for j in range(i, g[0])) >= 1)
-    # walk back over the run's earlier reciprocals (straight-line code: no label in between)
-    i = first
-    while i > 0 and not body[i].strip().endswith(":"):
-        i -= 1
-    last = g[-1]
-    while "v_addc_co_u32" not in body[last] and "v_cndmask" not in body[last + 1] and last < len(body) - 1 and mode == "0":
-        last += 1
-    last += 3 if mode != "0" else 1
-    valu, cyc = histogram(body[i + 1:last + 1], "one view of the select-free path: loop top (tile wait, next tile request, per-view constants) + the run over the 8 voxels of a lane (lines %d-%d of the kernel)" % (i + 1, last))
-    print("   => %.1f VALU instructions and %.1f issue cycles per voxel*view of a wave" % (valu / 8.0, cyc / 8.0))
+        else:
+            cur.append(l)
+    blocks.append(cur)
+    for b in blocks:
+        nrcp = sum("v_rcp_f32" in l for l in b)
+        ntap = sum("ds_read2_b32" in l for l in b)
+        if nrcp < 8 or ntap < 16:
+            continue
+        sig = []
+        if any("v_cmp_gt_f32_e32 vcc" in l for l in b):
+            sig.append("kMax update chain (brick touched everywhere)")
+        if any("v_cmp_ngt_f32_e32 vcc" in l for l in b):
+            sig.append("weighted average with the truncation test")
+        if nrcp == 9:
+            sig.append("weighted average, brick-wide weights (one count reciprocal per view)")
+        if nrcp == 16 and not any("v_cmp_ngt_f32_e32 vcc" in l for l in b):
+            sig.append("weighted average, per-voxel weights, truncation test compiled out")
+        if nrcp == 8 and not sig:
+            sig.append("first touch: plain store")
+        valu, cyc = histogram(b, "run over the 8 voxels of a lane, one view -- " + "; ".join(sig))
+        print("   => %.1f VALU instructions and %.1f issue cycles per voxel*view of a wave (per-view overhead not included)"
+              % (valu / 8.0, cyc / 8.0))
 
 
 if __name__ == "__main__":

@@ -32,9 +32,9 @@ if [ -f build/variants/phase/libvacancy_hip.so ]; then
 fi
 # the multi-rank path of bench.py on this one device: 2 ranks, 2 slabs each, halo exchange over gloo (RCCL refuses
 # two ranks on one device; --allow-gloo is the documented escape for exactly this check)
-python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-variants --allow-gloo > "$O/bench_2ranks_one_device_gloo.json" 2> "$O/bench_2ranks_one_device_gloo.err"
+VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-variants --allow-gloo > "$O/bench_2ranks_one_device_gloo.json" 2> "$O/bench_2ranks_one_device_gloo.err"
 echo "2 ranks (gloo) rc=$?" > "$O/status.txt"
-python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-variants > "$O/bench_2ranks_one_device_rccl.json" 2> "$O/bench_2ranks_one_device_rccl.err"
+VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-variants > "$O/bench_2ranks_one_device_rccl.json" 2> "$O/bench_2ranks_one_device_rccl.err"
 echo "2 ranks (rccl on one device, expected to be refused) rc=$?" >> "$O/status.txt"
 # the bench lines: with the counters of this session next to them
 mkdir -p profiles && cp "$CTR" profiles/counters.json
