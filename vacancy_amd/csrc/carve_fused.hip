@@ -38,6 +38,11 @@ namespace vcy {
 
 namespace {
 
+// Wave priority: everything but the runs over the voxels is short and ends in a memory request (view records,
+// window lookups, the next tile, the state) whose latency nothing of this wave can cover; it runs at raised
+// priority so that those requests leave as early as possible while the other waves of the SIMD are in their
+// runs.  +2 ... 3 % in every mode.
+#define VCY_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 // Waves per workgroup.  The waves never talk to each other, so 1 and 2 are just as correct; measured, they are
 // 3 % slower in the default mode (four bricks adjacent in x start together and share rows and footprints).
 constexpr int kWgWaves = 4;
@@ -732,6 +737,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   // Footprints holding a NaN or an infinity give no bound (0 * inf = NaN samples).
   constexpr bool kNeedBound = TRUNC || UPDATE == VCY_UPDATE_MAX;
 
+  VCY_SETPRIO(3);
   const int tid = threadIdx.x;
   // (the wave index is uniform, which the compiler cannot see: keeps the LDS bases of the wave in SGPRs)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -905,6 +911,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     // this view's record of the wave brick's x products: (x, y) pairs at [2 k], z at [16 + k]
     cfloat_ptr c0 = (cfloat_ptr)(c0_all + ((size_t)vi * (nxp / WX) + (x_first / WX)) * kC0Stride);
     // stage this view's tile (wave-private: program order is enough)
+    VCY_SETPRIO(3);
     wave_lds_fence();
     if (kRaw) {
       raw_tile_wait();  // this view's pixels have landed in raw_buf(cur)
@@ -934,6 +941,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     // c1 + c2 of this lane's (y, z): the inner sum of pc = t + (c0 + (c1 + c2)) (voxel_carver.cc:453)
     const float h12x = v.r[0][1] * py + v.r[0][2] * pz, h12y = v.r[1][1] * py + v.r[1][2] * pz;
     const float h12z = v.r[2][1] * py + v.r[2][2] * pz;
+    VCY_SETPRIO(0);
     VCY_PT(1);
 
     // Straight-line fast path for the 8 voxels of this thread (no divergent control flow, so
@@ -1130,6 +1138,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
       VCY_PT(4);
       VCY_PT_COUNT(9);
     }
+    VCY_SETPRIO(3);
     if (brick_moved) VCY_PT_COUNT(11);
     none_touched = false;  // (a checked view may have touched only some voxels)
     refresh_all_touched();
