@@ -401,37 +401,52 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total, int* sm /
 }
 
 // ---- pass 1: active cells, counted per word --------------------------------------------------
+// A workgroup handles kActiveBlocks consecutive blocks of 256 words, and every thread requests the corner
+// planes of all its words before it uses the first: the pass is one memory round trip deep and is bound by
+// how many of those a CU keeps in flight, not by the bytes (1024^3: 0.20 ms with one word per thread; with two,
+// between the same and 0.06 ms less from run to run; four and eight lose to their registers).
+constexpr int kActiveBlocks = 2;
+
 __global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restrict__ act,
                                                         uint32_t* __restrict__ word_cell_off,
-                                                        u64* __restrict__ block_cells) {
+                                                        u64* __restrict__ block_cells, int64_t nblocks) {
   __shared__ int sm[4];
   // XCD-aware order (workgroup b runs on XCD b % 8): consecutive word blocks -- which share their
   // boundary rows and, one layer later, the rows of slice z-1 -- stay on one XCD's L2
-  int64_t lb = blockIdx.x;
+  int64_t lg = blockIdx.x;
   {
     const int64_t per = gridDim.x >> 3;
-    if (lb < per * 8) lb = (lb & 7) * per + (lb >> 3);
+    if (lg < per * 8) lg = (lg & 7) * per + (lg >> 3);
   }
-  const int64_t cw = lb * 256 + threadIdx.x;
-  u64 a = 0;
-  if (cw < p.nwords) {
-    int li, cy, w;
-    if (decode_word(p, cw, &li, &cy, &w) && (li > 0 || p.has_ghost)) {
-      // a cell is active when its corners are neither all inside nor all outside (kEdgeTable != 0) and it
-      // is valid; the validity planes are only read for the few words that have a candidate
-      CellWord c;
-      const CellRows r = cell_rows(p, li, cy);
-      load_cell_in(p, r, w, &c);
-      c.valid = ~0ull;
-      a = active_mask(c);
-      if (a) a &= load_cell_valid(p, r, w);
-    }
-    act[cw] = a;
+  CellWord c[kActiveBlocks];
+  CellRows r[kActiveBlocks];
+  int w[kActiveBlocks];
+  bool live[kActiveBlocks];
+#pragma unroll
+  for (int k = 0; k < kActiveBlocks; ++k) {
+    const int64_t cw = (lg * kActiveBlocks + k) * 256 + threadIdx.x;
+    int li = 0, cy = 0;
+    w[k] = 0;
+    live[k] = cw < p.nwords && decode_word(p, cw, &li, &cy, &w[k]) && (li > 0 || p.has_ghost);
+    if (!live[k]) li = 1, cy = 0, w[k] = 0;  // (any valid word: the loads below are not branched around)
+    r[k] = cell_rows(p, li, cy);
+    load_cell_in(p, r[k], w[k], &c[k]);
   }
-  int total;
-  const int off = block_exclusive_scan(__popcll(a), &total, sm);
-  if (cw < p.nwords) word_cell_off[cw] = (uint32_t)off;
-  if (threadIdx.x == 0) block_cells[lb] = (u64)(unsigned)total;
+#pragma unroll
+  for (int k = 0; k < kActiveBlocks; ++k) {
+    const int64_t lb = lg * kActiveBlocks + k;
+    const int64_t cw = lb * 256 + threadIdx.x;
+    // a cell is active when its corners are neither all inside nor all outside (kEdgeTable != 0) and it
+    // is valid; the validity planes are only read for the few words that have a candidate
+    c[k].valid = ~0ull;
+    u64 a = live[k] ? active_mask(c[k]) : 0ull;
+    if (a) a &= load_cell_valid(p, r[k], w[k]);
+    if (cw < p.nwords) act[cw] = a;
+    int total;
+    const int off = block_exclusive_scan(__popcll(a), &total, sm);
+    if (cw < p.nwords) word_cell_off[cw] = (uint32_t)off;
+    if (threadIdx.x == 0 && lb < nblocks) block_cells[lb] = (u64)(unsigned)total;
+  }
 }
 
 // ---- pass 2: compact the active cells into a list (raster order is preserved) ------------------
@@ -585,6 +600,7 @@ __device__ __forceinline__ void vertex_interp(double iso, const float pa[3], con
 constexpr int kEmitMaxVerts = 512;  // 6 KB + 8 KB of keys (a smooth surface has about one vertex per active cell)
 constexpr int kEmitMaxTris = 768;   // 9 KB (about two triangles per active cell)
 
+// (123 VGPRs, 4 waves per SIMD: compiled for 5, 6 or 8 it spills and is 5 - 15 % slower)
 __global__ __launch_bounds__(256) void mc_emit_kernel(McParams p, const McTables* __restrict__ T,
                                                       const u64* __restrict__ act,
                                                       const u64* __restrict__ cell_list,
@@ -931,7 +947,8 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   } else {
     launch_bits(0, vox_words, false);
   }
-  hipLaunchKernelGGL(mc_active_kernel, dim3(nblocks), dim3(256), 0, s, p, d_act, d_woff, d_wcounts);
+  hipLaunchKernelGGL(mc_active_kernel, dim3((nblocks + kActiveBlocks - 1) / kActiveBlocks), dim3(256), 0, s, p, d_act, d_woff,
+                     d_wcounts, (int64_t)nblocks);
   MC_TRY(hipGetLastError());
   int rc = exclusive_scan_u64(d_wcounts, nblocks, d_total, d_scan, s);
   if (rc != VCY_OK) return rc;
