@@ -252,7 +252,7 @@ int vcy_reset(vcy_ctx* ctx);
 /* Tuning knobs that never change results.  "fused" (default 1): 0 forces one kernel launch
  * per view (the generic kernel) instead of the fused multi-view kernel.  "cull" (default 1): 0 never
  * drops provably idle (brick, view) pairs.  "tile" (default 0 = chosen from the pixel footprint of a
- * voxel): 1 / 2 force the raw 16 x 16 pixel tile / the 512-quad tile of the fused kernel.  "defer" (default 1): the per-view
+ * voxel): 1 / 2 force the 16 x 16 pixel tile / the 2048-pixel tile of the fused kernel.  "defer" (default 1): the per-view
  * entry points vcy_carve / vcy_carve_device / vcy_carve_silhouette keep a private device copy of the image
  * and queue the view; queued views are carved together, in call order, by one fused launch when the
  * state is next needed (extraction, download, upload, halo, vcy_sync, vcy_timer_end, a batch call) or

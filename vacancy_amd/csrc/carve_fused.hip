@@ -10,7 +10,7 @@
 //
 // Per view the wave keeps the image footprint of its brick in a wave-private LDS tile: 16 x 16 raw pixels
 // (kTileRaw: global memory -> LDS directly, double buffered, a sample = two ds_read2_b32), or for footprints
-// beyond 15 x 15 pixels a tile of *quads* { s(x,y), s(x1,y), s(x,y1), s(x1,y1) } filled in place (kTileBig).
+// beyond 15 x 15 pixels a raw tile of up to 2048 pixels with the footprint's own pitch, filled in place (kTileBig).
 // Either way the reference's ROI clamps of x + 1 and y + 1 (voxel_carver.cc:51-66) are applied when the
 // tile is filled, never per sample.  No workgroup barrier anywhere.  A voxel whose projection falls
 // outside the staged tile (brick near the camera plane, footprint larger than the tile, outside the ROI)
@@ -60,7 +60,10 @@ constexpr int kTileRaw = 16;
 constexpr int kRawBuffers = 2;
 template <int TQ>
 constexpr int tile_f4_per_wave() { return TQ == kTileRaw ? kRawBuffers * 64 : TQ; }  // LDS of one wave, in float4
-constexpr int kTileBig = 512;            // 8 KB per wave: footprints up to ~1.4 px per voxel, filled in place
+// The big tile: 8 KB per wave = 2048 raw pixels, pitch = width of the footprint, filled in place by ordinary
+// loads (footprints up to ~44 x 44 pixels, voxels up to ~3 px); the second tap row is one address add away.
+constexpr int kTileBig = 512;            // (in float4 units)
+constexpr int kBigPixels = 4 * kTileBig;
 
 constexpr int kWmaxPlanes = 2;           // window sizes 4 and 8
 
@@ -380,21 +383,21 @@ __device__ __forceinline__ float wave_min(float v) {
   return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 63));
 }
 
-// Fills a whole (big) tile in place: lane q, q+64, ... (no register prefetch).
-__device__ __forceinline__ void tile_fill(const ViewParams& v, const TileInfo& ti, int lane, float4* tile) {
+// Fills a whole (big) tile in place: pixel (i, j) of the (tw + 1) x (th + 1) window = image pixel
+// (min(tx0 + i, roi_max.x), min(ty0 + j, roi_max.y)), lane q, q + 64, ...
+__device__ __forceinline__ void tile_fill(const ViewParams& v, const TileInfo& ti, int lane, float* tile) {
   const int nq = __builtin_amdgcn_readfirstlane(ti.nq);
-  const int tw = __builtin_amdgcn_readfirstlane(ti.tw);
+  if (nq == 0) return;
+  const int tw = __builtin_amdgcn_readfirstlane(ti.tw), th = __builtin_amdgcn_readfirstlane(ti.th);
   const int tx0 = __builtin_amdgcn_readfirstlane(ti.tx0);
   const int ty0 = __builtin_amdgcn_readfirstlane(ti.ty0);
-  const float inv_tw = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ti.inv_tw)));
+  const float inv_pitch = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ti.inv_tw)));
+  const int pitch = tw + 1, npx = pitch * (th + 1);
   gfloat_ptr img = (gfloat_ptr)v.sdf;
-  for (int q = lane; q < nq; q += 64) {
-    const int j = div_small(q, inv_tw), i = q - j * tw;
-    const int xx = tx0 + i, yy = ty0 + j;
-    const int xx1 = min(xx + 1, v.roi_max_xi), yy1 = min(yy + 1, v.roi_max_yi);
-    gfloat_ptr r0 = img + (int64_t)v.width * yy;
-    gfloat_ptr r1 = img + (int64_t)v.width * yy1;
-    tile[q] = make_float4(r0[xx], r0[xx1], r1[xx], r1[xx1]);
+  for (int q = lane; q < npx; q += 64) {
+    const int j = div_small(q, inv_pitch), i = q - j * pitch;
+    const int xx = min(tx0 + i, v.roi_max_xi), yy = min(ty0 + j, v.roi_max_yi);
+    tile[q] = img[(int64_t)v.width * yy + xx];
   }
 }
 
@@ -586,7 +589,7 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
       const int ty1 = min((int)floorf(wmax_ + margin), v.roi_max_yi);
       const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
       constexpr bool kRaw = TQ == kTileRaw;
-      if (tw > 0 && th > 0 && (kRaw ? (tw <= 15 && th <= 15) : (tw <= TQ && th <= TQ && tw * th <= TQ))) {
+      if (tw > 0 && th > 0 && (kRaw ? (tw <= 15 && th <= 15) : ((tw + 1) * (th + 1) <= kBigPixels))) {
         // Every computed (u, w) of the brick is within corner error + voxel error < margin of the corner
         // hull, so when the ROI clipped nothing it lies in [tx0, tx1 + 1) x [ty0, ty1 + 1); the depth
         // guard keeps every computed pc.z within a factor 2 of the corner range, inside div_fast's.
@@ -594,7 +597,7 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
                                (int)floorf(umax + margin) < v.roi_max_xi && (int)floorf(wmax_ + margin) < v.roi_max_yi;
         const bool depth_ok = 0x1p-20f * mag[2] <= 0.25f * zmin && zmin >= 0x1p-58f && zmax <= 0x1p58f;
         // (|16 base| < 2^22: the fast path forms LDS addresses in the float pipeline, carve_view_fast)
-        const int pitch = kRaw ? 16 : tw;  // elements per tile row (raw: pixels, pitch 16; else quads)
+        const int pitch = kRaw ? 16 : tw + 1;  // pixels per tile row
         const bool small_base = ty0 * pitch + tx0 < (1 << 18);
         ti.sure = (!ortho && unclipped && depth_ok && small_base) ? 1 : 0;
         ti.tx0 = tx0;
@@ -602,7 +605,7 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
         ti.tw = tw;
         ti.th = th;
         ti.nq = tw * th;
-        ti.inv_tw = 1.0f / (float)tw;
+        ti.inv_tw = 1.0f / (float)pitch;
         ti.pitchf = (float)pitch;
         ti.base = -(ty0 * pitch + tx0);
         ti.lo_x = (float)tx0;
@@ -916,27 +919,30 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     if (kRaw) {
       raw_tile_wait();  // this view's pixels have landed in raw_buf(cur)
     } else {
-      tile_fill(v, tinfo[vi], lane, tile);
+      tile_fill(v, tinfo[vi], lane, (float*)tile);
     }
     wave_lds_fence();
     // the next live view's tile is fetched while this one is computed
     int vnext = next_view(live, vi);
     if (kRaw && vnext < nviews) raw_prefetch(views[vnext].v, tinfo[vnext], lane, raw_buf(cur ^ 1));
-    // the four taps of tile element idx (a quad, or the 2 x 2 pixels at idx of a raw tile)
+    const float pitchf = tinfo[vi].pitchf;
+    const int base = tinfo[vi].base;
+    const int big_pitch = kRaw ? 16 : (int)pitchf;  // pixels per row of the big tile
+    // the four taps of the sample whose upper left pixel is tile element idx
     const lds_float* rawcur = (const lds_float*)raw_buf(cur);
     auto quad_at = [&](unsigned idx) -> float4 {
       if constexpr (kRaw) {
         const lds_float* p = rawcur + idx;
         return make_float4(p[0], p[1], p[16], p[17]);
       } else {
-        return tile[idx];
+        const lds_float* p = (const lds_float*)(float*)tile + idx;
+        const lds_float* p2 = p + big_pitch;
+        return make_float4(p[0], p[1], p2[0], p2[1]);
       }
     };
 
     const float lo_x = tinfo[vi].lo_x, hi_x = tinfo[vi].hi_x;
     const float lo_y = tinfo[vi].lo_y, hi_y = tinfo[vi].hi_y;
-    const float pitchf = tinfo[vi].pitchf;
-    const int base = tinfo[vi].base;
     const bool is_ortho = GEN && mode.ortho != 0, is_nn = GEN && mode.interp == VCY_INTERP_NN;
     // c1 + c2 of this lane's (y, z): the inner sum of pc = t + (c0 + (c1 + c2)) (voxel_carver.cc:453)
     const float h12x = v.r[0][1] * py + v.r[0][2] * pz, h12y = v.r[1][1] * py + v.r[1][2] * pz;
@@ -979,7 +985,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
         const float mu = 1.0f - lu, mv = 1.0f - lv;
         // any index is harmless when !in_tile (the sample is discarded); keep it inside the tile
         unsigned idx = (unsigned)((int)__builtin_fmaf(fw, pitchf, fu) + base);
-        if (!SURE) idx = min(idx, (unsigned)(kRaw ? 256 - 18 : TQ - 1));
+        if (!SURE) idx = min(idx, (unsigned)(kRaw ? 256 - 18 : max(kBigPixels - big_pitch - 2, 0)));
         const float4 q = quad_at(idx);
         // ((1-lu)(1-lv)) s00 + (lu (1-lv)) s10 + ((1-lu) lv) s01 + (lu lv) s11, summed left to right (:69-73)
         float dist = ((((mu * mv) * q.x) + ((lu * mv) * q.y)) + ((mu * lv) * q.z)) + ((lu * lv) * q.w);
@@ -1041,14 +1047,14 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
       }
       // uniform -> VGPR (opaque to the compiler, which would otherwise fold them back into SGPR operands)
       float pitch16, cmagic;
-      constexpr int kElemB = kRaw ? 4 : 16;     // bytes per tile element (pixel or quad)
+      constexpr int kElemB = 4;                 // bytes per tile element (a pixel)
       // The address sum is carried out in units of 2^-149, i.e. in denormals (fp32 denormals are on for this
       // library and v_fma_f32 handles them at full rate): the bit pattern of the result IS the integer, no
       // mask or conversion needed.  The constant may be negative (base < 0); the final sum never is.
       constexpr float kAddrUnit = 0x1p-149f;
       {
         const float p16 = pitchf * ((float)kElemB * kAddrUnit);  // bytes per tile row; pitch <= 512: exact
-        const unsigned lds_off = kRaw ? (unsigned)(size_t)rawcur : (unsigned)(size_t)(lds_float4*)tile;
+        const unsigned lds_off = kRaw ? (unsigned)(size_t)rawcur : (unsigned)(size_t)(const lds_float*)(float*)tile;
         const int ci = kElemB * base + (int)lds_off;  // |16 base| < 2^22 (TileInfo::sure)
         const float cm = ci < 0 ? -__int_as_float(-ci) : __int_as_float(ci);
         asm volatile("v_mov_b32_e32 %0, %1" : "=v"(pitch16) : "s"(p16));
@@ -1075,11 +1081,12 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
           lv[j] = w - fw;
           const float a = __builtin_fmaf(fw, pitch16, __builtin_fmaf(fu, (float)kElemB * kAddrUnit, cmagic));
           const unsigned addr = __float_as_uint(a);
+          const lds_float* tp = (const lds_float*)(size_t)addr;
           if constexpr (kRaw) {
-            const lds_float* tp = (const lds_float*)(size_t)addr;
             q[j] = f4{tp[0], tp[1], tp[16], tp[17]};
           } else {
-            q[j] = *(const lds_float4*)(size_t)addr;
+            const lds_float* tp2 = tp + big_pitch;
+            q[j] = f4{tp[0], tp[1], tp2[0], tp2[1]};
           }
         }
 #pragma unroll
@@ -1467,7 +1474,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   const bool checkmax = c->views_carved + n_views > (int64_t)u.voxel_max_update_num;
   const dim3 grid((unsigned)nblocks);
   // Tile kind: footprint of an 8x8x8 wave brick in pixels ~ (8*sqrt(3)*pixels_per_voxel + 3)^2.  The raw
-  // 16 x 16 pixel tile covers voxels up to ~0.85 px; the quad tile filled in place up to ~1.4 px; wider
+  // 16 x 16 pixel tile covers voxels up to ~0.85 px; the 2048-pixel tile filled in place up to ~3 px; wider
   // footprints take the generic path inside the kernel either way.
   bool big = false;
   {

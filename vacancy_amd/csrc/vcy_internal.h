@@ -65,7 +65,7 @@ struct vcy_ctx {
   float* d_py = nullptr;
   float* d_pz = nullptr;
 
-  int tile_mode = 0;                  // 0 auto, 1 raw 16x16 pixel tile, 2 quad tile filled in place (vcy_set_param "tile")
+  int tile_mode = 0;                  // 0 auto, 1 the 16 x 16 pixel tile, 2 the 2048-pixel tile filled in place (vcy_set_param "tile")
   bool use_cull = true;               // vcy_set_param("cull", 0): never drop provably idle views
   // Views accepted by the per-view entry points (vcy_carve, vcy_carve_device, vcy_carve_silhouette) but
   // not applied yet: they are carved together, in order, by ONE fused launch when the state is next
