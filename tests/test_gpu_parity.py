@@ -175,11 +175,15 @@ def test_batch_equals_sequential():
 
 
 @pytest.mark.parametrize("kw", [dict(voxel_update=1, use_truncation=True), dict(voxel_update=1),
-                                dict(voxel_update=1, use_truncation=True, truncation_band=0.02), dict()])
+                                dict(voxel_update=1, use_truncation=True, truncation_band=0.02), dict(),
+                                dict(voxel_update=1, voxel_update_weight=0.37, use_truncation=True),
+                                dict(voxel_update=1, voxel_update_weight=2.25), dict(sdf_interp=0),
+                                dict(sdf_interp=0, voxel_update=1, use_truncation=True), dict(update_outside=1)])
 def test_select_free_loops_at_benchmark_footprints(kw):
     """The loops the benchmark runs in -- raw 16 x 16 tiles, first-touch stores, the update chains, the
     truncation test compiled out where the tile's lower bound allows it, brick-wide weights of the average
-    while all counts of a brick agree -- on a scene with the benchmark's sub-pixel voxel footprints
+    while all counts of a brick agree (unit and general weights), nearest-neighbour taps, update_outside = kMax
+    with its bound -- on a scene with the benchmark's sub-pixel voxel footprints
     (160^3 in 200 x 150 images), in two launches (the second starts from a carved, non-fresh state) and
     after an upload (update_num no longer implied by sdf), with view dropping on and off and with the quad
     tile instead of the raw one: state bit-identical to the oracle every time."""

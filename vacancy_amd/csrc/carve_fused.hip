@@ -670,7 +670,8 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
             }
           }
           // voxels projecting outside the ROI sample max_sdf instead (voxel_carver.cc:469-471)
-          if (outside_max) {
+          // (not in a `sure` tile: every sample of the brick lies inside it, hence inside the ROI)
+          if (outside_max && !ti.sure) {
             has_nan |= !(fabsf(v.max_sdf) <= 3.402823466e+38f);
             m = fmaxf(m, v.max_sdf);
           }
@@ -792,7 +793,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     ub_lane = brick_footprints<SAMEF, TQ, GEN>(views, nviews, lane, g.px[x_lo], g.px[x_hi], g.py[by * BY], g.py[y_hi],
                                                g.pz[g.z0 + zl0], g.pz[g.z0 + z_hi], mode.ortho != 0,
                                                mode.outside == VCY_OUTSIDE_MAX, want_bound,
-                                               want_bound && TRUNC && UPDATE == kUpdateWaUnitWeight, (lds_u32*)tinfo);
+                                               want_bound && TRUNC && UPDATE != VCY_UPDATE_MAX, (lds_u32*)tinfo);
   }
   wave_lds_fence();
 #ifdef VCY_PHASE_TIMING
@@ -864,7 +865,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   // n[] is only brought up to date when the brick leaves this state, and at the write-back.
   bool uniform_cnt = false;
   float fnu = 0.0f;  // the common update_num (as a float, like n[])
-  if (UPDATE == kUpdateWaUnitWeight) {
+  if (UPDATE != VCY_UPDATE_MAX) {
     if (fresh) {
       uniform_cnt = true;
     } else {
@@ -1025,8 +1026,12 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     //  - the two wave-uniform terms of that sum sit in VGPRs (back-to-back scalar operands halve the issue rate);
     //  - the update is a compare / select / carry chain through VCC (update_max_touched), or a plain store for
     //    a brick that has not been touched at all (FIRST).
-    constexpr bool kFastMax = !GEN && UPDATE == VCY_UPDATE_MAX && !TRUNC && !CHECKMAX;
-    constexpr bool kFastWa = !GEN && UPDATE == kUpdateWaUnitWeight && !CHECKMAX;
+    // (GEN kernels take them too when the camera is a pinhole one, i.e. for nearest-neighbour sampling: `sure`
+    // is never set for an orthographic view)
+    constexpr bool kFastMax = UPDATE == VCY_UPDATE_MAX && !TRUNC && !CHECKMAX;
+    constexpr bool kFastWa = UPDATE == kUpdateWaUnitWeight && !CHECKMAX;
+    // general weights: only the brick-wide flavour (UNIFORM) of the run, where the weights are formed once per view
+    constexpr bool kFastWaGeneral = UPDATE == VCY_UPDATE_WEIGHTED_AVERAGE && !CHECKMAX;
     // FIRST: no voxel of the brick has been touched yet (a fresh slab): the update is `sdf = dist, update_num = 1`
     // for every voxel (voxel_carver.cc:482-486), whatever the old value.
     // NOTRUNC: the prologue has proved that no sample of this tile is below -1 (TileInfo::sure bit 1): the
@@ -1038,11 +1043,17 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
       constexpr bool UNIFORM = decltype(uniform_tag)::value;
       // the brick's common weights, in VGPRs (uniform values; opaque to the compiler so that they are not
       // folded back into scalar operands): (fn * sdf + dist) * (1 / (fn + 1)), voxel_carver.cc:88-95
-      float fn_v = 0.0f, inv_v = 0.0f;
+      float fn_v = 0.0f, inv_v = 0.0f, wgt_v = 1.0f;
       if constexpr (UNIFORM) {
         const float f1 = fnu + 1.0f;
         asm volatile("v_mov_b32_e32 %0, %1" : "=v"(fn_v) : "s"(fnu));
-        inv_v = rcp_count(fn_v + 1.0f);
+        if constexpr (UPDATE == kUpdateWaUnitWeight) {
+          inv_v = rcp_count(fn_v + 1.0f);
+        } else {  // (w * n, w and 1 / (w * (n + 1)) of voxel_carver.cc:91-93)
+          asm volatile("v_mov_b32_e32 %0, %1" : "=v"(wgt_v) : "s"(g.weight));
+          inv_v = div_fast(1.0f, wgt_v * (fn_v + 1.0f));
+          fn_v = wgt_v * fn_v;
+        }
         fnu = f1;
       }
       // uniform -> VGPR (opaque to the compiler, which would otherwise fold them back into SGPR operands)
@@ -1093,15 +1104,22 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
         for (int j = 0; j < kGroup; ++j) {
           const int k = k0 + j;
           const float mu = 1.0f - lu[j], mv = 1.0f - lv[j];
-          const float dist =
+          float dist =
               ((((mu * mv) * q[j].x) + ((lu[j] * mv) * q[j].y)) + ((mu * lv[j]) * q[j].z)) + ((lu[j] * lv[j]) * q[j].w);
+          if constexpr (GEN) {
+            if (is_nn) {  // (uniform) SdfInterpolationNn, as in the checked loop above
+              const float top = lu[j] >= 0.5f ? q[j].y : q[j].x, bot = lu[j] >= 0.5f ? q[j].w : q[j].z;
+              dist = lv[j] >= 0.5f ? bot : top;
+            }
+          }
           if constexpr (FIRST) {
             s[k] = dist;
             n[k] = (NT)1;
           } else if constexpr (kFastMax) {
             update_max_touched(dist, s[k], n[k], took);
           } else if constexpr (UNIFORM) {
-            s[k] = (fn_v * s[k] + dist) * inv_v;
+            if constexpr (UPDATE == kUpdateWaUnitWeight) s[k] = (fn_v * s[k] + dist) * inv_v;
+            else s[k] = (fn_v * s[k] + wgt_v * dist) * inv_v;
           } else if constexpr (kFastWa) {
             update_wa_unit<TRUNC && !NOTRUNC>(dist, s[k], n[k]);
           }
@@ -1110,14 +1128,26 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
       return (kFastMax && !FIRST) ? took != 0ull : true;
     };
     bool brick_moved;
-    const int sure_bits = GEN ? 0 : __builtin_amdgcn_readfirstlane(tinfo[vi].sure);
+    const int sure_bits = (GEN && is_ortho) ? 0 : __builtin_amdgcn_readfirstlane(tinfo[vi].sure);
     const bool sure = (sure_bits & 1) != 0, never_truncated = (sure_bits & 2) != 0;
     // (Branch weights: the checked loops below are the rare ones in the kernels that have a select-free loop;
     // the register allocator then spills there, if anywhere, and not in the loops that do the work.)
-    constexpr bool kHasFast = kFastMax || kFastWa;
+    constexpr bool kHasFast = kFastMax || kFastWa || kFastWaGeneral;
     const bool fast_first = kFastMax && sure && none_touched;
     const bool fast_next = (kFastMax && sure && all_touched) || (kFastWa && sure && implied);
-    if (__builtin_expect_with_probability(fast_next, kHasFast, 0.9)) {
+    // general weights: every voxel updated by this view and all counts equal -- a first touch stores the sample
+    // (voxel_carver.cc:482-486), later views average with the brick's weights
+    const bool fast_general = kFastWaGeneral && sure && uniform_cnt && (!TRUNC || never_truncated);
+    if (kFastWaGeneral && __builtin_expect_with_probability(fast_general, 1, 0.9)) {
+      if (fnu < 1.0f) {
+        brick_moved = carve_view_fast(std::true_type{}, std::false_type{}, std::false_type{});
+        fnu = 1.0f;
+      } else {
+        brick_moved = carve_view_fast(std::false_type{}, std::true_type{}, std::true_type{});
+      }
+      VCY_PT(2);
+      VCY_PT_COUNT(7);
+    } else if (__builtin_expect_with_probability(fast_next, kHasFast && !kFastWaGeneral, 0.9)) {
       // weighted average: no truncation test when it cannot fire, and brick-wide weights while the counts agree
       const bool all_updated = kFastWa && (!TRUNC || never_truncated);
       if (kFastWa && all_updated && uniform_cnt) {
@@ -1367,7 +1397,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   if (need_bound) {
     size_t total = 0;
     // (two more planes, of the negated image, for the truncating unit-weight average: FusedView::has_lower)
-    const bool need_lower = u.use_truncation && u.voxel_update == VCY_UPDATE_WEIGHTED_AVERAGE && g.weight == 1.0f;
+    const bool need_lower = u.use_truncation && u.voxel_update == VCY_UPDATE_WEIGHTED_AVERAGE;
     const int planes = need_lower ? 2 * kWmaxPlanes : kWmaxPlanes;
     for (int vi = 0; vi < n_views; ++vi) total += ((size_t)planes * vp[vi].width * vp[vi].height + 3) & ~(size_t)3;
     if (c->wmax_bytes < total * sizeof(float)) {
