@@ -1,7 +1,7 @@
 """Long-running differential fuzz (not collected by pytest): benchmark-like geometry (40..90 voxels per
 side, 0.15..1.3 pixels per voxel, 3..11 views, smooth / noisy / silhouette SDFs, every update mode) carved
 as one context and as two z-slab contexts, against the oracle bit for bit.
-usage: python tests/fuzz/fuzz_fine_grids.py FIRST_SEED LAST_SEED   (round 1: seeds 0..1000 over the kernel versions of the round, 0 mismatches; round 2: seeds 0..800 on the final kernels, 0 mismatches)"""
+usage: python tests/fuzz/fuzz_fine_grids.py FIRST_SEED LAST_SEED [modes]   (round 1: seeds 0..1000 over the kernel versions of the round, 0 mismatches; round 2: seeds 0..1200, and 1200..1600 with the extra modes, on the final kernels: 0 mismatches)"""
 import sys, os, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -9,6 +9,7 @@ import oracle_lib as O
 from vacancy_amd import carver as vc, synth
 from vacancy_amd.capi import CarverOption, UpdateOption
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+extra_modes = len(sys.argv) > 3 and sys.argv[3] == "modes"  # also nearest neighbour, weights != 1, update limits
 bad = 0
 t0 = time.time()
 for seed in range(lo, hi):
@@ -19,8 +20,13 @@ for seed in range(lo, hi):
     half = dims * res / 2.0
     bb_min = (centre - half).astype(np.float32)
     bb_max = (bb_min + np.float32(res) * dims + np.float32(0.25)).astype(np.float32)
+    # (sampling, weight and update limit from their own stream, so that the scenes of a seed stay what they were)
+    rng2 = np.random.RandomState(9000 + seed)
     uo = UpdateOption(voxel_update=int(rng.randint(0, 2)), update_outside=int(rng.randint(0, 2)),
-                      use_truncation=bool(rng.randint(0, 2)), truncation_band=float(rng.choice([0.1, 0.35])))
+                      use_truncation=bool(rng.randint(0, 2)), truncation_band=float(rng.choice([0.1, 0.35])),
+                      sdf_interp=int(rng2.randint(0, 2)) if extra_modes else 1,
+                      voxel_update_weight=float(rng2.choice([1.0, 1.0, 0.5, 2.25])) if extra_modes else 1.0,
+                      voxel_max_update_num=int(rng2.choice([255, 255, 255, 3, 1000])) if extra_modes else 255)
     opt = CarverOption(bb_min=[float(x) for x in bb_min], bb_max=[float(x) for x in bb_max], resolution=res, update_option=uo)
     nviews = int(rng.randint(3, 12))
     extent = float(np.linalg.norm(half))

@@ -137,6 +137,37 @@ def test_orthographic_camera():
     assert_state_equal(dev, orc, "ortho")
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(voxel_update=1, use_truncation=True), dict(sdf_interp=0)])
+def test_orthographic_views_in_the_select_free_loops(kw):
+    """Orthographic cameras qualify for `sure` tiles too (no division; the only depth test is pc.z < 0): a grid
+    of 96^3 unit voxels seen by 8 orthographic views of 200 x 190 pixels (one voxel = one pixel), in one fused
+    launch, with view dropping on and off and with both tile kinds, against the oracle."""
+    n, nv, w, h = 96, 8, 200, 190
+    uo = UpdateOption(**kw)
+    opt = synth.sphere_option(n, uo)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    for v in views:
+        v.is_ortho = 1
+        v.w2c[3] += np.float32(w / 2)   # camera-space x, y are the pixel coordinates: centre the grid in the image
+        v.w2c[7] += np.float32(h / 2)
+    sdfs = [vc.make_sdf(m, use_truncation=bool(uo.use_truncation), band=uo.truncation_band) for m in masks]
+    orc = O.OracleGrid(opt)
+    for i in range(nv):
+        orc.carve(views[i], sdfs[i])
+    os_, ou = orc.download()
+    assert int((ou > 0).sum()) > n ** 3 // 2
+    for cull, tile in ((1, 0), (0, 1), (1, 2)):
+        dev = vc.VoxelCarver(opt)
+        assert dev.Init()
+        dev.set_param("cull", cull)
+        dev.set_param("tile", tile)
+        devs = [dev.upload_sdf(s_) for s_ in sdfs]
+        assert dev.CarveBatchDevice(views, devs), vc.last_error()
+        ds, du = dev.download()
+        assert np.array_equal(du, ou), (kw, cull, tile, int((du != ou).sum()))
+        assert np.array_equal(ds.view(np.uint32), os_.view(np.uint32)), (kw, cull, tile)
+
+
 def test_camera_inside_grid_and_behind():
     """voxels behind the camera (pc.z < 0), at pc.z == 0 and right at the camera."""
     n = 32

@@ -599,7 +599,10 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
         // (|16 base| < 2^22: the fast path forms LDS addresses in the float pipeline, carve_view_fast)
         const int pitch = kRaw ? 16 : tw + 1;  // pixels per tile row
         const bool small_base = ty0 * pitch + tx0 < (1 << 18);
-        ti.sure = (!ortho && unclipped && depth_ok && small_base) ? 1 : 0;
+        // orthographic: no division, and the only depth test is the reference's `pc.z < 0` skip
+        // (voxel_carver.cc:456): every computed pc.z of the brick is >= zmin - 2^-20 mag_z
+        const bool depth_ok_ortho = zmin > 0x1p-20f * mag[2];
+        ti.sure = (unclipped && (ortho ? depth_ok_ortho : depth_ok) && small_base) ? 1 : 0;
         ti.tx0 = tx0;
         ti.ty0 = ty0;
         ti.tw = tw;
@@ -1026,8 +1029,8 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     //  - the two wave-uniform terms of that sum sit in VGPRs (back-to-back scalar operands halve the issue rate);
     //  - the update is a compare / select / carry chain through VCC (update_max_touched), or a plain store for
     //    a brick that has not been touched at all (FIRST).
-    // (GEN kernels take them too when the camera is a pinhole one, i.e. for nearest-neighbour sampling: `sure`
-    // is never set for an orthographic view)
+    // (GEN kernels take them too: nearest-neighbour taps and orthographic projection are uniform branches
+    // inside the run)
     constexpr bool kFastMax = UPDATE == VCY_UPDATE_MAX && !TRUNC && !CHECKMAX;
     constexpr bool kFastWa = UPDATE == kUpdateWaUnitWeight && !CHECKMAX;
     // general weights: only the brick-wide flavour (UNIFORM) of the run, where the weights are formed once per view
@@ -1086,7 +1089,10 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
           const float qx = div_view<DIV>(v.fx, pcz);
           const float qy = SAMEF ? qx : div_view<DIV>(v.fy, pcz);
           const float pcx = v.t[0] + (c0[2 * k] + h12x), pcy = v.t[1] + (c0[2 * k + 1] + h12y);
-          const float u = qx * pcx + v.cx, w = qy * pcy + v.cy;
+          float u = qx * pcx + v.cx, w = qy * pcy + v.cy;
+          if constexpr (GEN) {
+            if (is_ortho) u = pcx, w = pcy;  // (uniform) camera.cc:201-205
+          }
           const float fu = floorf(u), fw = floorf(w);
           lu[j] = u - fu;
           lv[j] = w - fw;
@@ -1128,7 +1134,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
       return (kFastMax && !FIRST) ? took != 0ull : true;
     };
     bool brick_moved;
-    const int sure_bits = (GEN && is_ortho) ? 0 : __builtin_amdgcn_readfirstlane(tinfo[vi].sure);
+    const int sure_bits = __builtin_amdgcn_readfirstlane(tinfo[vi].sure);
     const bool sure = (sure_bits & 1) != 0, never_truncated = (sure_bits & 2) != 0;
     // (Branch weights: the checked loops below are the rare ones in the kernels that have a select-free loop;
     // the register allocator then spills there, if anywhere, and not in the loops that do the work.)
