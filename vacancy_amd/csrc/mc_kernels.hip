@@ -453,20 +453,30 @@ __global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restr
 // cell_list[i] = padded cell slot (word * 64 + bit).  The inverse map needs no array: the list index of
 // the active cell (word cw, bit b) is block_cell_offs[cw >> 8] + word_cell_off[cw] + popcount of the
 // active bits below b (list_index_of), three loads from arrays a few hundred times smaller than the grid.
+constexpr int kCompactBlocks = 16;
 __global__ __launch_bounds__(256) void mc_compact_kernel(McParams p, const u64* __restrict__ act,
                                                          const uint32_t* __restrict__ word_cell_off,
                                                          const u64* __restrict__ block_cell_offs,
+                                                         const u64* __restrict__ total_cells, int64_t nblocks,
                                                          u64* __restrict__ cell_list, int64_t capacity) {
-  const int64_t cw = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (cw >= p.nwords) return;
-  u64 a = act[cw];
-  if (!a) return;
-  int64_t i = (int64_t)block_cell_offs[blockIdx.x] + word_cell_off[cw];
-  while (a) {
-    const int b = __ffsll((long long)a) - 1;
-    a &= a - 1;
-    if (i < capacity) cell_list[i] = (u64)cell_slot(cw, b);  // (a list sized from the last extraction may be short)
-    ++i;
+  // A workgroup walks kCompactBlocks blocks of 256 words; most hold no active cell at all, which two offsets
+  // tell without touching the words (65 536 workgroups of one block each spent their time being dispatched).
+  for (int k = 0; k < kCompactBlocks; ++k) {
+    const int64_t blk = (int64_t)blockIdx.x * kCompactBlocks + k;
+    if (blk >= nblocks) return;
+    const u64 first = block_cell_offs[blk];
+    const u64 next = (blk + 1 < nblocks) ? block_cell_offs[blk + 1] : *total_cells;
+    if (next == first) continue;  // (uniform)
+    const int64_t cw = blk * 256 + threadIdx.x;
+    if (cw >= p.nwords) continue;
+    u64 a = act[cw];
+    int64_t i = (int64_t)first + word_cell_off[cw];
+    while (a) {
+      const int b = __ffsll((long long)a) - 1;
+      a &= a - 1;
+      if (i < capacity) cell_list[i] = (u64)cell_slot(cw, b);  // (a list sized from the last extraction may be short)
+      ++i;
+    }
   }
 }
 
@@ -987,7 +997,8 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   };
   // active cells -> list -> owner info + (vertices, triangles) per block -> offsets
   auto enqueue_owners = [&](const CellBuffers& b, int64_t cap_cells) -> int {
-    hipLaunchKernelGGL(mc_compact_kernel, dim3(nblocks), dim3(256), 0, s, p, d_act, d_woff, d_wcounts, b.list, cap_cells);
+    hipLaunchKernelGGL(mc_compact_kernel, dim3((nblocks + kCompactBlocks - 1) / kCompactBlocks), dim3(256), 0, s, p, d_act,
+                       d_woff, d_wcounts, d_total, (int64_t)nblocks, b.list, cap_cells);
     hipLaunchKernelGGL(mc_owner_kernel, dim3(b.blocks), dim3(256), 0, s, p, T, d_act, b.list, d_total, cap_cells, b.info,
                        b.counts);
     MC_TRY(hipGetLastError());
