@@ -1,7 +1,7 @@
 """Long-running differential fuzz (not collected by pytest): benchmark-like geometry (40..90 voxels per
 side, 0.15..1.3 pixels per voxel, 3..11 views, smooth / noisy / silhouette SDFs, every update mode) carved
 as one context and as two z-slab contexts, against the oracle bit for bit.
-usage: python tests/fuzz/fuzz_fine_grids.py FIRST_SEED LAST_SEED [modes]   (round 1: seeds 0..1000 over the kernel versions of the round, 0 mismatches; round 2: seeds 0..1200, and 1200..1600 with the extra modes, on the final kernels: 0 mismatches)"""
+usage: python tests/fuzz/fuzz_fine_grids.py FIRST_SEED LAST_SEED [modes]   (round 1: seeds 0..1000 over the kernel versions of the round, 0 mismatches; round 2: seeds 0..1200, and 1200..2500 with the extra modes, on the final kernels: 0 mismatches)"""
 import sys, os, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

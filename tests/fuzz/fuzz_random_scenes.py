@@ -1,6 +1,6 @@
 """Long-running differential fuzz (not collected by pytest): the random scenes of test_gpu_random.py
 for an arbitrary seed range, fused kernel with both tile sizes against the oracle.
-usage: python tests/fuzz/fuzz_random_scenes.py FIRST_SEED LAST_SEED   (round 1: seeds 100..4200 over the kernel versions of the round, 0 mismatches; round 2: seeds 0..1500 on the final kernels, 0 mismatches)"""
+usage: python tests/fuzz/fuzz_random_scenes.py FIRST_SEED LAST_SEED   (round 1: seeds 100..4200 over the kernel versions of the round, 0 mismatches; round 2: seeds 0..3000 on the final kernels, 0 mismatches)"""
 import sys, os, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -358,14 +358,27 @@ __device__ __forceinline__ bool neighbour_active(const McParams& p, const u64* _
 __device__ __forceinline__ int owned_edges(const McParams& p, const u64* __restrict__ act, int code, int li,
                                            int cy, int x) {
   const int cut = cut_edges(code);
+  // the ACT bits of the nine neighbour cells an edge can be shared with, requested together (cells outside
+  // the grid read word 0 and count as inactive), then pure bit logic
+  u64 aw[kNbrCount];
+  int bit[kNbrCount];
+#pragma unroll
+  for (int q = 0; q < kNbrCount; ++q) {
+    const int nl = li + kNbr[q][2], ncy = cy + kNbr[q][1], nxx = x + kNbr[q][0];
+    const bool there = nl >= 0 && ncy >= 0 && ncy < p.Y && nxx >= 1 && nxx < p.nx;
+    bit[q] = there ? (nxx & 63) : -1;
+    aw[q] = act[there ? word_index(p, nl, ncy, nxx >> 6) : 0];
+  }
+  int nactive = 0;
+#pragma unroll
+  for (int q = 0; q < kNbrCount; ++q) nactive |= (bit[q] >= 0 && ((aw[q] >> bit[q]) & 1ull)) ? (1 << q) : 0;
   int owned = 0;
 #pragma unroll
   for (int e = 0; e < 12; ++e) {
-    if (!(cut & (1 << e))) continue;
-    bool earlier = false;
-    for (int k = 0; k < kShare[e].n; ++k)
-      earlier |= neighbour_active(p, act, li, cy, x, kShare[e].d[k][0], kShare[e].d[k][1], kShare[e].d[k][2]);
-    if (!earlier) owned |= 1 << e;
+    int sharers = 0;
+#pragma unroll
+    for (int k = 0; k < kShare[e].n; ++k) sharers |= 1 << kShareNbr[e][k];
+    if ((cut & (1 << e)) && !(nactive & sharers)) owned |= 1 << e;
   }
   // a ghost cell only contributes vertices on the plane it shares with the slab (e4..e7)
   if (li == 0) owned &= 0xF0;
