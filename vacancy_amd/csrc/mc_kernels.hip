@@ -682,6 +682,8 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(McParams p, const McTables
     uint16_t prec[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) prec[e] = T->prec[code][e];
+    //     ... and its triangle row (16 edge numbers) as one 16-byte load
+    const uint4 trow = *reinterpret_cast<const uint4*>(&T->tri[code][0]);
     // (c) the neighbour cells that own the cut edges this cell does not: which of the nine exist and are
     //     active, their number in the cell list, their info word and their block's vertex offset.  Loads of
     //     neighbours that are not needed go to element 0 instead of being branched around, so that the three
@@ -786,7 +788,9 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(McParams p, const McTables
     // ---- triangles, marching_cubes.cc:199-218 (ghost cells have ntri == 0) -------------------------
     for (int t = 0; t < ntri; ++t) {
       for (int j = 0; j < 3; ++j) {
-        const int e = T->tri[code][3 * t + (2 - j)];
+        const int idx = 3 * t + (2 - j);
+        const uint32_t word = (idx < 4) ? trow.x : (idx < 8) ? trow.y : (idx < 12) ? trow.z : trow.w;
+        const int e = (int)((word >> (8 * (idx & 3))) & 0xFFu);
         int vid = -1;
 #pragma unroll
         for (int q = 0; q < 12; ++q) vid = (e == q) ? evid[q] : vid;
