@@ -384,7 +384,8 @@ __device__ __forceinline__ float wave_min(float v) {
 }
 
 // Fills a whole (big) tile in place: pixel (i, j) of the (tw + 1) x (th + 1) window = image pixel
-// (min(tx0 + i, roi_max.x), min(ty0 + j, roi_max.y)), lane q, q + 64, ...
+// (min(tx0 + i, roi_max.x), min(ty0 + j, roi_max.y)).  Every group of 64 consecutive tile pixels is one
+// LDS-direct request (lane L -> tile element 64 r + L); all requests are issued before the one wait.
 __device__ __forceinline__ void tile_fill(const ViewParams& v, const TileInfo& ti, int lane, float* tile) {
   const int nq = __builtin_amdgcn_readfirstlane(ti.nq);
   if (nq == 0) return;
@@ -394,11 +395,17 @@ __device__ __forceinline__ void tile_fill(const ViewParams& v, const TileInfo& t
   const float inv_pitch = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ti.inv_tw)));
   const int pitch = tw + 1, npx = pitch * (th + 1);
   gfloat_ptr img = (gfloat_ptr)v.sdf;
-  for (int q = lane; q < npx; q += 64) {
-    const int j = div_small(q, inv_pitch), i = q - j * pitch;
-    const int xx = min(tx0 + i, v.roi_max_xi), yy = min(ty0 + j, v.roi_max_yi);
-    tile[q] = img[(int64_t)v.width * yy + xx];
+  const unsigned width = (unsigned)v.width;
+  lds_float* dst = (lds_float*)tile;
+  for (int q0 = 0; q0 < npx; q0 += 64) {  // (uniform)
+    const int q = q0 + lane;
+    if (q < npx) {  // lanes beyond the window request nothing (and write nothing)
+      const int j = div_small(q, inv_pitch), i = q - j * pitch;
+      const unsigned xx = (unsigned)min(tx0 + i, v.roi_max_xi), yy = (unsigned)min(ty0 + j, v.roi_max_yi);
+      __builtin_amdgcn_global_load_lds(img + (__umul24(width, yy) + xx), dst + q0, 4, 0, 0);
+    }
   }
+  raw_tile_wait();
 }
 
 // ---- window maxima (FusedView::wmax) --------------------------------------------------------
