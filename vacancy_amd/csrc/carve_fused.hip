@@ -49,7 +49,7 @@ constexpr int kWgWaves = 4;
 constexpr int BX = 8 * kWgWaves, BY = 8, BZ = 8;  // voxels per workgroup: kWgWaves 8x8x8 wave bricks along x
 constexpr int WX = 8;                    // wave brick is WX x BY x BZ, lane = (y & 7) | (z << 3), WX voxels per lane
 constexpr int kMaxFusedViews = 64;         // one prologue lane per view
-// Raw-pixel tile (the default for footprints up to 15 x 15 quads): 16 x 16 pixels of the image, pitch 16, 1 KB.
+// Raw-pixel tile (the default: footprints up to 15 x 15 taps): 16 x 16 pixels of the image, pitch 16, 1 KB.
 // The pixels go from global memory straight into LDS (global_load_lds_dword: lane L of the r-th load
 // writes dword 64 r + L, i.e. pixel (L & 15, 4 r + (L >> 4))), two tiles per wave so that the next live
 // view's footprint arrives while the current one is sampled -- no staging registers, no LDS stores, one
@@ -60,8 +60,9 @@ constexpr int kTileRaw = 16;
 constexpr int kRawBuffers = 2;
 template <int TQ>
 constexpr int tile_f4_per_wave() { return TQ == kTileRaw ? kRawBuffers * 64 : TQ; }  // LDS of one wave, in float4
-// The big tile: 8 KB per wave = 2048 raw pixels, pitch = width of the footprint, filled in place by ordinary
-// loads (footprints up to ~44 x 44 pixels, voxels up to ~3 px); the second tap row is one address add away.
+// The big tile: 8 KB per wave = 2048 raw pixels, pitch = width of the footprint, filled in place by LDS-direct
+// loads (tile_fill; footprints up to ~44 x 44 pixels, voxels up to ~3 px); the second tap row is one address
+// add away.
 constexpr int kTileBig = 512;            // (in float4 units)
 constexpr int kBigPixels = 4 * kTileBig;
 
@@ -72,7 +73,7 @@ constexpr int kWmaxPlanes = 2;           // window sizes 4 and 8
 #define VCY_FAST_GROUP 4   // voxels whose LDS reads are in flight together
 #endif
 // Waves per SIMD the kernels are compiled for (register budget 512 / waves).  The kernels whose work is done by
-// the select-free loop (raw tiles, pinhole + bilinear, no update_num limit in reach) need 57-59 VGPRs there; what
+// the select-free loop (raw tiles, no update_num limit in reach) need 57-59 VGPRs there; what
 // wants more is the checked loop with its call of the generic sampler, which those kernels rarely enter.  They
 // are compiled for 7 waves (72 VGPRs: a handful of spills, placed in the rare blocks by the branch weights at
 // the loop selection; 8 waves spill in the tile staging as well and lose 15 %).  The others keep 5.
