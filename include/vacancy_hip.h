@@ -261,9 +261,12 @@ int vcy_reset(vcy_ctx* ctx);
  * "shortdiv" (default 1): fx / z in the fused kernel may use a 4- or 6-instruction sequence instead of
  * the full IEEE expansion, but only after the library has checked on the device, for each focal length
  * in use, that the sequence equals IEEE division for EVERY admissible depth (all 2^23 significands in 121
- * binades, about a millisecond once per focal length per process). */
+ * binades, about a millisecond once per focal length per process).
+ * "mcsweep" (default 1): vcy_extract_iso finds the surface cells in one sweep over the state with the bit
+ * planes in LDS when a voxel row is a power-of-two number of 64-voxel words (nx = 64 ... 2048); 0 forces the
+ * path every other shape takes (bit planes in memory, two passes). */
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
-/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv"), or "div_level": the division sequence
+/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep"), or "div_level": the division sequence
  * the last fused launch was instantiated with (2: 4 instructions, 1: 6, 0: full IEEE expansion). */
 int vcy_get_param(vcy_ctx* ctx, const char* name, int* value);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all launches. */

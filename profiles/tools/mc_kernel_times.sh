@@ -1,0 +1,37 @@
+#!/bin/bash
+# Runs ON the GPU box: per-kernel times (rocprofv3 --kernel-trace --stats) of marching cubes at 1024^3 for each
+# build named on the command line ("prod" = vacancy_amd/csrc/libvacancy_hip.so); MCSWEEP=0 for the bit-plane path.
+R=$(pwd -P); O=$R/gpurun_out/mck; mkdir -p $O
+cat > /tmp/mc_drive.py <<'PY'
+import os, sys
+sys.path.insert(0, os.environ["VCY_ROOT"])
+from vacancy_amd import synth
+from vacancy_amd import carver as vc
+from vacancy_amd.capi import UpdateOption
+n, nv = 1024, 32
+opt = synth.sphere_option(n, UpdateOption())
+views, masks = synth.sphere_views(n, nv, 1280, 720)
+sdf0 = vc.make_sdf(masks[0])
+c = vc.VoxelCarver(opt)
+assert c.Init()
+d = [c.upload_sdf(sdf0)] * nv
+assert c.CarveBatchDevice(vc.VoxelCarver.prepare_batch(views, d))
+c.set_param("mcsweep", int(os.environ.get("MCSWEEP", "1")))
+for it in range(6):
+    m = c.ExtractIsoSurface(0.0, True)
+print("device_ms", m["device_ms"], "faces", len(m["faces"]))
+PY
+cd /tmp; export TMPDIR=/tmp
+for v in "$@"; do
+  lib=$R/build/variants/$v/libvacancy_hip.so
+  [ "$v" = "prod" ] && lib=$R/vacancy_amd/csrc/libvacancy_hip.so
+  VCY_ROOT=$R VCY_HIP_LIB=$lib rocprofv3 --kernel-trace --stats -d $O -o $v --output-format csv -- python /tmp/mc_drive.py > $O/$v.log 2>&1
+  echo "== $v: $(grep device_ms $O/$v.log)"
+  python - $O/${v}_kernel_stats.csv <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Name"]
+    if "mc_" in n or "scan" in n or "chunk" in n:
+        print("   %-28s calls %4s  avg %9.1f us  min %9.1f" % (n.split("(")[0].split("::")[-1][:28], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
+PY
+done

@@ -328,6 +328,48 @@ def test_marching_cubes_random_state():
                               "random iso=%s interp=%s" % (iso, interp))
 
 
+@pytest.mark.parametrize("dims", [(64, 23, 29), (128, 70, 37), (256, 67, 12), (512, 40, 19), (1024, 70, 11),
+                                  (2048, 35, 4)])
+def test_marching_cubes_one_sweep_and_bit_plane_paths(dims):
+    """Rows of 1, 2, 4 ... 32 whole 64-voxel words take the one-sweep cell search (mc_sweep_kernel: bit planes in
+    LDS, several row groups and z chunks per grid at these sizes); "mcsweep" 0 sends the same state through the
+    bit planes in memory.  Both against the oracle on uploaded state (update_num is read) and on carved state
+    (it is not), for an iso level that is a float and one that is not."""
+    rng = np.random.RandomState(dims[0] + dims[2])
+    half = tuple(0.5 * d for d in dims)
+    opt = vc.CarverOption(bb_min=tuple(-v for v in half), bb_max=half, resolution=1.0)
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init(), vc.last_error()
+    orc = O.OracleGrid(opt)
+    assert dev.dims == orc.dims == dims
+    # carved state: a few views of a ball around the origin that cuts through the box
+    nv, w, h = 3, 160, 120
+    views, masks = synth.sphere_views(max(dims), nv, w, h)
+    for i in range(nv):
+        sdf = vc.make_sdf(masks[i])
+        assert dev.Carve(views[i], sdf)
+        orc.carve(views[i], sdf)
+    for sweep in (1, 0):
+        dev.set_param("mcsweep", sweep)
+        assert_mesh_equal(dev.ExtractIsoSurface(0.0, True), orc.marching_cubes(0.0, True), "carved sweep=%d" % sweep)
+    # arbitrary state
+    nvox = orc.n
+    sdf = rng.uniform(-1, 1, nvox).astype(np.float32)
+    smooth = rng.rand(nvox) < 0.7  # long runs of equal sign as well as noise
+    x = np.arange(nvox) % dims[0]
+    sdf[smooth] = (np.sin(x * 0.05) * 0.9 + 0.05).astype(np.float32)[smooth]
+    sdf[rng.rand(nvox) < 0.02] = np.finfo(np.float32).min
+    cnt = (rng.rand(nvox) < 0.97).astype(np.int32)
+    dev.upload(sdf, cnt)
+    orc.upload(sdf, cnt)
+    for iso, interp in ((0.0, True), (0.3, False)):
+        ref = orc.marching_cubes(iso, interp)
+        assert len(ref["faces"]) > 0
+        for sweep in (1, 0):
+            dev.set_param("mcsweep", sweep)
+            assert_mesh_equal(dev.ExtractIsoSurface(iso, interp), ref, "uploaded sweep=%d iso=%s" % (sweep, iso))
+
+
 def test_extract_voxel_predicates_on_adversarial_state():
     """ExtractVoxel's keep predicates run on the device (extract_voxel.hip): both of them on uploaded state
     with zeros of either sign, denormals, products that underflow to -0 or to the smallest denormal,
@@ -419,13 +461,14 @@ def test_cpp_bunny_example(tmp_path):
     assert open(os.path.join(str(tmp_path), "surface_00005.ply")).read() == expected
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_z_slab_sharding_on_one_gpu(world):
+@pytest.mark.parametrize("world,n", [(2, 44), (3, 44), (2, 64), (3, 64)])
+def test_z_slab_sharding_on_one_gpu(world, n):
     """The multi-GPU path with every 'rank' as its own context on cuda:0: slab carve (no
     exchange), halo pack -> (host all-gather stand-in) -> unpack, per-slab extraction with the
-    ghost layer, host merge == the single-context mesh == the oracle, array for array."""
+    ghost layer, host merge == the single-context mesh == the oracle, array for array.  n = 64: rows of
+    whole words, i.e. the one-sweep cell search (ghost layer, halo slices whose update_num is read)."""
     from vacancy_amd import dist as vdist
-    n, nv, w, h = 44, 5, 128, 96
+    nv, w, h = 5, 128, 96
     opt = synth.sphere_option(n)
     views, masks = synth.sphere_views(n, nv, w, h)
     sdfs = [vc.make_sdf(m) for m in masks]

@@ -30,6 +30,7 @@
 // update_num, everything else is 1 bit per voxel/cell, plus 12 B per vertex/triangle out.
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "vcy_internal.h"
@@ -109,7 +110,9 @@ __device__ const int8_t kShareNbr[12][3] = {{0, 1, 2}, {1, 3, 0}, {1, 4, 0}, {5,
 
 // Cell (x, y, z) is named by its max corner; bit b of word w of a row is x = 64*w + b.
 // Cell rows: layer li = 0 is the ghost layer (z = zc0-1), li = l+1 the slab's own layer l;
-// word index of (li, cy = y-1, w):  li == 0 ? cy*Wr + w : G + ((li-1)*Y + cy)*Wr + w,
+// word index of (li, cy = y-1, w):  li == 0 ? cy*Wr + w : G + ((li-1)*Yc + cy)*Wr + w,
+// Yc >= Y = rows a layer takes in the cell-word arrays (the sweep pads a layer to whole row groups, so that
+// a group is a whole number of 256-word blocks; padding rows hold no active cell),
 // G = ghost words rounded up to a whole block so that own cells start on a block boundary.
 // Exact n / d for 32-bit unsigned n (Granlund-Montgomery): three integer instructions instead of the
 // long 64-bit division sequence.
@@ -130,15 +133,16 @@ struct McParams {
   int nslices;        // stored voxel slices
   int Wr;             // 64-bit words per row
   int Y;              // cell rows per layer = ny-1
+  int Yc;             // rows per layer in the cell-word arrays (>= Y)
   int L;              // own cell layers
   int zc0;            // global z of own layer 0
   int zs0;            // global z of stored slice 0
   int has_ghost;
   int64_t G;          // words reserved for the ghost layer
-  int64_t nwords;     // G + L*Y*Wr
+  int64_t nwords;     // G + L*Yc*Wr
   double iso;
   int linear;
-  FastDiv div_row, div_layer;  // by Wr and by Y * Wr; used when small32 (every word index < 2^32)
+  FastDiv div_row, div_layer;  // by Wr and by Yc * Wr; used when small32 (every word index < 2^32)
   int small32;
 };
 
@@ -231,7 +235,7 @@ __device__ __forceinline__ bool decode_word(const McParams& p, int64_t cw, int* 
   if (p.small32) {
     uint32_t r;
     if (cw < p.G) {
-      if (cw >= (int64_t)p.Y * p.Wr) return false;  // padding
+      if (cw >= (int64_t)p.Yc * p.Wr) return false;  // padding
       *li = 0;
       r = (uint32_t)cw;
     } else {
@@ -243,26 +247,26 @@ __device__ __forceinline__ bool decode_word(const McParams& p, int64_t cw, int* 
     const uint32_t row = fast_div(r, p.div_row);
     *cy = (int)row;
     *w = (int)(r - row * p.div_row.d);
-    return true;
+    return *cy < p.Y;  // (rows Y .. Yc-1 are padding)
   }
   int64_t r;
   if (cw < p.G) {
-    if (cw >= (int64_t)p.Y * p.Wr) return false;  // padding
+    if (cw >= (int64_t)p.Yc * p.Wr) return false;  // padding
     *li = 0;
     r = cw;
   } else {
     const int64_t q = cw - p.G;
-    const int64_t layer = q / ((int64_t)p.Y * p.Wr);
+    const int64_t layer = q / ((int64_t)p.Yc * p.Wr);
     *li = (int)layer + 1;
-    r = q - layer * ((int64_t)p.Y * p.Wr);
+    r = q - layer * ((int64_t)p.Yc * p.Wr);
   }
   *cy = (int)(r / p.Wr);
   *w = (int)(r - (int64_t)(*cy) * p.Wr);
-  return true;
+  return *cy < p.Y;
 }
 
 __device__ __forceinline__ int64_t word_index(const McParams& p, int li, int cy, int w) {
-  return (li == 0 ? 0 : p.G + (int64_t)(li - 1) * p.Y * p.Wr) + (int64_t)cy * p.Wr + w;
+  return (li == 0 ? 0 : p.G + (int64_t)(li - 1) * p.Yc * p.Wr) + (int64_t)cy * p.Wr + w;
 }
 
 // padded per-cell index (info array)
@@ -459,6 +463,231 @@ __global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restr
     const int off = block_exclusive_scan(__popcll(a), &total, sm);
     if (cw < p.nwords) word_cell_off[cw] = (uint32_t)off;
     if (threadIdx.x == 0 && lb < nblocks) block_cells[lb] = (u64)(unsigned)total;
+  }
+}
+
+// ---- passes 0 + 1 in one sweep: the bit planes never reach memory ------------------------------------
+// Taken when a voxel row is a power-of-two number of whole words (nx = 64, 128 ... 2048).  A workgroup owns R
+// cell rows (R * Wr = K whole 256-word blocks) and walks `layers` cell layers in z.  Per step its four waves turn
+// the R + 1 voxel rows of the next slice into IN / OK (/ TC) words in LDS -- sixteen requests in flight per lane,
+// then the ballots, as in mc_bits -- and every thread evaluates its K cell words from the words of this slice and
+// of the one before (LDS holds two slices).  What goes to memory is what the later passes read: ACT, the offsets
+// per word and per block, and the IN words around ACTIVE cells (case_at reads nothing else of that plane: the
+// sparse 32-byte sectors of the surface instead of two dense planes written and read back).  The state is read
+// once plus the row shared by two row groups (1 / R) and the slice shared by two z chunks (1 / layers).
+struct SweepParams {
+  int R;           // cell rows per workgroup
+  int K;           // 256-word blocks per step = R * Wr / 256
+  int groups;      // row groups per layer = Yc / R
+  int layers;      // cell layers per workgroup
+  int dl;          // cells whose max corner lies in stored slice s form layer li = s + dl
+  int cnt_slices;  // READS_CNT: update_num is read for the stored slices below this one
+  int wshift;      // log2 Wr
+};
+constexpr int kSweepMaxK = 4;
+constexpr int kSweepBatch = 16;
+#ifndef VCY_SWEEP_SETS
+#define VCY_SWEEP_SETS 2
+#endif
+constexpr int kSweepSets = VCY_SWEEP_SETS;  // register sets of kSweepBatch requests in flight per wave
+#ifndef VCY_SWEEP_TARGET_WGS
+#define VCY_SWEEP_TARGET_WGS 1024
+#endif
+
+// lane K of the result = the scalar `sval`, the other lanes keep `old` (the lane select must be an immediate: a
+// second scalar register would be a second constant-bus operand)
+template <int K>
+__device__ __forceinline__ uint32_t write_lane(uint32_t sval, uint32_t old) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "n"(K));
+  return old;
+}
+template <typename F, int... Ks>
+__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, Ks...>) {
+  (f(std::integral_constant<int, Ks>{}), ...);
+}
+
+template <typename CountT, bool ISO_F32, bool READS_CNT, int KMAX>
+__global__ __launch_bounds__(256) void mc_sweep_kernel(McParams p, SweepParams q, u64* __restrict__ act,
+                                                       uint32_t* __restrict__ word_cell_off,
+                                                       u64* __restrict__ block_cells, u64* __restrict__ in_plane) {
+  extern __shared__ u64 planes[];  // [2 slices][IN, OK (, TC)][(R + 1) * Wr]
+  __shared__ int sm[2][KMAX][4];
+  constexpr int kPlanes = READS_CNT ? 3 : 2;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Wr = p.Wr;
+  const int plane_words = (q.R + 1) * Wr;
+  // XCD-aware order (workgroup b runs on XCD b % 8): neighbouring row groups of one z chunk -- they share a
+  // voxel row per slice -- run on the same XCD at about the same time
+  int64_t lg = blockIdx.x;
+  {
+    const int64_t per = gridDim.x >> 3;
+    if (lg < per * 8) lg = (lg & 7) * per + (lg >> 3);
+  }
+  const int chunk = (int)(lg / q.groups);
+  const int cy0 = (int)(lg - (int64_t)chunk * q.groups) * q.R;
+  const int li_a = chunk * q.layers;
+  const int li_b = min(li_a + q.layers, p.L + 1);
+
+  // Voxel rows cy0 .. cy0 + R of a stored slice -> plane words of LDS buffer (slice & 1).  Each wave takes a
+  // quarter of the slice's words in batches of kSweepBatch, and the slices a workgroup needs are consecutive, so
+  // the batches form ONE sequence per wave across the steps: two batches are always requested ahead (register
+  // sets A and B), also over the barriers and the cell evaluation of a step.
+  // (rows cy0 .. cy0 + R of a slice are contiguous in memory: word u of the group starts 64 u voxels after the
+  // group's first voxel; words of rows beyond the grid are not requested and read as "outside, invalid")
+  const int per_wave = (plane_words + 3) >> 2;
+  const int nb = ((per_wave + kSweepBatch - 1) / kSweepBatch + kSweepSets - 1) / kSweepSets * kSweepSets;  // batches per wave and slice
+  const int ubase = wave * per_wave;
+  const int uend = min(min(ubase + per_wave, plane_words), (p.ny - cy0) * Wr);
+  const bool first_has_cells = li_a >= 1 || p.has_ghost;
+  const int s_first = li_a - q.dl - ((first_has_cells && li_a - q.dl >= 1) ? 1 : 0);
+  const int s_last = li_b - 1 - q.dl;  // (<= nslices - 1 since li <= L)
+  int rq_s = s_first, rq_j = 0;        // the next batch to request
+  auto request = [&](float (&sv)[kSweepBatch], int (&nv)[kSweepBatch]) {
+    // No branch around a request: words that do not exist (beyond the wave's share, the grid or the last slice)
+    // read the group's first word instead and are masked in `ballots` -- with a single path the compiler counts
+    // the outstanding requests exactly and waits for the older register set only.
+    const int sl = min(rq_s, s_last);
+    const int u0 = ubase + rq_j * kSweepBatch;
+    const bool cnt_here = READS_CNT && sl < q.cnt_slices;
+    const float* __restrict__ ps = p.sdf + ((int64_t)sl * p.ny + cy0) * p.nx + lane;
+    const CountT* __restrict__ pc = (const CountT*)p.cnt + ((int64_t)sl * p.ny + cy0) * p.nx + lane;
+#pragma unroll
+    for (int k = 0; k < kSweepBatch; ++k) {
+      const int u = u0 + k < uend ? u0 + k : 0;  // (scalar)
+      sv[k] = __builtin_nontemporal_load(ps + (int64_t)u * 64);  // (ordinary loads: the extraction 8 % slower)
+      nv[k] = 1;
+      if (cnt_here) nv[k] = (int)pc[(int64_t)u * 64];
+    }
+    if (++rq_j == nb) rq_j = 0, ++rq_s;
+  };
+  auto ballots = [&](int s, int j, const float (&sv)[kSweepBatch], const int (&nv)[kSweepBatch]) {
+    u64* __restrict__ dst = planes + (size_t)(s & 1) * kPlanes * plane_words;
+    const int u0 = ubase + j * kSweepBatch;
+    if (u0 >= min(ubase + per_wave, plane_words)) return;
+    // word k of the batch goes to lane k (v_writelane: the ballot is a scalar)
+    uint32_t in_lo = 0, in_hi = 0, ok_lo = 0, ok_hi = 0, tc_lo = 0, tc_hi = 0;
+    static_for([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const bool there = u0 + k < uend;
+      // (comparisons as in mc_bits_kernel)
+      const u64 a = __ballot(there && (ISO_F32 ? sv[k] < (float)p.iso : (double)sv[k] < p.iso));
+      const u64 b = __ballot(there && sv[k] != kInvalidSdf);
+      in_lo = write_lane<k>((uint32_t)a, in_lo);
+      in_hi = write_lane<k>((uint32_t)(a >> 32), in_hi);
+      ok_lo = write_lane<k>((uint32_t)b, ok_lo);
+      ok_hi = write_lane<k>((uint32_t)(b >> 32), ok_hi);
+      if (READS_CNT) {
+        const u64 c = __ballot(nv[k] >= 1);
+        tc_lo = write_lane<k>((uint32_t)c, tc_lo);
+        tc_hi = write_lane<k>((uint32_t)(c >> 32), tc_hi);
+      }
+    }, std::make_integer_sequence<int, kSweepBatch>{});
+    const u64 m_in = ((u64)in_hi << 32) | in_lo, m_ok = ((u64)ok_hi << 32) | ok_lo, m_tc = ((u64)tc_hi << 32) | tc_lo;
+    if (lane < kSweepBatch && u0 + lane < min(ubase + per_wave, plane_words)) {
+      dst[u0 + lane] = m_in;
+      dst[plane_words + u0 + lane] = m_ok;
+      if (READS_CNT) dst[2 * plane_words + u0 + lane] = m_tc;
+    }
+  };
+  float sa[kSweepBatch], sb[kSweepBatch], sc[kSweepBatch];
+  int na[kSweepBatch], nbb[kSweepBatch], nc[kSweepBatch];
+  request(sa, na);
+  request(sb, nbb);
+  if (kSweepSets == 3) request(sc, nc);
+  auto fill = [&](int s) {
+    for (int j = 0; j < nb; j += kSweepSets) {
+      ballots(s, j, sa, na);
+      request(sa, na);
+      ballots(s, j + 1, sb, nbb);
+      request(sb, nbb);
+      if (kSweepSets == 3) {
+        ballots(s, j + 2, sc, nc);
+        request(sc, nc);
+      }
+    }
+  };
+
+  if (s_first < li_a - q.dl) fill(s_first);
+  for (int li = li_a; li < li_b; ++li) {
+    const int s = li - q.dl;  // stored slice of the max corners
+    const bool cells = (li >= 1 || p.has_ghost) && s >= 1;
+    fill(s);
+    __syncthreads();
+    const u64* __restrict__ cur = planes + (size_t)(s & 1) * kPlanes * plane_words;
+    const u64* __restrict__ prv = planes + (size_t)((s & 1) ^ 1) * kPlanes * plane_words;
+    const int par = li & 1;
+    const int64_t cw0 = word_index(p, li, cy0, 0);
+    int excl[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      excl[k] = 0;
+      if (k < q.K) {
+        const int i = k * 256 + threadIdx.x;
+        const int row = i >> q.wshift, w = i & (Wr - 1);
+        u64 m = 0;
+        if (cells && cy0 + row < p.Y) {
+          // voxel rows y-1 (r0) and y (r1) of slices z-1 (prv) and z (cur); corner order of load_cell_in
+          const int r0 = row * Wr + w, r1 = r0 + Wr;
+          const u64 i00 = prv[r0], i10 = prv[r1], i01 = cur[r0], i11 = cur[r1];
+          u64 b00 = 0, b10 = 0, b01 = 0, b11 = 0;  // the words before (for x - 1 of bit 0)
+          if (w > 0) b00 = prv[r0 - 1], b10 = prv[r1 - 1], b01 = cur[r0 - 1], b11 = cur[r1 - 1];
+          const u64 s00 = (i00 << 1) | (b00 >> 63), s10 = (i10 << 1) | (b10 >> 63);
+          const u64 s01 = (i01 << 1) | (b01 >> 63), s11 = (i11 << 1) | (b11 >> 63);
+          const u64 all = i00 & i10 & i01 & i11 & s00 & s10 & s01 & s11;
+          const u64 any = i00 | i10 | i01 | i11 | s00 | s10 | s01 | s11;
+          m = any & ~all;  // kEdgeTable[cube] != 0 (:131-133)
+          if (w == 0) m &= ~1ull;  // x = 0 is not a cell
+          if (m) {
+            // corner 6 touched (:88-90), no corner invalid (:103-112)
+            const u64* __restrict__ okp = prv + plane_words;
+            const u64* __restrict__ okc = cur + plane_words;
+            const u64 o00 = okp[r0], o10 = okp[r1], o01 = okc[r0], o11 = okc[r1];
+            u64 v = o00 & o10 & o01 & o11;
+            u64 p00 = ~0ull, p10 = ~0ull, p01 = ~0ull, p11 = ~0ull;
+            if (w > 0) p00 = okp[r0 - 1], p10 = okp[r1 - 1], p01 = okc[r0 - 1], p11 = okc[r1 - 1];
+            v &= ((o00 << 1) | (p00 >> 63)) & ((o10 << 1) | (p10 >> 63)) & ((o01 << 1) | (p01 >> 63)) &
+                 ((o11 << 1) | (p11 >> 63));
+            if (READS_CNT) v &= cur[2 * plane_words + r1];
+            m &= v;
+          }
+          if (m) {
+            const int64_t g11 = ((int64_t)s * p.ny + (cy0 + row + 1)) * Wr + w;
+            const int64_t g01 = g11 - Wr, g10 = g11 - (int64_t)p.ny * Wr, g00 = g10 - Wr;
+            in_plane[g00] = i00;
+            in_plane[g10] = i10;
+            in_plane[g01] = i01;
+            in_plane[g11] = i11;
+            if ((m & 1ull) && w > 0) {
+              in_plane[g00 - 1] = b00;
+              in_plane[g10 - 1] = b10;
+              in_plane[g01 - 1] = b01;
+              in_plane[g11 - 1] = b11;
+            }
+          }
+        }
+        act[cw0 + i] = m;
+        const int pc = __popcll(m);
+        const int inc = wave_inclusive_scan(pc);
+        excl[k] = inc - pc;
+        if (lane == 63) sm[par][k][wave] = inc;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < q.K) {
+        int base = 0, tot = 0;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+          const int t = sm[par][k][w4];
+          if (w4 < wave) base += t;
+          tot += t;
+        }
+        const int64_t cw = cw0 + k * 256 + threadIdx.x;
+        word_cell_off[cw] = (uint32_t)(base + excl[k]);
+        if (threadIdx.x == 0) block_cells[cw >> 8] = (u64)(unsigned)tot;
+      }
+    }
   }
 }
 
@@ -848,9 +1077,26 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   p.linear = linear_interp;
   c->last_extract_device_ms = 0.0f;
   if (c->nx < 2 || p.Y <= 0 || p.L <= 0) return VCY_OK;  // no cells (reference loops do not run)
-  const int64_t ghost_words = (int64_t)p.Y * p.Wr;
+  // one sweep (mc_sweep_kernel) when a voxel row is a power-of-two number of whole words, else bit planes in
+  // memory (mc_bits + mc_active); "mcsweep" 0 forces the latter
+  const bool sweep = c->mc_sweep && c->nx == p.Wr * 64 && (p.Wr & (p.Wr - 1)) == 0 && p.Wr <= 32;
+  SweepParams q{};
+  p.Yc = p.Y;
+  if (sweep) {
+    q.R = std::max(32, kWordsPerBlock / p.Wr);
+    q.K = q.R * p.Wr / kWordsPerBlock;  // <= kSweepMaxK
+    p.Yc = (p.Y + q.R - 1) / q.R * q.R;
+    q.groups = p.Yc / q.R;
+    // enough workgroups to fill the GPU, few enough that the slice two z chunks share stays a small part
+    const int64_t want = ((int64_t)(p.L + 1) * q.groups + VCY_SWEEP_TARGET_WGS - 1) / VCY_SWEEP_TARGET_WGS;
+    q.layers = (int)std::min<int64_t>(std::max<int64_t>(want, 8), 64);
+    q.dl = p.zs0 - p.zc0 + 1;
+    q.cnt_slices = c->cnt_implied ? c->halo_lo : p.nslices;
+    while ((1 << q.wshift) < p.Wr) ++q.wshift;
+  }
+  const int64_t ghost_words = (int64_t)p.Yc * p.Wr;
   p.G = (ghost_words + kWordsPerBlock - 1) / kWordsPerBlock * kWordsPerBlock;
-  p.nwords = p.G + (int64_t)p.L * p.Y * p.Wr;
+  p.nwords = p.G + (int64_t)p.L * p.Yc * p.Wr;
   {
     auto make_div = [](uint32_t d) {
       FastDiv f;
@@ -862,9 +1108,9 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
       f.s2 = l < 1 ? 0 : l - 1;
       return f;
     };
-    p.small32 = p.nwords < 0xffffffffLL && (int64_t)p.Y * p.Wr < 0x7fffffffLL ? 1 : 0;
+    p.small32 = p.nwords < 0xffffffffLL && (int64_t)p.Yc * p.Wr < 0x7fffffffLL ? 1 : 0;
     p.div_row = make_div((uint32_t)p.Wr);
-    p.div_layer = make_div(p.small32 ? (uint32_t)((int64_t)p.Y * p.Wr) : 1u);
+    p.div_layer = make_div(p.small32 ? (uint32_t)((int64_t)p.Yc * p.Wr) : 1u);
   }
   const int64_t nblocks64 = (p.nwords + kWordsPerBlock - 1) / kWordsPerBlock;
   const int64_t vox_rows = (int64_t)p.nslices * c->ny;
@@ -892,7 +1138,7 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   const size_t sz_woff = align(sizeof(uint32_t) * (size_t)p.nwords);
   const size_t sz_counts = align(sizeof(u64) * ((size_t)nblocks + 1));
   const size_t sz_scan = align(sizeof(u64) * ((size_t)nblocks / 1024 + 64) * 2);
-  const size_t need = 3 * sz_plane + sz_act + sz_woff + sz_counts + sz_scan + 256;
+  const size_t need = (sweep ? 1 : 3) * sz_plane + sz_act + sz_woff + sz_counts + sz_scan + 256;
   if (c->mc_scratch_bytes < need) {
     VCY_HIP_CHECK(hipStreamSynchronize(s));
     if (c->d_mc_scratch) VCY_HIP_CHECK(hipFree(c->d_mc_scratch));
@@ -903,8 +1149,8 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   }
   char* base = (char*)c->d_mc_scratch;
   u64* d_in = (u64*)base;                     base += sz_plane;
-  u64* d_ok = (u64*)base;                     base += sz_plane;
-  u64* d_tc = (u64*)base;                     base += sz_plane;
+  u64* d_ok = (u64*)base;                     base += sweep ? 0 : sz_plane;  // (the sweep keeps OK / TC in LDS)
+  u64* d_tc = (u64*)base;                     base += sweep ? 0 : sz_plane;
   u64* d_act = (u64*)base;                    base += sz_act;
   uint32_t* d_woff = (uint32_t*)base;         base += sz_woff;
   u64* d_wcounts = (u64*)base;                base += sz_counts;
@@ -961,21 +1207,50 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
 #undef VCY_BITS_F
 #undef VCY_BITS
   };
-  const int64_t halo_words = (int64_t)c->halo_lo * c->ny * p.Wr;
-  // a whole grid whose state implies TC == OK: no third plane at all
-  const bool alias_tc = c->cnt_implied && c->nx == p.Wr * 64 && c->halo_lo == 0;
-  if (alias_tc) {
-    p.tc = d_ok;
-    d_tc = nullptr;
-  }
-  if (c->cnt_implied && c->nx == p.Wr * 64) {
-    launch_bits(0, halo_words, false);
-    launch_bits(halo_words, vox_words - halo_words, true);
+  if (sweep) {
+    const bool reads_cnt = q.cnt_slices > 0;
+    const unsigned chunks = (unsigned)((p.L + 1 + q.layers - 1) / q.layers);
+    const size_t lds = sizeof(u64) * 2 * (reads_cnt ? 3 : 2) * (size_t)(q.R + 1) * p.Wr;
+#define VCY_SWEEP(CT, F32, RC, KM)                                                                                   \
+  hipLaunchKernelGGL((mc_sweep_kernel<CT, F32, RC, KM>), dim3(chunks * (unsigned)q.groups), dim3(256), lds, s, p, q, d_act, \
+                     d_woff, d_wcounts, d_in)
+#define VCY_SWEEP_K(CT, F32, RC)                      \
+  do {                                                \
+    if (q.K <= 1) VCY_SWEEP(CT, F32, RC, 1);          \
+    else if (q.K == 2) VCY_SWEEP(CT, F32, RC, 2);     \
+    else VCY_SWEEP(CT, F32, RC, kSweepMaxK);          \
+  } while (0)
+#define VCY_SWEEP_F(CT, RC)                                                       \
+  do {                                                                            \
+    if (iso_f32) VCY_SWEEP_K(CT, true, RC); else VCY_SWEEP_K(CT, false, RC);      \
+  } while (0)
+    if (reads_cnt) {
+      if (c->cnt_bytes == 1) VCY_SWEEP_F(uint8_t, true);
+      else if (c->cnt_bytes == 2) VCY_SWEEP_F(uint16_t, true);
+      else VCY_SWEEP_F(uint32_t, true);
+    } else {
+      VCY_SWEEP_F(uint16_t, false);  // (update_num is not read)
+    }
+#undef VCY_SWEEP_F
+#undef VCY_SWEEP_K
+#undef VCY_SWEEP
   } else {
-    launch_bits(0, vox_words, false);
+    const int64_t halo_words = (int64_t)c->halo_lo * c->ny * p.Wr;
+    // a whole grid whose state implies TC == OK: no third plane at all
+    const bool alias_tc = c->cnt_implied && c->nx == p.Wr * 64 && c->halo_lo == 0;
+    if (alias_tc) {
+      p.tc = d_ok;
+      d_tc = nullptr;
+    }
+    if (c->cnt_implied && c->nx == p.Wr * 64) {
+      launch_bits(0, halo_words, false);
+      launch_bits(halo_words, vox_words - halo_words, true);
+    } else {
+      launch_bits(0, vox_words, false);
+    }
+    hipLaunchKernelGGL(mc_active_kernel, dim3((nblocks + kActiveBlocks - 1) / kActiveBlocks), dim3(256), 0, s, p, d_act,
+                       d_woff, d_wcounts, (int64_t)nblocks);
   }
-  hipLaunchKernelGGL(mc_active_kernel, dim3((nblocks + kActiveBlocks - 1) / kActiveBlocks), dim3(256), 0, s, p, d_act, d_woff,
-                     d_wcounts, (int64_t)nblocks);
   MC_TRY(hipGetLastError());
   int rc = exclusive_scan_u64(d_wcounts, nblocks, d_total, d_scan, s);
   if (rc != VCY_OK) return rc;
