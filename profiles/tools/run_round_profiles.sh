@@ -23,8 +23,10 @@ python profiles/tools/summarize_pmc.py "$O/tsdf" "$O/pmc_1024x32_tsdf.json" --ke
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$O/mc" -o trace --output-format csv -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-variants ) > "$O/mc_trace.log" 2>&1
 ( cd /tmp && rocprofv3 --pmc FETCH_SIZE -d "$O/mc" -o fetch --output-format csv -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-variants ) > "$O/mc_fetch.log" 2>&1
 ( cd /tmp && rocprofv3 --pmc WRITE_SIZE -d "$O/mc" -o write --output-format csv -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-variants ) > "$O/mc_write.log" 2>&1
-python profiles/tools/summarize_pmc.py "$O/mc" "$O/pmc_1024_marching_cubes.json"
+python profiles/tools/summarize_pmc.py "$O/mc" "$O/pmc_1024_marching_cubes.json" --mc-key mc_1024 --counters "$CTR"
 profiles/tools/ab_mc.sh prod > "$O/mc_unprofiled.txt" 2>&1
+# the one-sweep cell search against the bit planes in memory ("mcsweep" 1 / 0), alternating in one process
+profiles/tools/ab_mc_sweep.sh prod 2>&1 | grep mcsweep > "$O/mc_sweep_vs_bit_planes.txt"
 # phase breakdown of the fused kernel (development build with s_memtime marks)
 if [ -f build/variants/phase/libvacancy_hip.so ]; then
   VCY_HIP_LIB=build/variants/phase/libvacancy_hip.so python profiles/tools/phase_timing.py > "$O/phase_timing.log" 2>&1

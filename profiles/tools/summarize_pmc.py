@@ -6,6 +6,8 @@ kernel-trace average duration, and for the dominant kernel the HBM bytes per lau
 correction, confirmed for the access widths used here in profiles/r01/fetch_calibration.txt).
 
   summarize_pmc.py <dir with *_counter_collection.csv> <out.json> [--key K --counters profiles/counters.json]
+  summarize_pmc.py <dir> <out.json> --mc-key mc_1024 --counters profiles/counters.json
+      (marching cubes: HBM bytes of ALL its kernels per extraction -> counters[mc_1024].hbm_bytes_per_call)
 """
 import csv
 import glob
@@ -68,6 +70,32 @@ def main():
         allc[key] = entry
         json.dump(allc, open(cpath, "w"), indent=1, sort_keys=True)
         print("updated", cpath, key)
+    if "--mc-key" in sys.argv:
+        key = sys.argv[sys.argv.index("--mc-key") + 1]
+        cpath = sys.argv[sys.argv.index("--counters") + 1]
+        entry = mc_entry(per)
+        if entry:
+            try:
+                allc = json.load(open(cpath))
+            except Exception:
+                allc = {}
+            entry["source"] = os.path.relpath(out, os.path.dirname(os.path.dirname(os.path.abspath(cpath))))
+            allc[key] = entry
+            json.dump(allc, open(cpath, "w"), indent=1, sort_keys=True)
+            print("updated", cpath, key, entry["hbm_bytes_per_call"])
+
+
+def mc_entry(per):
+    """Bytes one extraction moves: every marching-cubes kernel x its launches, over the number of extractions in
+    the run (= launches of the cell search: mc_sweep, or mc_active on the bit-plane path)."""
+    names = [k for k in per if re.match(r"mc_|scan_chunks|add_chunk_offsets", k) and "hbm_bytes_per_launch" in per[k]]
+    calls = per.get("mc_sweep", per.get("mc_active", {})).get("dispatches_FETCH_SIZE", 0)
+    if not calls:
+        return None
+    total = sum(per[k]["hbm_bytes_per_launch"] * per[k]["dispatches_FETCH_SIZE"] for k in names)
+    return {"hbm_bytes_per_call": int(total / calls), "extractions_in_run": calls,
+            "kernels": {k: {"launches_per_call": per[k]["dispatches_FETCH_SIZE"] / calls,
+                            "hbm_bytes_per_launch": per[k]["hbm_bytes_per_launch"]} for k in sorted(names)}}
 
 
 if __name__ == "__main__":
