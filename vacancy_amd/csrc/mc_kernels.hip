@@ -475,13 +475,15 @@ __global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restr
 // per word and per block, and the IN words around ACTIVE cells (case_at reads nothing else of that plane: the
 // sparse 32-byte sectors of the surface instead of two dense planes written and read back).  The state is read
 // once plus the row shared by two row groups (1 / R) and the slice shared by two z chunks (1 / layers).
+// update_num: READS_CNT reads it next to sdf (state set by vcy_upload); otherwise OK implies TC, except for the
+// ghost layer of a slab, whose max corners lie in the slab below: those TC words come in `tc_ghost`.
 struct SweepParams {
   int R;           // cell rows per workgroup
   int K;           // 256-word blocks per step = R * Wr / 256
   int groups;      // row groups per layer = Yc / R
   int layers;      // cell layers per workgroup
   int dl;          // cells whose max corner lies in stored slice s form layer li = s + dl
-  int cnt_slices;  // READS_CNT: update_num is read for the stored slices below this one
+  int cnt_slices;  // READS_CNT: update_num is read for the stored slices below this one (all of them)
   int wshift;      // log2 Wr
 };
 constexpr int kSweepMaxK = 4;
@@ -509,7 +511,8 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, Ks.
 template <typename CountT, bool ISO_F32, bool READS_CNT, int KMAX>
 __global__ __launch_bounds__(256) void mc_sweep_kernel(McParams p, SweepParams q, u64* __restrict__ act,
                                                        uint32_t* __restrict__ word_cell_off,
-                                                       u64* __restrict__ block_cells, u64* __restrict__ in_plane) {
+                                                       u64* __restrict__ block_cells, u64* __restrict__ in_plane,
+                                                       const u64* __restrict__ tc_ghost) {
   extern __shared__ u64 planes[];  // [2 slices][IN, OK (, TC)][(R + 1) * Wr]
   __shared__ int sm[2][KMAX][4];
   constexpr int kPlanes = READS_CNT ? 3 : 2;
@@ -649,6 +652,8 @@ __global__ __launch_bounds__(256) void mc_sweep_kernel(McParams p, SweepParams q
             v &= ((o00 << 1) | (p00 >> 63)) & ((o10 << 1) | (p10 >> 63)) & ((o01 << 1) | (p01 >> 63)) &
                  ((o11 << 1) | (p11 >> 63));
             if (READS_CNT) v &= cur[2 * plane_words + r1];
+            // the ghost layer's max corners lie in a slice of another context: its TC words, made by mc_bits
+            if (!READS_CNT && tc_ghost != nullptr && li == 0) v &= tc_ghost[(cy0 + row + 1) * Wr + w];
             m &= v;
           }
           if (m) {
@@ -1092,7 +1097,7 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
     const int64_t want = ((int64_t)(p.L + 1) * q.groups + VCY_SWEEP_TARGET_WGS - 1) / VCY_SWEEP_TARGET_WGS;
     q.layers = (int)std::min<int64_t>(std::max<int64_t>(want, 8), 64);
     q.dl = p.zs0 - p.zc0 + 1;
-    q.cnt_slices = c->cnt_implied ? c->halo_lo : p.nslices;
+    q.cnt_slices = c->cnt_implied ? 0 : p.nslices;
     while ((1 << q.wshift) < p.Wr) ++q.wshift;
   }
   const int64_t ghost_words = (int64_t)p.Yc * p.Wr;
@@ -1139,7 +1144,8 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   const size_t sz_woff = align(sizeof(uint32_t) * (size_t)p.nwords);
   const size_t sz_counts = align(sizeof(u64) * ((size_t)nblocks + 1));
   const size_t sz_scan = align(sizeof(u64) * ((size_t)nblocks / 1024 + 64) * 2);
-  const size_t need = (sweep ? 1 : 3) * sz_plane + sz_act + sz_woff + sz_counts + sz_scan + 256;
+  const size_t sz_ghost = sweep ? align(sizeof(u64) * 3 * (size_t)c->ny * p.Wr) : 0;  // IN / OK / TC of one slice
+  const size_t need = (sweep ? 1 : 3) * sz_plane + sz_ghost + sz_act + sz_woff + sz_counts + sz_scan + 256;
   if (c->mc_scratch_bytes < need) {
     VCY_HIP_CHECK(hipStreamSynchronize(s));
     if (c->d_mc_scratch) VCY_HIP_CHECK(hipFree(c->d_mc_scratch));
@@ -1152,6 +1158,7 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   u64* d_in = (u64*)base;                     base += sz_plane;
   u64* d_ok = (u64*)base;                     base += sweep ? 0 : sz_plane;  // (the sweep keeps OK / TC in LDS)
   u64* d_tc = (u64*)base;                     base += sweep ? 0 : sz_plane;
+  u64* d_ghost = (u64*)base;                  base += sz_ghost;
   u64* d_act = (u64*)base;                    base += sz_act;
   uint32_t* d_woff = (uint32_t*)base;         base += sz_woff;
   u64* d_wcounts = (u64*)base;                base += sz_counts;
@@ -1184,14 +1191,14 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   const bool iso_f32 = (double)(float)iso == iso;
   // the halo slices come from another context: their update_num is read; the owned slices need it
   // only if the state was ever set from outside (vcy_upload), see mc_bits_kernel
-  auto launch_bits = [&](int64_t word0, int64_t nw, bool tc_from_ok) {
+  auto launch_bits = [&](int64_t word0, int64_t nw, bool tc_from_ok, u64* o_in, u64* o_ok, u64* o_tc) {
     if (nw <= 0) return;
     const unsigned blocks = (unsigned)((nw + 4 * kBitsWordsPerWave - 1) / (4 * kBitsWordsPerWave));
     const float* sdf0 = c->d_sdf + word0 * 64;  // whole rows: only used when nx == Wr * 64 or word0 == 0
     const char* cnt0 = (const char*)c->d_cnt + word0 * 64 * c->cnt_bytes;
 #define VCY_BITS(CT, F32, TCOK)                                                                          \
   hipLaunchKernelGGL((mc_bits_kernel<CT, F32, TCOK>), dim3(blocks), dim3(256), 0, s, sdf0, (const CT*)cnt0, \
-                     c->nx, p.Wr, nw, iso, d_in + word0, d_ok + word0, d_tc ? d_tc + word0 : nullptr)
+                     c->nx, p.Wr, nw, iso, o_in, o_ok, o_tc)
 #define VCY_BITS_F(CT, TCOK)                                                    \
   do {                                                                          \
     if (iso_f32) VCY_BITS(CT, true, TCOK); else VCY_BITS(CT, false, TCOK);      \
@@ -1210,11 +1217,18 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   };
   if (sweep) {
     const bool reads_cnt = q.cnt_slices > 0;
+    // TC words of the slice the ghost layer's max corners lie in (stored slice 1), from its update_num
+    const u64* d_tc_ghost = nullptr;
+    if (!reads_cnt && c->halo_lo > 0) {
+      const int64_t row_words = (int64_t)c->ny * p.Wr;
+      launch_bits(row_words, row_words, false, d_ghost, d_ghost + row_words, d_ghost + 2 * row_words);
+      d_tc_ghost = d_ghost + 2 * row_words;
+    }
     const unsigned chunks = (unsigned)((p.L + 1 + q.layers - 1) / q.layers);
     const size_t lds = sizeof(u64) * 2 * (reads_cnt ? 3 : 2) * (size_t)(q.R + 1) * p.Wr;
 #define VCY_SWEEP(CT, F32, RC, KM)                                                                                   \
   hipLaunchKernelGGL((mc_sweep_kernel<CT, F32, RC, KM>), dim3(chunks * (unsigned)q.groups), dim3(256), lds, s, p, q, d_act, \
-                     d_woff, d_wcounts, d_in)
+                     d_woff, d_wcounts, d_in, d_tc_ghost)
 #define VCY_SWEEP_K(CT, F32, RC)                      \
   do {                                                \
     if (q.K <= 1) VCY_SWEEP(CT, F32, RC, 1);          \
@@ -1244,10 +1258,11 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
       d_tc = nullptr;
     }
     if (c->cnt_implied && c->nx == p.Wr * 64) {
-      launch_bits(0, halo_words, false);
-      launch_bits(halo_words, vox_words - halo_words, true);
+      launch_bits(0, halo_words, false, d_in, d_ok, d_tc);
+      launch_bits(halo_words, vox_words - halo_words, true, d_in + halo_words, d_ok + halo_words,
+                  d_tc ? d_tc + halo_words : nullptr);
     } else {
-      launch_bits(0, vox_words, false);
+      launch_bits(0, vox_words, false, d_in, d_ok, d_tc);
     }
     hipLaunchKernelGGL(mc_active_kernel, dim3((nblocks + kActiveBlocks - 1) / kActiveBlocks), dim3(256), 0, s, p, d_act,
                        d_woff, d_wcounts, (int64_t)nblocks);
