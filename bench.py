@@ -403,7 +403,9 @@ def main():
                 collective["note"] = backend_note
             mc_ms, mc_wall, nvert, nface = 0.0, 0.0, 0, 0
             mc_calls = []
+            single = world == 1 and len(devs) == 1  # no slab merge: the mesh is vertices + faces, as the reference's
             for c in devs:
+                c.set_param("meshkeys", 0 if single else 1)
                 mesh = c.ExtractIsoSurface(0.0, True)  # first run: scratch and host buffers are allocated
                 best = None
                 for _ in range(3):  # a sequence of extractions, as in the reference's carve-and-extract loop
@@ -430,6 +432,7 @@ def main():
                                "the extraction with the shortest wall time of three consecutive ones after a first "
                                "that allocates (all listed in calls_device_wall_ms)",
                   "calls_device_wall_ms": mc_calls,
+                  "mesh_arrays": "vertices, faces" if single else "vertices, faces, edge keys (slab merge)",
                   "vertices": int(nvert), "faces": int(nface),
                   "roofline_frac": round(cells * 4.0 / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             mctr = load_counters("mc_%d" % n) if world == 1 else None

@@ -89,7 +89,7 @@ typedef struct vcy_mesh {
   int64_t  n_faces;
   float*   vertices;   /* 3 * n_vertices, xyz                         */
   int32_t* faces;      /* 3 * n_faces, indices into vertices          */
-  int64_t* edge_keys;  /* 2 * n_vertices, (lower id, higher id), GLOBAL voxel ids */
+  int64_t* edge_keys;  /* 2 * n_vertices, (lower id, higher id), GLOBAL voxel ids; NULL with "meshkeys" 0 */
   /* Multi-GPU only (0 for a whole grid): the first n_foreign_vertices entries duplicate
    * vertices that the previous z-slab owns (edges on the shared plane z_begin-1); a merge
    * maps them onto that slab's numbering by edge key. */
@@ -264,9 +264,12 @@ int vcy_reset(vcy_ctx* ctx);
  * binades, about a millisecond once per focal length per process).
  * "mcsweep" (default 1): vcy_extract_iso finds the surface cells in one sweep over the state with the bit
  * planes in LDS when a voxel row is a power-of-two number of 64-voxel words (nx = 64 ... 2048); 0 forces the
- * path every other shape takes (bit planes in memory, two passes). */
+ * path every other shape takes (bit planes in memory, two passes).
+ * "meshkeys" (default 1): vcy_extract_iso returns vcy_mesh.edge_keys; 0 leaves it NULL (nothing is computed for
+ * it or copied: a third of the mesh bytes) -- for callers that do not merge z-slabs, i.e. what the reference's
+ * MarchingCubes returns. */
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
-/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep"), or "div_level": the division sequence
+/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep", "meshkeys"), or "div_level": the division sequence
  * the last fused launch was instantiated with (2: 4 instructions, 1: 6, 0: full IEEE expansion). */
 int vcy_get_param(vcy_ctx* ctx, const char* name, int* value);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all launches. */

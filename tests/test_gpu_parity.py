@@ -370,6 +370,27 @@ def test_marching_cubes_one_sweep_and_bit_plane_paths(dims):
             assert_mesh_equal(dev.ExtractIsoSurface(iso, interp), ref, "uploaded sweep=%d iso=%s" % (sweep, iso))
 
 
+def test_mesh_without_edge_keys():
+    """"meshkeys" 0: vcy_mesh.edge_keys stays NULL, vertices and faces are the same arrays."""
+    n, nv = 48, 4
+    opt = synth.sphere_option(n)
+    views, masks = synth.sphere_views(n, nv, 128, 96)
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init()
+    for i in range(nv):
+        assert dev.Carve(views[i], vc.make_sdf(masks[i]))
+    full = dev.ExtractIsoSurface(0.0, True)
+    assert len(full["keys"]) == len(full["vertices"]) > 0
+    dev.set_param("meshkeys", 0)
+    assert dev.get_param("meshkeys") == 0
+    bare = dev.ExtractIsoSurface(0.0, True)
+    assert len(bare["keys"]) == 0
+    assert np.array_equal(bare["faces"], full["faces"])
+    assert np.array_equal(bare["vertices"].view(np.uint32), full["vertices"].view(np.uint32))
+    dev.set_param("meshkeys", 1)
+    assert_mesh_equal(dev.ExtractIsoSurface(0.0, True), full, "keys back on")
+
+
 def test_extract_voxel_predicates_on_adversarial_state():
     """ExtractVoxel's keep predicates run on the device (extract_voxel.hip): both of them on uploaded state
     with zeros of either sign, denormals, products that underflow to -0 or to the smallest denormal,

@@ -990,8 +990,10 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(McParams p, const McTables
         verts[3 * vid + 0] = out[0];
         verts[3 * vid + 1] = out[1];
         verts[3 * vid + 2] = out[2];
-        keys[2 * vid + 0] = k0;
-        keys[2 * vid + 1] = k1;
+        if (keys != nullptr) {
+          keys[2 * vid + 0] = k0;
+          keys[2 * vid + 1] = k1;
+        }
       }
     }
 
@@ -1039,8 +1041,10 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(McParams p, const McTables
   // whole rows of dwords: 3 floats per vertex, 2 x 8 bytes per key pair, 3 ints per triangle
   float* gv = verts + 3 * vb;
   for (int k = threadIdx.x; k < 3 * tot_v; k += 256) gv[k] = sv[k];
-  long long* gk = keys + 2 * vb;
-  for (int k = threadIdx.x; k < 2 * tot_v; k += 256) gk[k] = sk[k];
+  if (keys != nullptr) {  // (null: the caller does not merge slabs, "meshkeys" 0)
+    long long* gk = keys + 2 * vb;
+    for (int k = threadIdx.x; k < 2 * tot_v; k += 256) gk[k] = sk[k];
+  }
   int* gf = faces + 3 * fb;
   for (int k = threadIdx.x; k < 3 * tot_t; k += 256) gf[k] = sf[k];
 }
@@ -1326,7 +1330,7 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
       c->mc_out_bytes = sz_v + sz_k + sz_f;
     }
     d_verts = (float*)c->d_mc_out;
-    d_keys = (long long*)((char*)c->d_mc_out + sz_v);
+    d_keys = c->mesh_keys ? (long long*)((char*)c->d_mc_out + sz_v) : nullptr;
     d_faces = (int*)((char*)c->d_mc_out + sz_v + sz_k);
     hipLaunchKernelGGL(mc_emit_kernel, dim3(b.blocks), dim3(256), 0, s, p, T, d_act, b.list, d_total, cap_cells, d_woff,
                        d_wcounts, b.info, b.counts, b.total, cap_v, cap_f, d_verts, d_keys, d_faces);
@@ -1405,16 +1409,17 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   // the mesh arrays: page-locked host buffers, three DMAs in flight on the context's stream
   if (nv > 0) {
     out->vertices = (float*)mesh_host_alloc(sizeof(float) * 3 * (size_t)nv);
-    out->edge_keys = (int64_t*)mesh_host_alloc(sizeof(int64_t) * 2 * (size_t)nv);
+    if (c->mesh_keys) out->edge_keys = (int64_t*)mesh_host_alloc(sizeof(int64_t) * 2 * (size_t)nv);
   }
   if (nf > 0) out->faces = (int32_t*)mesh_host_alloc(sizeof(int32_t) * 3 * (size_t)nf);
-  if ((nv > 0 && (!out->vertices || !out->edge_keys)) || (nf > 0 && !out->faces)) {
+  if ((nv > 0 && (!out->vertices || (c->mesh_keys && !out->edge_keys))) || (nf > 0 && !out->faces)) {
     set_error("out of host memory for the mesh");
     return VCY_ERR_INTERNAL;
   }
   if (nv > 0) {
     MC_TRY(hipMemcpyAsync(out->vertices, d_verts, sizeof(float) * 3 * (size_t)nv, hipMemcpyDeviceToHost, s));
-    MC_TRY(hipMemcpyAsync(out->edge_keys, d_keys, sizeof(long long) * 2 * (size_t)nv, hipMemcpyDeviceToHost, s));
+    if (c->mesh_keys)
+      MC_TRY(hipMemcpyAsync(out->edge_keys, d_keys, sizeof(long long) * 2 * (size_t)nv, hipMemcpyDeviceToHost, s));
   }
   if (nf > 0) MC_TRY(hipMemcpyAsync(out->faces, d_faces, sizeof(int) * 3 * (size_t)nf, hipMemcpyDeviceToHost, s));
   MC_TRY(hipStreamSynchronize(s));

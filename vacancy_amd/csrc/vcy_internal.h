@@ -65,6 +65,7 @@ struct vcy_ctx {
   float* d_py = nullptr;
   float* d_pz = nullptr;
 
+  bool mesh_keys = true;              // vcy_extract_iso also returns the edge key of every vertex (vcy_set_param "meshkeys")
   bool mc_sweep = true;               // marching cubes: bit planes through LDS where the row shape allows (vcy_set_param "mcsweep")
   int tile_mode = 0;                  // 0 auto, 1 the 16 x 16 pixel tile, 2 the 2048-pixel tile filled in place (vcy_set_param "tile")
   bool use_cull = true;               // vcy_set_param("cull", 0): never drop provably idle views

@@ -141,6 +141,9 @@ bool VoxelCarver::Init() {
     LOGE("%s\n", vcy_last_error());
     return false;
   }
+  // one context holds the whole grid: no slab merge, so the mesh needs no edge keys (the reference's
+  // MarchingCubes returns vertices and faces)
+  vcy_set_param(impl_->ctx, "meshkeys", 0);
   return true;
 }
 
