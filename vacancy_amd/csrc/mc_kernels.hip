@@ -1087,9 +1087,15 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   p.linear = linear_interp;
   c->last_extract_device_ms = 0.0f;
   if (c->nx < 2 || p.Y <= 0 || p.L <= 0) return VCY_OK;  // no cells (reference loops do not run)
-  // one sweep (mc_sweep_kernel) when a voxel row is a power-of-two number of whole words, else bit planes in
-  // memory (mc_bits + mc_active); "mcsweep" 0 forces the latter
-  const bool sweep = c->mc_sweep && c->nx == p.Wr * 64 && (p.Wr & (p.Wr - 1)) == 0 && p.Wr <= 32;
+  // One sweep (mc_sweep_kernel) needs a voxel row that is a power-of-two number of whole words; "mcsweep" 2 takes it
+  // whenever the shape allows, 0 never, 1 (default) where it is at least as fast as the bit planes in memory
+  // (mc_bits + mc_active): grids with work for 1024 workgroups of >= 24 layers and rows of <= 16 words (measured,
+  // sweep / planes: 256^3 0.166 / 0.127 ms, 512^3 0.284 / 0.256, 1024^3 1.17-1.26 / 1.19-1.26, 2048^3 9.60 / 9.49)
+  const bool sweep_shape = c->nx == p.Wr * 64 && (p.Wr & (p.Wr - 1)) == 0 && p.Wr <= 32;
+  const int sweep_rows = std::max(32, kWordsPerBlock / std::max(p.Wr, 1));
+  const int64_t sweep_work = (int64_t)(p.L + 1) * ((p.Y + sweep_rows - 1) / sweep_rows);  // (row group, layer) steps
+  const bool sweep = sweep_shape && (c->mc_sweep == 2 || (c->mc_sweep == 1 && p.Wr <= 16 &&
+                                                          sweep_work >= 24 * (int64_t)VCY_SWEEP_TARGET_WGS));
   SweepParams q{};
   p.Yc = p.Y;
   if (sweep) {
