@@ -262,10 +262,9 @@ int vcy_reset(vcy_ctx* ctx);
  * the full IEEE expansion, but only after the library has checked on the device, for each focal length
  * in use, that the sequence equals IEEE division for EVERY admissible depth (all 2^23 significands in 121
  * binades, about a millisecond once per focal length per process).
- * "mcsweep" (default 1): vcy_extract_iso can find the surface cells in one sweep over the state with the bit
- * planes in LDS when a voxel row is a power-of-two number of 64-voxel words (nx = 64 ... 2048).  1 takes that path
- * where it is at least as fast as the other (large grids with rows of up to 1024 voxels), 2 wherever the shape
- * allows, 0 never (bit planes in memory, two passes: the path of every other shape).
+ * "mcsweep" (default 0): 1 makes vcy_extract_iso find the surface cells in one sweep over the state with the bit
+ * planes in LDS when a voxel row is a power-of-two number of 64-voxel words (nx = 64 ... 2048): 2 % fewer bytes
+ * moved than with the bit planes in memory (the default and the path of every other shape), 2 - 30 % more time.
  * "meshkeys" (default 1): vcy_extract_iso returns vcy_mesh.edge_keys; 0 leaves it NULL (nothing is computed for
  * it or copied: a third of the mesh bytes) -- for callers that do not merge z-slabs, i.e. what the reference's
  * MarchingCubes returns. */

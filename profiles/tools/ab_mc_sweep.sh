@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON the GPU box: marching cubes of the bench scene (1024^3) with the one-sweep cell search and with the
-# bit planes in memory ("mcsweep" 2 / 0), same context, alternating; kernel ms, wall ms, mesh hash.
+# bit planes in memory ("mcsweep" 1 / 0), same context, alternating; kernel ms, wall ms, mesh hash.
 #   profiles/tools/ab_mc_sweep.sh [<variant>...]     (default "prod" = vacancy_amd/csrc/libvacancy_hip.so)
 [ $# -eq 0 ] && set -- prod
 for v in "$@"; do
@@ -21,7 +21,7 @@ assert c.Init()
 d = [c.upload_sdf(sdf0)] * nv
 assert c.CarveBatchDevice(vc.VoxelCarver.prepare_batch(views, d))
 for rnd in range(2):
-    for sweep in (2, 0):
+    for sweep in (1, 0):
         c.set_param("mcsweep", sweep)
         every = []
         best = (1e9, 1e9)

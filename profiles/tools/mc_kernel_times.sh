@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON the GPU box: per-kernel times (rocprofv3 --kernel-trace --stats) of marching cubes at 1024^3 for each
-# build named on the command line ("prod" = vacancy_amd/csrc/libvacancy_hip.so); MCSWEEP=0 for the bit-plane path.
+# build named on the command line ("prod" = vacancy_amd/csrc/libvacancy_hip.so); MCSWEEP=1 for the one-sweep cell search.
 R=$(pwd -P); O=$R/gpurun_out/mck; mkdir -p $O
 cat > /tmp/mc_drive.py <<'PY'
 import os, sys
@@ -16,7 +16,7 @@ c = vc.VoxelCarver(opt)
 assert c.Init()
 d = [c.upload_sdf(sdf0)] * nv
 assert c.CarveBatchDevice(vc.VoxelCarver.prepare_batch(views, d))
-c.set_param("mcsweep", int(os.environ.get("MCSWEEP", "1")))
+c.set_param("mcsweep", int(os.environ.get("MCSWEEP", "0")))
 for it in range(6):
     m = c.ExtractIsoSurface(0.0, True)
 print("device_ms", m["device_ms"], "faces", len(m["faces"]))
@@ -32,6 +32,6 @@ import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"]
     if "mc_" in n or "scan" in n or "chunk" in n:
-        print("   %-28s calls %4s  avg %9.1f us  min %9.1f" % (n.split("(")[0].split("::")[-1][:28], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
+        import re; short = re.search(r"(mc_\w+|scan_chunks\w*|add_chunk\w*)", n).group(1); print("   %-28s calls %4s  avg %9.1f us  min %9.1f" % (short, r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
 PY
 done

@@ -1,5 +1,5 @@
 """Runs ON the GPU box: marching cubes with the one-sweep cell search and with the bit planes in memory
-("mcsweep" 2 / 0) on sphere scenes of several grid sizes; kernel ms (HIP events), best of 4 after a warm-up call.
+("mcsweep" 1 / 0) on sphere scenes of several grid sizes; kernel ms (HIP events), best of 4 after a warm-up call.
 usage: python profiles/tools/mc_sizes.py [n ...]      (default 256 512 1024 2048)"""
 import sys
 sys.path.insert(0, ".")
@@ -18,7 +18,7 @@ for n in sizes:
     assert c.CarveBatchDevice(vc.VoxelCarver.prepare_batch(views, d))
     c.set_param("meshkeys", 0)
     row = []
-    for sweep in (2, 0, 2, 0):
+    for sweep in (1, 0, 1, 0):
         c.set_param("mcsweep", sweep)
         c.ExtractIsoSurface(0.0, True)
         best = min(c.ExtractIsoSurface(0.0, True)["device_ms"] for _ in range(4))

@@ -1,7 +1,7 @@
 """Long-running differential fuzz of marching cubes alone (not collected by pytest): arbitrary uploaded state
 (noise, smooth runs, invalid holes, untouched voxels, values in the 1e-5 snap band) on grids whose rows are 1 .. 8
 whole 64-voxel words (the one-sweep cell search) or ragged (the bit-plane path), as one context and as two
-z-slab contexts with the halo installed, "mcsweep" 2 and 0, float and non-float iso levels, both interpolation
+z-slab contexts with the halo installed, "mcsweep" 1 and 0, float and non-float iso levels, both interpolation
 modes -- every mesh against the oracle array for array.
 usage: python tests/fuzz/fuzz_marching_cubes.py FIRST_SEED LAST_SEED   (round 2, final kernels: seeds 0..2000, 0 mismatches)"""
 import sys, os, time
@@ -58,7 +58,7 @@ for seed in range(lo, hi):
     whole = vc.VoxelCarver(opt)
     assert whole.Init(), vc.last_error()
     whole.upload(sdf, cnt)
-    for sweep in (2, 0):
+    for sweep in (1, 0):
         whole.set_param("mcsweep", sweep)
         if not same(whole.ExtractIsoSurface(iso, interp), ref):
             bad += 1
@@ -72,7 +72,7 @@ for seed in range(lo, hi):
         upper.halo_install_host(lower.halo_pack_host())
         for c, (z0, z1) in ((lower, (0, cut)), (upper, (cut, nz))):
             sref = O.marching_cubes_slab(orc, z0, z1, iso, interp)
-            for sweep in (2, 0):
+            for sweep in (1, 0):
                 c.set_param("mcsweep", sweep)
                 m = c.ExtractIsoSurface(iso, interp)
                 if not (same(m, sref) and m["n_foreign"] == sref["n_foreign"]):

@@ -420,7 +420,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total, int* sm /
 // ---- pass 1: active cells, counted per word --------------------------------------------------
 // A workgroup handles kActiveBlocks consecutive blocks of 256 words, and every thread requests the corner
 // planes of all its words before it uses the first: the pass is one memory round trip deep and is bound by
-// how many of those a CU keeps in flight, not by the bytes (1024^3: 0.20 ms with one word per thread; with two,
+// how many requests a CU issues, not by the bytes (1024^3: 0.20 ms with one word per thread; with two,
 // between the same and 0.06 ms less from run to run; four and eight lose to their registers).
 constexpr int kActiveBlocks = 2;
 
@@ -447,7 +447,32 @@ __global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restr
     live[k] = cw < p.nwords && decode_word(p, cw, &li, &cy, &w[k]) && (li > 0 || p.has_ghost);
     if (!live[k]) li = 1, cy = 0, w[k] = 0;  // (any valid word: the loads below are not branched around)
     r[k] = cell_rows(p, li, cy);
-    load_cell_in(p, r[k], w[k], &c[k]);
+    // The pass is bound by the number of load instructions (reading the validity planes for every word as well
+    // makes it 50 % slower): a thread loads its own word of the four voxel rows; the word before -- for x - 1 of
+    // bit 0 -- is the one the lane before loaded (consecutive lanes hold consecutive words of a row), only lane 0
+    // of a wave fetches it itself.
+    const u64 m00 = p.in[r[k].r00 + w[k]], m10 = p.in[r[k].r10 + w[k]];
+    const u64 m01 = p.in[r[k].r01 + w[k]], m11 = p.in[r[k].r11 + w[k]];
+    uint32_t h00 = 0, h10 = 0, h01 = 0, h11 = 0;  // high halves of the words before
+    const bool edge = (threadIdx.x & 63) == 0 && w[k] > 0;
+    if (edge) {
+      h00 = (uint32_t)(p.in[r[k].r00 + w[k] - 1] >> 32);
+      h10 = (uint32_t)(p.in[r[k].r10 + w[k] - 1] >> 32);
+      h01 = (uint32_t)(p.in[r[k].r01 + w[k] - 1] >> 32);
+      h11 = (uint32_t)(p.in[r[k].r11 + w[k] - 1] >> 32);
+    }
+    const uint32_t s00 = __shfl_up((uint32_t)(m00 >> 32), 1, 64), s10 = __shfl_up((uint32_t)(m10 >> 32), 1, 64);
+    const uint32_t s01 = __shfl_up((uint32_t)(m01 >> 32), 1, 64), s11 = __shfl_up((uint32_t)(m11 >> 32), 1, 64);
+    if (!edge) h00 = s00, h10 = s10, h01 = s01, h11 = s11;
+    if (w[k] == 0) h00 = h10 = h01 = h11 = 0;
+    c[k].c[0] = (m00 << 1) | (h00 >> 31);
+    c[k].c[1] = m00;
+    c[k].c[2] = m10;
+    c[k].c[3] = (m10 << 1) | (h10 >> 31);
+    c[k].c[4] = (m01 << 1) | (h01 >> 31);
+    c[k].c[5] = m01;
+    c[k].c[6] = m11;
+    c[k].c[7] = (m11 << 1) | (h11 >> 31);
   }
 #pragma unroll
   for (int k = 0; k < kActiveBlocks; ++k) {
@@ -1087,15 +1112,11 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   p.linear = linear_interp;
   c->last_extract_device_ms = 0.0f;
   if (c->nx < 2 || p.Y <= 0 || p.L <= 0) return VCY_OK;  // no cells (reference loops do not run)
-  // One sweep (mc_sweep_kernel) needs a voxel row that is a power-of-two number of whole words; "mcsweep" 2 takes it
-  // whenever the shape allows, 0 never, 1 (default) where it is at least as fast as the bit planes in memory
-  // (mc_bits + mc_active): grids with work for 1024 workgroups of >= 24 layers and rows of <= 16 words (measured,
-  // sweep / planes: 256^3 0.166 / 0.127 ms, 512^3 0.284 / 0.256, 1024^3 1.17-1.26 / 1.19-1.26, 2048^3 9.60 / 9.49)
-  const bool sweep_shape = c->nx == p.Wr * 64 && (p.Wr & (p.Wr - 1)) == 0 && p.Wr <= 32;
-  const int sweep_rows = std::max(32, kWordsPerBlock / std::max(p.Wr, 1));
-  const int64_t sweep_work = (int64_t)(p.L + 1) * ((p.Y + sweep_rows - 1) / sweep_rows);  // (row group, layer) steps
-  const bool sweep = sweep_shape && (c->mc_sweep == 2 || (c->mc_sweep == 1 && p.Wr <= 16 &&
-                                                          sweep_work >= 24 * (int64_t)VCY_SWEEP_TARGET_WGS));
+  // One sweep (mc_sweep_kernel) needs a voxel row that is a power-of-two number of whole words.  It moves 2 % fewer
+  // bytes than the bit planes in memory (mc_bits + mc_active) but is not faster anywhere (sweep / planes, one box:
+  // 256^3 0.172 / 0.133 ms, 512^3 0.291 / 0.260, 1024^3 1.26-1.27 / 1.23-1.24, 2048^3 9.55 / 9.18), so it is
+  // taken only on request ("mcsweep" 1).
+  const bool sweep = c->mc_sweep && c->nx == p.Wr * 64 && (p.Wr & (p.Wr - 1)) == 0 && p.Wr <= 32;
   SweepParams q{};
   p.Yc = p.Y;
   if (sweep) {

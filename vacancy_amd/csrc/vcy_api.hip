@@ -380,8 +380,7 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
     return VCY_OK;
   }
   if (std::strcmp(name, "mcsweep") == 0) {
-    if (value < 0 || value > 2) return VCY_ERR_INVALID_ARG;
-    c->mc_sweep = value;
+    c->mc_sweep = value != 0;
     return VCY_OK;
   }
   if (std::strcmp(name, "meshkeys") == 0) {
@@ -400,7 +399,7 @@ int vcy_get_param(vcy_ctx* c, const char* name, int* value) {
   else if (std::strcmp(name, "defer") == 0) *value = c->defer ? 1 : 0;
   else if (std::strcmp(name, "shortdiv") == 0) *value = c->use_short_div ? 1 : 0;
   else if (std::strcmp(name, "div_level") == 0) *value = c->last_div_level;
-  else if (std::strcmp(name, "mcsweep") == 0) *value = c->mc_sweep;
+  else if (std::strcmp(name, "mcsweep") == 0) *value = c->mc_sweep ? 1 : 0;
   else if (std::strcmp(name, "meshkeys") == 0) *value = c->mesh_keys ? 1 : 0;
   else {
     set_error("unknown parameter %s", name);

@@ -66,7 +66,7 @@ struct vcy_ctx {
   float* d_pz = nullptr;
 
   bool mesh_keys = true;              // vcy_extract_iso also returns the edge key of every vertex (vcy_set_param "meshkeys")
-  int mc_sweep = 1;                   // marching cubes, cell search in one sweep with the bit planes in LDS: 0 never, 1 where it pays, 2 wherever the row shape allows (vcy_set_param "mcsweep")
+  bool mc_sweep = false;              // marching cubes: cell search in one sweep with the bit planes in LDS where the row shape allows (vcy_set_param "mcsweep")
   int tile_mode = 0;                  // 0 auto, 1 the 16 x 16 pixel tile, 2 the 2048-pixel tile filled in place (vcy_set_param "tile")
   bool use_cull = true;               // vcy_set_param("cull", 0): never drop provably idle views
   // Views accepted by the per-view entry points (vcy_carve, vcy_carve_device, vcy_carve_silhouette) but
