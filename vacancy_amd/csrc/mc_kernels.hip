@@ -12,6 +12,8 @@
 //             TC  = update_num >= 1          (:88-90, tested on corner 6 only)
 //   active    one thread per 64-cell word: the 8 corner planes of the cells are word shifts /
 //             row offsets of IN and OK; active = valid & ~all_inside & any_inside.
+//   (sweep    on request, "mcsweep" 1: bits + active in ONE kernel that walks z with the planes of two slices
+//             in LDS; fewer bytes, not faster -- see mc_sweep_kernel.)
 //   owner     a cut edge belongs to the FIRST active cell (scan order) among the <= 4 cells
 //             that share it -- where the reference's map insert happens, which also fixes the
 //             interpolation direction.  Active cells (sparse) find the
