@@ -422,9 +422,12 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total, int* sm /
 // ---- pass 1: active cells, counted per word --------------------------------------------------
 // A workgroup handles kActiveBlocks consecutive blocks of 256 words, and every thread requests the corner
 // planes of all its words before it uses the first: the pass is one memory round trip deep and is bound by
-// how many requests a CU issues, not by the bytes (1024^3: 0.20 ms with one word per thread; with two,
-// between the same and 0.06 ms less from run to run; four and eight lose to their registers).
-constexpr int kActiveBlocks = 2;
+// how many requests a CU issues, not by the bytes (1024^3, after the carry loads went: 0.164 ms with one block per
+// workgroup, 0.166 with two, 0.186 with three, 0.216 with four).
+#ifndef VCY_ACTIVE_BLOCKS
+#define VCY_ACTIVE_BLOCKS 2
+#endif
+constexpr int kActiveBlocks = VCY_ACTIVE_BLOCKS;
 
 __global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restrict__ act,
                                                         uint32_t* __restrict__ word_cell_off,
