@@ -432,7 +432,7 @@ constexpr int kActiveBlocks = VCY_ACTIVE_BLOCKS;
 __global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restrict__ act,
                                                         uint32_t* __restrict__ word_cell_off,
                                                         u64* __restrict__ block_cells, int64_t nblocks) {
-  __shared__ int sm[4];
+  __shared__ int sm[kActiveBlocks][4];
   // XCD-aware order (workgroup b runs on XCD b % 8): consecutive word blocks -- which share their
   // boundary rows and, one layer later, the rows of slice z-1 -- stay on one XCD's L2
   int64_t lg = blockIdx.x;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restr
     const u64 m01 = p.in[r[k].r01 + w[k]], m11 = p.in[r[k].r11 + w[k]];
     uint32_t h00 = 0, h10 = 0, h01 = 0, h11 = 0;  // high halves of the words before
     const bool edge = (threadIdx.x & 63) == 0 && w[k] > 0;
-    if (edge) {
+    if (__ballot(edge) != 0 && edge) {  // (never when a row is 1 .. 64 words: lane 0 then starts a row)
       h00 = (uint32_t)(p.in[r[k].r00 + w[k] - 1] >> 32);
       h10 = (uint32_t)(p.in[r[k].r10 + w[k] - 1] >> 32);
       h01 = (uint32_t)(p.in[r[k].r01 + w[k] - 1] >> 32);
@@ -479,19 +479,58 @@ __global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restr
     c[k].c[6] = m11;
     c[k].c[7] = (m11 << 1) | (h11 >> 31);
   }
+  // the offsets of all the workgroup's blocks with ONE barrier: wave scans, the wave totals through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int excl[kActiveBlocks];
 #pragma unroll
   for (int k = 0; k < kActiveBlocks; ++k) {
-    const int64_t lb = lg * kActiveBlocks + k;
-    const int64_t cw = lb * 256 + threadIdx.x;
+    const int64_t cw = (lg * kActiveBlocks + k) * 256 + threadIdx.x;
     // a cell is active when its corners are neither all inside nor all outside (kEdgeTable != 0) and it
     // is valid; the validity planes are only read for the few words that have a candidate
     c[k].valid = ~0ull;
     u64 a = live[k] ? active_mask(c[k]) : 0ull;
-    if (a) a &= load_cell_valid(p, r[k], w[k]);
+    if (__ballot(a != 0) != 0) {  // (uniform: the whole wave reads, so that the words before can come from lane - 1)
+      // corner 6 touched (marching_cubes.cc:88-90), no corner invalid (:103-112) -- load_cell_valid with the carry
+      // words taken from the neighbouring lane, as for IN above
+      const u64 o00 = p.ok[r[k].r00 + w[k]], o10 = p.ok[r[k].r10 + w[k]];
+      const u64 o01 = p.ok[r[k].r01 + w[k]], o11 = p.ok[r[k].r11 + w[k]];
+      const u64 t11 = p.tc[r[k].r11 + w[k]];
+      uint32_t g00 = 0, g10 = 0, g01 = 0, g11 = 0;
+      const bool edge = lane == 0 && w[k] > 0;
+      if (edge) {
+        g00 = (uint32_t)(p.ok[r[k].r00 + w[k] - 1] >> 32);
+        g10 = (uint32_t)(p.ok[r[k].r10 + w[k] - 1] >> 32);
+        g01 = (uint32_t)(p.ok[r[k].r01 + w[k] - 1] >> 32);
+        g11 = (uint32_t)(p.ok[r[k].r11 + w[k] - 1] >> 32);
+      }
+      const uint32_t u00 = __shfl_up((uint32_t)(o00 >> 32), 1, 64), u10 = __shfl_up((uint32_t)(o10 >> 32), 1, 64);
+      const uint32_t u01 = __shfl_up((uint32_t)(o01 >> 32), 1, 64), u11 = __shfl_up((uint32_t)(o11 >> 32), 1, 64);
+      if (!edge) g00 = u00, g10 = u10, g01 = u01, g11 = u11;
+      // (x = 0 is not a cell: bit 0 of word 0 is cleared, whatever its carry)
+      u64 v = t11 & o00 & o10 & o01 & o11;
+      v &= ((o00 << 1) | (g00 >> 31)) & ((o10 << 1) | (g10 >> 31)) & ((o01 << 1) | (g01 >> 31)) & ((o11 << 1) | (g11 >> 31));
+      if (w[k] == 0) v &= ~1ull;
+      a &= v;
+    }
     if (cw < p.nwords) act[cw] = a;
-    int total;
-    const int off = block_exclusive_scan(__popcll(a), &total, sm);
-    if (cw < p.nwords) word_cell_off[cw] = (uint32_t)off;
+    const int pc = __popcll(a);
+    const int inc = wave_inclusive_scan(pc);
+    excl[k] = inc - pc;
+    if (lane == 63) sm[k][wave] = inc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kActiveBlocks; ++k) {
+    const int64_t lb = lg * kActiveBlocks + k;
+    const int64_t cw = lb * 256 + threadIdx.x;
+    int base = 0, total = 0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int t = sm[k][v];
+      if (v < wave) base += t;
+      total += t;
+    }
+    if (cw < p.nwords) word_cell_off[cw] = (uint32_t)(base + excl[k]);
     if (threadIdx.x == 0 && lb < nblocks) block_cells[lb] = (u64)(unsigned)total;
   }
 }
