@@ -3,7 +3,7 @@
 whole 64-voxel words (the one-sweep cell search) or ragged (the bit-plane path), as one context and as two
 z-slab contexts with the halo installed, "mcsweep" 1 and 0, float and non-float iso levels, both interpolation
 modes -- every mesh against the oracle array for array.
-usage: python tests/fuzz/fuzz_marching_cubes.py FIRST_SEED LAST_SEED   (round 2, final kernels: seeds 0..2500, 0 mismatches)"""
+usage: python tests/fuzz/fuzz_marching_cubes.py FIRST_SEED LAST_SEED   (round 2: seeds 0..2500 over the kernel versions of the round, 0..2300 on the final ones: 0 mismatches)"""
 import sys, os, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
