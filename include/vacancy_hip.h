@@ -267,7 +267,9 @@ int vcy_reset(vcy_ctx* ctx);
  * moved than with the bit planes in memory (the default and the path of every other shape), 2 - 30 % more time.
  * "meshkeys" (default 1): vcy_extract_iso returns vcy_mesh.edge_keys; 0 leaves it NULL (nothing is computed for
  * it or copied: a third of the mesh bytes) -- for callers that do not merge z-slabs, i.e. what the reference's
- * MarchingCubes returns. */
+ * MarchingCubes returns.
+ * "inject_carve_failure" (test hook, default 0): the next `value` applications of views fail with
+ * VCY_ERR_INTERNAL before anything is launched -- how the tests exercise the error contract of vcy_carve. */
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
 /* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep", "meshkeys"), or "div_level": the division sequence
  * the last fused launch was instantiated with (2: 4 instructions, 1: 6, 0: full IEEE expansion). */

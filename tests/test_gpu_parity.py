@@ -857,3 +857,46 @@ def test_short_division_is_only_used_when_verified():
             assert_state_equal(dev, orc, "f=%r shortdiv=%d level=%d" % (float(f), short, lvl))
             dev.close()
     assert 2 in levels  # the common case
+
+
+def test_failed_flush_is_reported_once_to_the_carve_loop():
+    """vacancy_hip.h, vcy_carve: a failure while applying queued views is returned by the call that applies
+    them; only when that call was NOT a carve entry point (a download, an extraction) does the next carve
+    call return it once more.  A carve entry point that already returned the failure must not make the
+    following, valid view fail as well.  ("inject_carve_failure": test hook, the next application fails.)"""
+    n, nv, w, h = 40, 40, 96, 80
+    opt = synth.sphere_option(n)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    sdf = O.make_sdf(masks[0])
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init(), vc.last_error()
+    # (a) the flush happens inside a download: reported there AND by the next carve call, then cleared
+    dev.set_param("inject_carve_failure", 1)
+    assert dev.Carve(views[0], sdf)              # queued
+    with pytest.raises(RuntimeError, match="injected"):
+        dev.download()
+    assert not dev.Carve(views[1], sdf)          # the loop's `if (!Carve())` sees it ...
+    assert "earlier queued view failed" in vc.last_error()
+    assert dev.Carve(views[1], sdf), vc.last_error()   # ... once
+    dev.download()
+    # (b) the flush happens inside a carve entry point (32 views waiting): that call returns the failure,
+    # the next valid view is accepted and queued
+    dev.reset()
+    dev.set_param("inject_carve_failure", 1)
+    for i in range(31):
+        assert dev.Carve(views[i], sdf), vc.last_error()
+    assert not dev.Carve(views[31], sdf)
+    assert "injected" in vc.last_error()
+    assert dev.Carve(views[32], sdf), vc.last_error()
+    # (c) the same through the batch entry point with views still queued
+    dev.reset()
+    assert dev.Carve(views[0], sdf)
+    dev.set_param("inject_carve_failure", 1)
+    d = dev.upload_sdf(sdf)
+    assert not dev.CarveBatchDevice(views[1:3], [d, d])
+    assert dev.Carve(views[3], sdf), vc.last_error()
+    dev.free_device(d)
+    # and the state after all this is what the oracle gets from the views that were applied
+    orc = O.OracleGrid(opt)
+    orc.carve(views[3], sdf)
+    assert_state_equal(dev, orc, "after injected failures")

@@ -334,6 +334,9 @@ typedef uint32_t __attribute__((address_space(3))) lds_u32;
 // image pixel (min(tx0 + i, roi_max.x), min(ty0 + j, roi_max.y)), for the th + 1 <= 16 rows the taps reach.
 // Asynchronous: the data is in LDS once the wave's vmcnt has drained (raw_tile_wait).
 __device__ __forceinline__ void raw_prefetch(const ViewParams& v, const TileInfo& ti, int lane, float* buf) {
+#ifdef VCY_FLOOR_NO_TILE_LOADS  // development build (issue floor, profiles/tools/issue_floor.sh): the taps read whatever LDS holds
+  return;
+#endif
   const int nq = __builtin_amdgcn_readfirstlane(ti.nq);
   if (nq == 0) return;
   const int th = __builtin_amdgcn_readfirstlane(ti.th);
@@ -1215,7 +1218,12 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   if (lane_valid) {
     if (vec_io) {
       bool changed = fresh != 0;  // (a fresh slab has never been written: every voxel is stored)
+#ifdef VCY_FLOOR_NO_STORES  // development build (issue floor): results stay live, nothing is stored
+      changed = s[0] == 1.2345e-30f && s[7] == 5.4321e-30f && (int)n[3] == 77;
+      if (false) {
+#else
       if (!fresh) {
+#endif
         const CountVec cv = *(const CountVec*)(cnt + row0 + x_first);
 #pragma unroll
         for (int k = 0; k < WX; ++k) changed = changed || (int)n[k] != (int)cv[k];

@@ -114,8 +114,10 @@ static void launch_view(vcy_ctx* c, const GridParams& g, const ViewParams& v, co
   }
 }
 
-// Applies the views queued by the per-view entry points, in order, as one batch.
-int flush_pending(vcy_ctx* c) {
+// Applies the views queued by the per-view entry points, in order, as one batch.  `from_carve`: the caller is
+// a carve entry point, whose own return value carries a failure to the `if (!Carve())` of the host loop; any
+// other caller (an extraction, a download ...) cannot, so the failure is kept for the next carve call.
+int flush_pending(vcy_ctx* c, bool from_carve) {
   if (c->pending.empty()) return VCY_OK;
   std::vector<vcy_ctx::PendingView> todo;
   todo.swap(c->pending);  // launch_carve flushes first: nothing left to recurse on
@@ -130,7 +132,7 @@ int flush_pending(vcy_ctx* c) {
   // from a neighbour that has applied the same views and stay valid
   const bool halo_valid = c->halo_valid;
   const int rc = launch_carve(c, (int)todo.size(), views.data(), ptrs.data());
-  if (rc != VCY_OK) {  // also reported by the next carve call, whoever triggered this flush
+  if (rc != VCY_OK && !from_carve) {  // also reported by the next carve call (vacancy_hip.h, vcy_carve)
     c->deferred_rc = rc;
     c->deferred_msg = vcy_last_error();
   }
@@ -148,8 +150,13 @@ int flush_pending(vcy_ctx* c) {
 
 int launch_carve(vcy_ctx* c, int n_views, const vcy_view* views, const float* const* sdf_dev) {
   {
-    const int rcf = flush_pending(c);  // earlier per-view calls come first
+    const int rcf = flush_pending(c, true);  // earlier per-view calls come first
     if (rcf != VCY_OK) return rcf;
+  }
+  if (c->inject_fail > 0) {  // test hook (vcy_set_param "inject_carve_failure"): this application of views fails
+    --c->inject_fail;
+    set_error("injected failure (vcy_set_param inject_carve_failure)");
+    return VCY_ERR_INTERNAL;
   }
   const vcy_update_option& u = c->opt.update_option;
   GridParams g;

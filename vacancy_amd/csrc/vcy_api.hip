@@ -357,6 +357,10 @@ int vcy_set_stream(vcy_ctx* c, void* s) {
 
 int vcy_set_param(vcy_ctx* c, const char* name, int value) {
   if (!c || !name) return VCY_ERR_INVALID_ARG;
+  if (std::strcmp(name, "inject_carve_failure") == 0) {  // test hook; does not touch the queue
+    c->inject_fail = value > 0 ? value : 0;
+    return VCY_OK;
+  }
   { const int rcf = flush_pending(c); if (rcf != VCY_OK) return rcf; }  // queued views keep the old setting
   if (std::strcmp(name, "defer") == 0) {
     c->defer = value != 0;
@@ -739,11 +743,11 @@ constexpr int kMaxPendingViews = 32;  // queued images held at most (3.7 MB each
 // model (one model per fused launch).
 static int enqueue_view(vcy_ctx* c, const vcy_view* view, float* d_img, size_t cap) {
   int rc = VCY_OK;
-  if (!c->pending.empty() && (c->pending.front().view.is_ortho != 0) != (view->is_ortho != 0)) rc = flush_pending(c);
+  if (!c->pending.empty() && (c->pending.front().view.is_ortho != 0) != (view->is_ortho != 0)) rc = flush_pending(c, true);
   if (rc == VCY_OK) {
     c->pending.push_back(vcy_ctx::PendingView{*view, d_img, cap});
     c->halo_valid = false;
-    if ((int)c->pending.size() >= kMaxPendingViews) rc = flush_pending(c);
+    if ((int)c->pending.size() >= kMaxPendingViews) rc = flush_pending(c, true);
   } else {
     c->sdf_pool.emplace_back(d_img, cap);
   }

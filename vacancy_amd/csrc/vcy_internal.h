@@ -86,6 +86,7 @@ struct vcy_ctx {
   // A queued view that failed to apply inside a call that cannot report it to a Carve() caller (an
   // extraction, a download ...) is remembered: the NEXT carve entry point returns it (then clears it).
   int deferred_rc = 0;
+  int inject_fail = 0;                // test hook: the next n applications of views fail (vcy_set_param "inject_carve_failure")
   std::string deferred_msg;
   int last_div_level = 0;             // division variant of the last fused launch (vcy_get_param "div_level")
   bool use_short_div = true;          // vcy_set_param("shortdiv", 0): always the full division sequence
@@ -140,7 +141,7 @@ bool fused_eligible(const vcy_ctx* ctx, int n_views, const vcy_view* views);
 int launch_carve_fused(vcy_ctx* ctx, const GridParams& g, int n_views, const ViewParams* vp);
 int fused_max_views();
 int selftest_fused(hipStream_t stream);
-int flush_pending(vcy_ctx* ctx);   // applies vcy_ctx::pending (no-op when empty)
+int flush_pending(vcy_ctx* ctx, bool from_carve = false);   // applies vcy_ctx::pending (no-op when empty)
 // mc_kernels.hip
 int extract_iso(vcy_ctx* ctx, double iso, int linear_interp, vcy_mesh* out);
 // sdf2d.hip
