@@ -61,6 +61,11 @@ def parse(argv=None):
     ap.add_argument("--allow-gloo", action="store_true",
                     help="let the halo exchange fall back to gloo (host staging) when RCCL cannot initialise; "
                          "without this flag that is a failure")
+    ap.add_argument("--launch", default="auto", choices=["auto", "torchrun", "inprocess"],
+                    help="how N > 1 GPUs are driven: torchrun = one process per GPU (torch.distributed.run, the halo "
+                         "all-gather through torch.distributed's nccl backend); inprocess = ONE process, a host thread "
+                         "per GPU over the C-ABI, the all-gather issued by the library (vcy_halo_allgather); auto = "
+                         "torchrun, and inprocess if that cannot start or its nccl backend fails")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="no GPU work: launch, rendezvous and the halo all-gather of this configuration with "
                          "rank-stamped host buffers (CPU test of the multi-rank launch path)")
@@ -84,6 +89,7 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
+    env["VCY_BENCH_SELF_LAUNCHED"] = "1"  # a failing nccl backend is then handled by this parent (main)
     return subprocess.call(cmd, env=env)
 
 
@@ -163,14 +169,27 @@ def cpu_baseline(args, views, sdfs, budget_s):
     }
 
 
-def load_counters(key):
+def library_build():
+    """vcy_version() of the loaded library: "vacancy_amd <version> (gfx950) src:<hash of its sources>"."""
+    from vacancy_amd import capi
+    return capi.load().vcy_version().decode()
+
+
+def load_counters(key, build, path=None):
     """Per-launch hardware counters of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/counters.json, written by profiles/tools/summarize_pmc.py), or None."""
-    path = os.path.join(ROOT, "profiles", "counters.json")
+    (profiles/counters.json, written by profiles/tools/summarize_pmc.py).  Returns (entry, None), or
+    (None, reason): counters are only meaningful for the build they were collected on, so an entry whose
+    "build" stamp is not `build` -- the vcy_version() of the library loaded now -- is refused."""
+    path = path or os.path.join(ROOT, "profiles", "counters.json")
     try:
-        return json.load(open(path)).get(key)
-    except Exception:
-        return None
+        entry = json.load(open(path)).get(key)
+    except Exception as e:
+        return None, "no counters file (%s)" % type(e).__name__
+    if entry is None:
+        return None, "no counters collected for %s" % key
+    if entry.get("build") != build:
+        return None, "counters of another build (%s), this library is %s" % (entry.get("build"), build)
+    return entry, None
 
 
 def valu_issue_cycles(ctr):
@@ -224,10 +243,102 @@ def plumbing_check(args, rank, world, dist, backend):
     return 0 if ok else 1
 
 
+def run_inprocess(args, why=None):
+    """N GPUs from ONE process (vacancy_amd.sharded.ShardedVoxelCarver): a host thread per device over the
+    C-ABI, no torch, no rendezvous; the halo exchange is the library's own RCCL all-gather.  Same workload,
+    same timed region (barrier -- here a thread barrier after a device sync -- on both sides, the slowest
+    device's time) and the same JSON line as the one-process-per-GPU form."""
+    from vacancy_amd import carver as vc
+    from vacancy_amd import synth
+    from vacancy_amd.capi import UpdateOption
+    from vacancy_amd.sharded import ShardedVoxelCarver
+
+    n, nv, G = args.grid, args.views, args.gpus
+    uo = UpdateOption(voxel_update=1, use_truncation=True, truncation_band=0.1) if args.mode == "tsdf" \
+        else UpdateOption()
+    opt = synth.sphere_option(n, uo)
+    views, masks = synth.sphere_views(n, nv, args.width, args.height)
+    sdf0 = vc.make_sdf(masks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
+    devices = list(range(G))
+    if "VCY_BENCH_FORCE_DEVICE" in os.environ:  # several "GPUs" on one device (boxes with a single GPU)
+        devices = [int(os.environ["VCY_BENCH_FORCE_DEVICE"])] * G
+    k = args.slabs_per_gpu if args.slabs_per_gpu > 0 else 2
+    sh = ShardedVoxelCarver(opt, devices, k)
+    if not sh.Init():
+        raise SystemExit("vcy_create failed: " + vc.last_error())
+    sh.set_param("fused", args.batch)
+    sh.set_param("cull", args.cull)
+    # inputs resident in HBM of every device before the timed region
+    imgs = [cs[0].upload_sdf(sdf0) for cs in sh.by_device]
+    batches = [vc.VoxelCarver.prepare_batch(views, [imgs[g]] * nv) for g in range(G)]
+    sh.carve_batch(batches, steps=args.warmup)
+    wall_ms = sh.carve_batch(batches, steps=args.steps)
+    kernel_ms = list(sh.last_kernel_ms)
+    value = float(n) ** 3 * nv * args.steps / (wall_ms * 1e-3) / 1e6
+    bpv = 4.0 if args.mode == "default" else 4.0 + (1 if uo.voxel_max_update_num <= 254 else 2)
+    views_per_launch = min(nv, 64) if args.batch else 1
+    launches = ((nv + views_per_launch - 1) // views_per_launch) * k
+    slab_vox = float(n) ** 3 / (G * k)
+    avg_launch_ms = max(kernel_ms) / launches
+    achieved = slab_vox * views_per_launch * bpv / (avg_launch_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "carve_fused_kernel" if args.batch else "carve_view_kernel",
+                "avg_launch_ms": round(avg_launch_ms, 4),
+                "note": "per GPU, of the slowest device; algorithmic bytes as in the one-GPU line"}
+    mc = None
+    collective = None
+    if not args.no_mc:
+        try:
+            sh.set_param("meshkeys", 1)
+            sh.extract_slabs(0.0, True)  # first run allocates
+            meshes = sh.extract_slabs(0.0, True)
+            collective = dict(sh.last_collective)
+            per_dev = [sum(m["device_ms"] for m, c in zip(meshes, sh.slabs) if c in cs) for cs in sh.by_device]
+            mc_ms = max(per_dev)
+            cells = float(n - 1) ** 3
+            mc = {"mcells_per_s": round(cells / (mc_ms * 1e-3) / 1e6, 1), "device_ms": round(mc_ms, 3),
+                  "device_ms_per_gpu": [round(x, 3) for x in per_dev],
+                  "vertices": int(sum(len(m["vertices"]) - m["n_foreign"] for m in meshes)),
+                  "faces": int(sum(len(m["faces"]) for m in meshes)),
+                  "roofline_frac": round(cells * 4.0 / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS / G, 4),
+                  "mesh_arrays": "vertices, faces, edge keys (slab merge)"}
+        except Exception as e:
+            mc = {"error": "%s: %s" % (type(e).__name__, e)}
+    if collective is None:
+        collective = {"backend": "none", "ranks": G, "bytes_per_rank": 0}
+    collective["launch"] = "in-process: one host thread per GPU over the C-ABI"
+    out = {"metric": "Mvoxel*views/s (Carve)", "value": round(value, 1), "unit": "Mvoxel*views/s", "n_gpus": G,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall_ms / args.steps, 3),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%d^3 grid x %d views at %dx%d, %s mode, z-slab sharded over %d GPU(s)"
+                                  % (n, nv, args.width, args.height, args.mode, G),
+                      "grid": n, "views": nv, "image": [args.width, args.height], "mode": args.mode,
+                      "fused_views_per_launch": views_per_launch, "view_dropping": bool(args.cull),
+                      "slabs_per_gpu": k, "launch": "inprocess", "devices": devices},
+           "roofline": roofline, "mc": mc, "collective": collective,
+           "per_gpu": [{"device": devices[g], "kernel_ms_per_step": round(kernel_ms[g], 3),
+                        "slabs_z": [list(sh.z_ranges[s]) for s in range(g, G * k, G)]} for g in range(G)]}
+    if why:
+        out["config"]["launch_note"] = why
+    print(json.dumps(out))
+    for g, cs in enumerate(sh.by_device):
+        cs[0].free_device(imgs[g])
+    sh.close()
+    return 0
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        raise SystemExit(self_launch(args))
+        if args.launch == "inprocess" and not args.plumbing_check:
+            raise SystemExit(run_inprocess(args))
+        rc = self_launch(args)
+        if rc != 0 and args.launch == "auto" and not args.plumbing_check:
+            sys.stderr.write("bench: torch.distributed.run ended with rc %d; running the %d GPUs from this process\n"
+                             % (rc, args.gpus))
+            raise SystemExit(run_inprocess(args, "torch.distributed.run failed (rc %d): in-process fallback" % rc))
+        raise SystemExit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -256,6 +367,17 @@ def main():
                 if int(probe.item()) != world:
                     raise RuntimeError("all_reduce over RCCL returned %r for %d ranks" % (probe.item(), world))
             except Exception as e:
+                if not args.allow_gloo and args.launch == "auto" and "VCY_BENCH_INPROCESS_FALLBACK" not in os.environ:
+                    # torch's nccl backend cannot start: the same job from ONE process (rank 0 drives every GPU
+                    # through the C-ABI, the library issues the all-gather itself); the other ranks step aside.
+                    # Under `python bench.py --gpus N` the parent does this after rc 3 instead (self_launch).
+                    sys.stderr.write("bench: RCCL (backend nccl) failed on rank %d: %s\n" % (rank, e))
+                    if os.environ.get("VCY_BENCH_SELF_LAUNCHED") == "1":
+                        raise SystemExit(3)
+                    if rank != 0:
+                        raise SystemExit(0)
+                    raise SystemExit(run_inprocess(args, "torch.distributed nccl backend failed (%s): in-process "
+                                                         "fallback on rank 0" % str(e)[:160]))
                 if not args.allow_gloo:
                     sys.stderr.write("bench: RCCL (backend nccl) failed: %s\n" % e)
                     raise SystemExit(3)
@@ -348,6 +470,20 @@ def main():
 
     total_vv = float(n) ** 3 * nv * args.steps
     value = total_vv / elapsed / 1e6
+    # per rank: device, kernel time per step (HIP events on its stream) and the z-ranges of its slabs, so that an
+    # imbalance between the ranks is visible in the line
+    per_gpu = None
+    if dist is not None:
+        row = torch.zeros(world, 2 + 2 * len(my_slabs), dtype=torch.float64, device=red_dev)
+        row[rank, 0] = float(local_rank)
+        row[rank, 1] = sum(kernel_ms) / max(1, len(kernel_ms))
+        for j, (_, z0, z1) in enumerate(my_slabs):
+            row[rank, 2 + 2 * j], row[rank, 3 + 2 * j] = float(z0), float(z1)
+        dist.all_reduce(row)
+        rows = row.cpu().tolist()
+        per_gpu = [{"rank": r, "device": int(rows[r][0]), "kernel_ms_per_step": round(rows[r][1], 3),
+                    "slabs_z": [[int(rows[r][2 + 2 * j]), int(rows[r][3 + 2 * j])] for j in range(len(my_slabs))]}
+                   for r in range(world)]
 
     # roofline of the dominant kernel (carve), this rank's slab: algorithmic bytes per launch /
     # launch duration from HIP events on the launch stream.
@@ -362,7 +498,8 @@ def main():
     alg_bytes = slab_vox * views_per_launch * bytes_per_vv(args.mode, uo)
     achieved = alg_bytes / (avg_launch_ms * 1e-3) / 1e9
     ckey = "%s_%d_%d_b%d_c%d" % (args.mode, n, nv, args.batch, args.cull)
-    ctr = load_counters(ckey) if world == 1 else None
+    build = library_build()
+    ctr, ctr_note = load_counters(ckey, build) if world == 1 else (None, "counters are collected on one GPU")
     traffic = ctr.get("hbm_bytes_per_launch") if ctr else None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -373,6 +510,8 @@ def main():
                         "reference's per-view API); the fused kernel keeps the state in registers across the views, "
                         "so its real HBM traffic is `traffic` and the roof that binds it is VALU issue: see "
                         "hbm_real_frac and valu_issue_frac"}
+    if ctr is None:
+        roofline["counters_note"] = ctr_note
     # the roofs that actually bind the kernel: real HBM traffic and VALU issue slots (counters of the
     # committed PMC passes for this workload, duration measured live above)
     if traffic:
@@ -407,14 +546,14 @@ def main():
             for c in devs:
                 c.set_param("meshkeys", 0 if single else 1)
                 mesh = c.ExtractIsoSurface(0.0, True)  # first run: scratch and host buffers are allocated
-                best = None
+                runs = []
                 for _ in range(3):  # a sequence of extractions, as in the reference's carve-and-extract loop
                     mesh = c.ExtractIsoSurface(0.0, True)
                     mc_calls.append([round(mesh["device_ms"], 3), round(mesh["wall_ms"], 3)])
-                    if best is None or mesh["wall_ms"] < best[1]:
-                        best = (mesh["device_ms"], mesh["wall_ms"])
-                mc_ms += best[0]
-                mc_wall += best[1]
+                    runs.append((mesh["wall_ms"], mesh["device_ms"]))
+                runs.sort()
+                mc_ms += runs[1][1]   # the MEDIAN of the three by wall time
+                mc_wall += runs[1][0]
                 nvert += len(mesh["vertices"]) - mesh["n_foreign"]
                 nface += len(mesh["faces"])
             if dist is not None:
@@ -429,13 +568,24 @@ def main():
                   "wall_ms": round(mc_wall, 3),
                   "wall_note": "vcy_extract_iso entry -> mesh arrays in host memory (what the reference's "
                                "MarchingCubes timer brackets, marching_cubes.cc:65-66,226-227); device_ms = kernels only; "
-                               "the extraction with the shortest wall time of three consecutive ones after a first "
+                               "the median (by wall time) of three consecutive extractions after a first "
                                "that allocates (all listed in calls_device_wall_ms)",
                   "calls_device_wall_ms": mc_calls,
                   "mesh_arrays": "vertices, faces" if single else "vertices, faces, edge keys (slab merge)",
                   "vertices": int(nvert), "faces": int(nface),
                   "roofline_frac": round(cells * 4.0 / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            mctr = load_counters("mc_%d" % n) if world == 1 else None
+            if single:
+                # the same extraction reading every brick ("mcskip" 0: no use of the brick minima the carve kernel keeps)
+                c = devs[0]
+                c.set_param("mcskip", 0)
+                dense = sorted(c.ExtractIsoSurface(0.0, True)["device_ms"] for _ in range(3))[1]
+                c.set_param("mcskip", 1)
+                mc["device_ms_every_brick_read"] = round(dense, 3)
+                mc["roofline_frac_every_brick_read"] = round(cells * 4.0 / (dense * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                mc["note"] = ("roofline_frac counts the ALGORITHMIC 4 B per cell; with the brick minima (default) voxels of "
+                              "bricks the carve left entirely outside the surface are not read, so the bytes really moved "
+                              "are fewer (`traffic`); *_every_brick_read is the dense sweep")
+            mctr = load_counters("mc_%d" % n, build)[0] if world == 1 else None
             if mctr:
                 mc["traffic"] = mctr.get("hbm_bytes_per_call")
         except Exception as e:  # the carve metric above stands on its own
@@ -488,6 +638,52 @@ def main():
                 variants[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         roofline["value_cull0"] = variants.get("cull0", {}).get("value")
         roofline["value_tsdf"] = variants.get("tsdf", {}).get("value")
+        # The reference's own call pattern (examples.cc:117-149): `for each view: Carve(one view); ExtractIsoSurface()`.
+        # An extraction between two views means every view is a launch of its own (nothing to fuse across): the
+        # single-view path, where a wave drops its view against the brick minimum the previous launch left
+        # before it reads any state.  "defer" 0 so that the carve is timed by itself (HIP events around each call);
+        # per_view_defer0 is the same loop without the extractions.
+        for name, extract in (("per_view_interleaved", True), ("per_view_defer0", False)):
+            try:
+                cs = make_carvers(opt, args.cull, my_slabs)
+                c0 = cs[0]
+                c0.set_param("defer", 0)
+                c0.set_param("meshkeys", 0)
+                carve_ms, mc_dev, mc_wall, t_wall = [], [], [], None
+                for rep in range(2):  # the second pass is the one reported (buffers allocated, sizes guessed)
+                    c0.reset()
+                    carve_ms, mc_dev, mc_wall = [], [], []
+                    c0.sync()
+                    tw = time.perf_counter()
+                    for i in range(nv):
+                        c0.timer_begin()
+                        if not c0.CarveDevice(views[i], d_sdf[i]):
+                            raise RuntimeError(vc.last_error())
+                        carve_ms.append(c0.timer_end())
+                        if extract:
+                            mesh = c0.ExtractIsoSurface(0.0, True)
+                            mc_dev.append(mesh["device_ms"])
+                            mc_wall.append(mesh["wall_ms"])
+                    c0.sync()
+                    t_wall = (time.perf_counter() - tw) * 1e3
+                tot = sum(carve_ms)
+                rec = {"value": round(float(n) ** 3 * nv / (tot * 1e-3) / 1e6, 1), "unit": "Mvoxel*views/s",
+                       "carve_ms_total": round(tot, 3), "carve_ms_first_view": round(carve_ms[0], 3),
+                       "carve_ms_per_view_after_first": round((tot - carve_ms[0]) / max(1, nv - 1), 3),
+                       "algorithmic_frac": round(float(n) ** 3 * nv * bytes_per_vv(args.mode, uo) / (tot * 1e-3) / 1e9
+                                                 / HBM_PEAK_GBS, 4),
+                       "loop_wall_ms": round(t_wall, 2), "launches": nv, "defer": 0}
+                if extract:
+                    cells = float(n - 1) ** 3
+                    med = sorted(mc_dev)[len(mc_dev) // 2]
+                    rec["mc_device_ms_median"] = round(med, 3)
+                    rec["mc_wall_ms_median"] = round(sorted(mc_wall)[len(mc_wall) // 2], 3)
+                    rec["mc_mcells_per_s"] = round(cells / (med * 1e-3) / 1e6, 1)
+                variants[name] = rec
+                for c in reversed(cs):
+                    c.close()
+            except Exception as e:
+                variants[name] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     out = {
         "metric": "Mvoxel*views/s (Carve)", "value": round(value, 1), "unit": "Mvoxel*views/s",
@@ -503,6 +699,11 @@ def main():
                                 0: "full IEEE expansion"}.get(dev.get_param("div_level"), "?")},
         "roofline": roofline, "mc": mc, "collective": collective,
     }
+    if per_gpu is not None:
+        out["per_gpu"] = per_gpu
+        out["config"]["launch"] = "torch.distributed.run (one process per GPU)"
+        if isinstance(out["collective"], dict):
+            out["collective"]["launch"] = "one process per GPU (torch.distributed, backend %s)" % backend
     if variants is not None:
         out["variants"] = variants
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

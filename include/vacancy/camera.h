@@ -3,6 +3,8 @@
 // size, pose (w2c = c2w.inverse(), reference camera.cc:25,39-42) and Project (:131-137, :201-205).
 #pragma once
 
+#include <cmath>
+
 #include "vacancy/common.h"
 
 namespace vacancy {

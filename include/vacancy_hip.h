@@ -233,6 +233,9 @@ int vcy_halo_copy_from(vcy_ctx* ctx, vcy_ctx* below);
  * opened on first use; VCY_ERR_UNSUPPORTED if it cannot be loaded -- there is no silent fallback to
  * peer copies (vcy_halo_copy_from is the explicit alternative). */
 int vcy_halo_allgather(vcy_ctx* const* slabs, int n_slabs);
+/* Releases what vcy_halo_allgather keeps between calls (communicators, streams and staging buffers per
+ * device set); the next exchange builds them again.  Call when no exchange is in flight. */
+void vcy_halo_shutdown(void);
 /* What the last vcy_halo_allgather of this process did, as text:
  * "backend=rccl op=ncclAllGather version=V ranks=R bytes_per_rank=B calls=N lib=..." or "none". */
 const char* vcy_last_collective(void);
@@ -296,6 +299,8 @@ int vcy_selftest(vcy_ctx* ctx);
 int vcy_measure_bandwidth(int device_id, uint64_t bytes, int reps, double* read_gbs, double* copy_gbs);
 
 const char* vcy_last_error(void);
+/* "vacancy_amd <version> (gfx950) src:<hash>": the hash covers every source file the library was built from
+ * (profiles/counters.json entries are stamped with this string; bench.py drops counters of another build). */
 const char* vcy_version(void);
 
 #ifdef __cplusplus

@@ -25,6 +25,13 @@ def short(name):
     return n.replace("_kernel", "")
 
 
+def library_build():
+    """vcy_version() of the library the counters were collected on (VCY_HIP_LIB or the in-tree build)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from vacancy_amd import capi
+    return capi.load().vcy_version().decode()
+
+
 def main():
     d, out = sys.argv[1], sys.argv[2]
     per = {}
@@ -67,6 +74,7 @@ def main():
             allc = {}
         entry = {k: v for k, v in per[kernel].items() if not k.startswith("dispatches_")}
         entry["source"] = os.path.relpath(out, os.path.dirname(os.path.dirname(os.path.abspath(cpath))))
+        entry["build"] = library_build()  # bench.py only uses counters of the build it runs
         allc[key] = entry
         json.dump(allc, open(cpath, "w"), indent=1, sort_keys=True)
         print("updated", cpath, key)
@@ -80,6 +88,7 @@ def main():
             except Exception:
                 allc = {}
             entry["source"] = os.path.relpath(out, os.path.dirname(os.path.dirname(os.path.abspath(cpath))))
+            entry["build"] = library_build()
             allc[key] = entry
             json.dump(allc, open(cpath, "w"), indent=1, sort_keys=True)
             print("updated", cpath, key, entry["hbm_bytes_per_call"])

@@ -142,3 +142,124 @@ def test_bench_refuses_a_gloo_halo_exchange_unless_allowed():
     rc, line, err = _run_bench(["--gpus", "2", "--grid", "64"], {"VCY_BENCH_BACKEND": "gloo"})
     assert rc != 0 and line is None
     assert "allow-gloo" in err
+
+
+# ---- the in-process form: one thread per device, no torch (vacancy_amd/sharded.py) -----------------
+
+class OracleSlab:
+    """Stand-in for vacancy_amd.carver.VoxelCarver on a "device": the CPU oracle carves, and extracts exactly what
+    one GPU extracts from its slab + two halo slices (oracle_lib.marching_cubes_slab).  Records which thread drove
+    it and what halo it was handed."""
+    log = []
+
+    def __init__(self, option, device_id, z_range):
+        self.option, self.device, self.z_range = option, device_id, tuple(z_range)
+        self.grid, self.halo, self.dims, self.params = None, None, None, {}
+
+    def Init(self):
+        self.grid = O.OracleGrid(self.option)
+        self.dims = self.grid.dims
+        self.s = self.dims[0] * self.dims[1]
+        return True
+
+    def close(self):
+        if self.grid is not None:
+            self.grid.close()
+            self.grid = None
+
+    def set_param(self, name, value):
+        self.params[name] = value
+
+    def reset(self):
+        self.grid.close()
+        self.grid = O.OracleGrid(self.option)
+
+    def sync(self):
+        pass
+
+    def timer_begin(self):
+        import time
+        self._t = time.perf_counter()
+
+    def timer_end(self):
+        import time
+        return (time.perf_counter() - self._t) * 1e3
+
+    def CarveBatchDevice(self, batch):
+        import threading
+        OracleSlab.log.append((self.device, threading.get_ident()))
+        for view, sdf in batch:
+            self.grid.carve(view, sdf)
+        return True
+
+    def halo_pack_host(self):
+        sdf, cnt = self.grid.download()
+        z1 = self.z_range[1]
+        a = sdf[(z1 - 2) * self.s:z1 * self.s].astype(np.float32).tobytes()
+        b = cnt[(z1 - 2) * self.s:z1 * self.s].astype(np.uint16).tobytes()
+        return np.frombuffer(a + b, np.uint8).copy()
+
+    def halo_install_host(self, pack):
+        part = np.ascontiguousarray(pack, np.uint8).tobytes()
+        self.halo = (np.frombuffer(part[:2 * self.s * 4], np.float32), np.frombuffer(part[2 * self.s * 4:], np.uint16))
+
+    def ExtractIsoSurface(self, iso=0.0, linear=True):
+        m = O.marching_cubes_slab(self.grid, self.z_range[0], self.z_range[1], iso, linear)
+        m["device_ms"] = 0.0
+        return m
+
+
+@pytest.mark.parametrize("devices,k", [([0, 1], 1), ([0, 1, 2], 2), ([5], 3)])
+def test_inprocess_sharded_carver_with_fake_devices(devices, k):
+    """bench.py --launch inprocess / the nccl-failure fallback: ShardedVoxelCarver cuts the grid into
+    len(devices) * k slabs, slab s on device s % G, one host thread per device; the halo exchange and the merge
+    by edge key are the code the GPU run uses (host packs instead of RCCL for the stand-ins).  The merged mesh
+    is the serial extraction's, array for array."""
+    from vacancy_amd.sharded import ShardedVoxelCarver
+    masks = B.load_masks()
+    views = B.bunny_views(lambda t, q: O.affine_inverse(O.pose_from_tum(t, q)))
+    opt = B.bunny_option(10.0)
+    full = O.OracleGrid(opt)
+    batch = [(views[i], O.make_sdf(masks[i])) for i in range(6)]
+    for v, s in batch:
+        full.carve(v, s)
+    nz = full.dims[2]
+    OracleSlab.log = []
+    sh = ShardedVoxelCarver(opt, devices, k, factory=OracleSlab, nz=nz)
+    assert sh.Init()
+    G = len(devices)
+    assert len(sh.slabs) == G * k and sh.z_ranges[0][0] == 0 and sh.z_ranges[-1][1] == nz
+    for s, c in enumerate(sh.slabs):
+        assert c.device == devices[s % G] and c.z_range == vdist.slab_range(nz, s, G * k)
+    wall = sh.carve_batch([batch] * G, steps=1)
+    assert wall > 0 and len(sh.last_kernel_ms) == G
+    # every device's slabs were driven by ONE thread, and different devices by different threads
+    threads = {}
+    for dev, tid in OracleSlab.log:
+        threads.setdefault(dev, set()).add(tid)
+    assert all(len(t) == 1 for t in threads.values())
+    assert len({next(iter(t)) for t in threads.values()}) == G
+    merged = sh.ExtractIsoSurface(0.0, True)
+    assert sh.last_collective["backend"] == ("host" if G * k > 1 else "none")
+    sdf, cnt = full.download()
+    s = full.dims[0] * full.dims[1]
+    for sid, c in enumerate(sh.slabs):
+        if sid == 0:
+            assert c.halo is None
+            continue
+        z0 = c.z_range[0]
+        assert np.array_equal(c.halo[0], sdf[(z0 - 2) * s:z0 * s])
+        assert np.array_equal(c.halo[1], cnt[(z0 - 2) * s:z0 * s].astype(np.uint16))
+    ref = full.marching_cubes()
+    assert len(ref["vertices"]) == 8672
+    assert np.array_equal(merged["vertices"].view(np.uint32), ref["vertices"].view(np.uint32))
+    assert np.array_equal(merged["faces"], ref["faces"]) and np.array_equal(merged["keys"], ref["keys"])
+    sh.close()
+
+
+def test_bench_inprocess_launch_is_selected_without_torch_distributed():
+    """`--launch inprocess` never re-executes under torch.distributed.run: without a GPU it must fail inside
+    vcy_create of THIS process (no rendezvous, no child ranks), loudly."""
+    rc, line, err = _run_bench(["--gpus", "2", "--launch", "inprocess", "--grid", "64", "--views", "2", "--no-mc"])
+    assert rc != 0 and line is None
+    assert "vcy_create failed" in err and "torch.distributed" not in err

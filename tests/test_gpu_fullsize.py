@@ -73,6 +73,63 @@ def _mesh_invariants(m, expect_closed=True):
         assert nv - len(uniq) + len(f) == 2  # Euler characteristic of a sphere-like hull
 
 
+def _oracle_slices_check(dev, mesh, n, za, uo=None, nslices=16):
+    """Marching cubes at full size against the ORACLE: the carved state of slices [za, za + 16) is read back
+    (vcy_download_voxels), loaded into an oracle grid of n x n x 16 voxels whose voxel centres are those slices',
+    and the oracle's slab extraction of its layers 2..15 (slices 0, 1 as the halo, exactly what one rank of a
+    sharded run computes) is compared with what the device's WHOLE-GRID extraction holds for those cell layers:
+    the same faces in the same order (as triples of global edge keys), the same vertex bits, and the device's
+    vertex numbering increasing in order of first reference.  This is where the 64-bit offsets, the plane layout
+    and cell indices beyond 2^32 are exercised under an oracle's eyes."""
+    sl = n * n
+    ids = np.arange(za * sl, (za + nslices) * sl, dtype=np.int64)
+    ds, du = dev.download_voxels(ids)
+    h = n / 2.0
+    from vacancy_amd.capi import CarverOption
+    sub = CarverOption(bb_min=(-h, -h, za - h), bb_max=(h, h, za + nslices - h), resolution=1.0,
+                       update_option=uo or UpdateOption())
+    orc = O.OracleGrid(sub)
+    assert orc.dims == (n, n, nslices)
+    ax = O.axis_positions(-h, h, 1.0, n)
+    zpos = orc.positions()[::sl, 2]
+    assert np.array_equal(zpos.view(np.uint32), ax[za:za + nslices].view(np.uint32))  # same voxel centres
+    orc.upload(ds, du)
+    del ds, du
+    om = O.marching_cubes_slab(orc, 2, nslices, 0.0, True)
+    orc.close()
+    assert len(om["faces"]) > 0, "the slices chosen hold no surface"
+    okeys = om["keys"] + np.int64(za) * sl          # local voxel ids -> global
+    otri = okeys[om["faces"]].reshape(-1, 6)        # a face as the edge keys of its three vertices
+    dkeys, dfaces = mesh["keys"], mesh["faces"]
+    # where the oracle's first face sits in the device's face array (faces are in scan order: one block)
+    k0 = otri[0]
+    cand = np.nonzero((dkeys[dfaces[:, 0], 0] == k0[0]) & (dkeys[dfaces[:, 0], 1] == k0[1]))[0]
+    start = None
+    for c in cand:
+        if np.array_equal(dkeys[dfaces[c]].reshape(6), k0):
+            start = int(c)
+            break
+    assert start is not None, "the oracle's first face of layer %d is not in the device mesh" % (za + 2)
+    nf = len(otri)
+    block = dfaces[start:start + nf]
+    assert len(block) == nf
+    assert np.array_equal(dkeys[block].reshape(-1, 6), otri), "faces of layers %d..%d differ" % (za + 2, za + nslices - 1)
+    assert np.array_equal(mesh["vertices"][block].view(np.uint32), om["vertices"][om["faces"]].view(np.uint32))
+    # the face before / after the block belongs to another layer (the block is ALL faces of these layers)
+    zmax = lambda f: int(dkeys[f].max() // sl)  # noqa: E731
+    if start > 0:
+        assert zmax(dfaces[start - 1]) <= za + 1
+    if start + nf < len(dfaces):
+        assert dkeys[dfaces[start + nf]].max() // sl >= za + nslices - 1
+    # numbering: the vertices these layers create are numbered in order of first reference
+    nfor = int(om["n_foreign"])
+    own = om["faces"] >= nfor                       # oracle: indices below n_foreign belong to the slab below
+    flat_o, flat_d = om["faces"].reshape(-1), block.reshape(-1)
+    first = np.unique(flat_o[own.reshape(-1)], return_index=True)[1]
+    own_dev = flat_d[own.reshape(-1)][np.sort(first)]
+    assert (np.diff(own_dev) == 1).all(), "device vertex numbers of these layers are not consecutive in scan order"
+
+
 def test_config1_512_tsdf():
     """configs[1]: 512^3, 16 sphere silhouettes at 640x480, TSDF fusion on."""
     n, nv, w, h = 512, 16, 640, 480
@@ -118,9 +175,9 @@ def test_config2_1024_default():
     # the comparison itself must see a difference: one more view on one side only
     assert ref.CarveBatchDevice(views[:1], [ref.upload_sdf(sdf0 * np.float32(1.5))])
     assert ref.state_diff(dev) > 0
-    # idempotence of kMax: a second pass over the same views changes nothing
-    assert ref.CarveBatchDevice(views, [ref.upload_sdf(sdf0)] * nv)
     ref.close()
+    # idempotence of kMax on the fused path (view dropping against a non-fresh state, brick minima in use):
+    # a second pass over the same views changes nothing
     ref = vc.VoxelCarver(opt)
     assert ref.Init()
     assert ref.CarveBatchDevice(views, [ref.upload_sdf(sdf0)] * nv)
@@ -136,6 +193,16 @@ def test_config2_1024_default():
     p1 = np.stack([ax[k1 % n], ax[(k1 // n) % n], ax[k1 // (n * n)]], 1)
     lo, hi = np.minimum(p0, p1), np.maximum(p0, p1)
     assert ((m["vertices"] >= lo) & (m["vertices"] <= hi)).all()
+    # against the oracle, 16 slices at a time: inside the object, across z = nz / 2, and the top of the hull
+    for za in (300, 504, 856):
+        _oracle_slices_check(dev, m, n, za)
+    # the same extraction without the brick minima (every brick read) is the same mesh
+    dev.set_param("mcskip", 0)
+    m0 = dev.ExtractIsoSurface(0.0, True)
+    dev.set_param("mcskip", 1)
+    assert np.array_equal(m0["faces"], m["faces"]) and np.array_equal(m0["keys"], m["keys"])
+    assert np.array_equal(m0["vertices"].view(np.uint32), m["vertices"].view(np.uint32))
+    del m0
     dev.close()
     # configs[3]: the same grid sharded by z-slab (2 contexts on this GPU) gives the same mesh
     parts, ranks = [], []
@@ -180,3 +247,5 @@ def test_config4_2048_64_views_streamed():
     m = dev.ExtractIsoSurface(0.0, True)
     assert len(m["faces"]) > 15_000_000
     _mesh_invariants(m)
+    # against the oracle: the slices around linear cell index 2^32 (z = 1024 at 2048^2 cells per layer)
+    _oracle_slices_check(dev, m, n, 1016)

@@ -900,3 +900,62 @@ def test_failed_flush_is_reported_once_to_the_carve_loop():
     orc = O.OracleGrid(opt)
     orc.carve(views[3], sdf)
     assert_state_equal(dev, orc, "after injected failures")
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(use_truncation=True, truncation_band=0.1),
+                                dict(voxel_update=1, use_truncation=True, truncation_band=0.1)])
+def test_single_view_launches_with_brick_minima(kw):
+    """The reference's call pattern (examples.cc:117-149): carve ONE view, extract, carve the next ... With
+    `defer` 0 every call is a launch of its own; from the second on a wave whose view provably changes nothing
+    (bound against the brick minimum the previous launch left, or below the truncation limit) returns without
+    reading the state, and marching cubes skips bricks whose minimum lies above the iso level.  State and mesh
+    equal the oracle's after every view, on smooth and adversarial images; writes that bypass the fused kernel
+    (vcy_upload, the per-view kernel) switch the minima off until the next fused launch has rebuilt them."""
+    n, nv, w, h = 72, 14, 200, 150
+    uo = UpdateOption(**kw)
+    opt = synth.sphere_option(n, uo)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    rng = np.random.RandomState(5)
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init(), vc.last_error()
+    dev.set_param("defer", 0)
+    orc = O.OracleGrid(opt)
+    base = O.make_sdf(masks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
+    for i in range(nv):
+        sdf = base
+        if i % 5 == 3:  # plateaus: ties with the running maximum
+            sdf = (np.round(base * 8) / 8).astype(np.float32)
+        if i % 5 == 4:  # noise + a few non-finite pixels
+            sdf = (base + rng.uniform(-0.05, 0.05, base.shape)).astype(np.float32)
+            sdf[rng.rand(*sdf.shape) < 0.002] = np.nan
+            sdf[rng.rand(*sdf.shape) < 0.002] = np.finfo(np.float32).min
+        assert dev.Carve(views[i], sdf), vc.last_error()
+        orc.carve(views[i], sdf)
+        assert dev.get_param("brick_min_valid") == (1 if i <= 9 else 0)
+        ds, du = dev.download()
+        os_, ou = orc.download()
+        assert np.array_equal(du, ou), (kw, i, int((du != ou).sum()))
+        nan_d, nan_o = np.isnan(ds), np.isnan(os_)
+        assert np.array_equal(nan_d, nan_o), (kw, i)
+        assert np.array_equal(np.where(nan_d, 0, ds.view(np.uint32)), np.where(nan_o, 0, os_.view(np.uint32))), (kw, i)
+        if i % 3 == 0 and not nan_o.any():
+            for iso in (0.0, 0.25, -0.125, 0.1):
+                m1 = dev.ExtractIsoSurface(iso, True)
+                dev.set_param("mcskip", 0)
+                m0 = dev.ExtractIsoSurface(iso, True)
+                dev.set_param("mcskip", 1)
+                om = orc.marching_cubes(iso, True)
+                assert_mesh_equal(m1, om, "%s view %d iso %g (bricks skipped)" % (kw, i, iso))
+                assert_mesh_equal(m0, om, "%s view %d iso %g (every brick read)" % (kw, i, iso))
+        if i == 4:  # the per-view kernel does not keep the minima; the next fused launch rebuilds them
+            dev.set_param("fused", 0)
+            assert dev.Carve(views[0], base), vc.last_error()
+            orc.carve(views[0], base)
+            assert dev.get_param("brick_min_valid") == 0
+            dev.set_param("fused", 1)
+        if i == 9:  # a state from outside ("update_num == 0 implies sdf == lowest()" is gone): no minima from here on
+            s2 = np.where(rng.rand(ds.size) < 0.3, ds + np.float32(0.5), ds).astype(np.float32)
+            s2 = np.where(np.isnan(s2), np.float32(0.0), s2)
+            dev.upload(s2, du)
+            orc.upload(s2, du)
+            assert dev.get_param("brick_min_valid") == 0

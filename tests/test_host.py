@@ -169,3 +169,21 @@ def test_c_abi_argument_validation_without_a_gpu():
     # null context
     assert lib.vcy_sync(None) == -2 and lib.vcy_reset(None) == -2
     assert lib.vcy_halo_bytes(None) == 0
+
+
+def test_public_headers_compile_in_their_eigen_form():
+    """The facade headers pick Eigen when <Eigen/Geometry> is on the include path (include/vacancy/common.h) --
+    the branch every real user of the reference takes, and one this image cannot build: Eigen is an un-vendored
+    submodule.  tests/eigen_decl/ holds DECLARATIONS of the Eigen names those headers use (no bodies: it pins no
+    arithmetic and nothing can run against it); compiling the headers against it with -fsyntax-only catches
+    syntax rot in that branch (it found a missing <cmath> in camera.h)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gxx = shutil.which("g++")
+    assert gxx, "g++ is part of the image"
+    r = subprocess.run([gxx, "-std=c++14", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "tests", "eigen_decl"),
+                        "-I", os.path.join(root, "include"),
+                        os.path.join(root, "tests", "eigen_decl", "use_public_headers.cc")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-3000:]

@@ -138,6 +138,7 @@ def load():
         "vcy_halo_install": (C.c_int, [vp, vp]),
         "vcy_halo_copy_from": (C.c_int, [vp, vp]),
         "vcy_halo_allgather": (C.c_int, [P(vp), C.c_int]),
+        "vcy_halo_shutdown": (None, []),
         "vcy_last_collective": (C.c_char_p, []),
         "vcy_state_equal": (C.c_int, [vp, vp, P(C.c_int64)]),
         "vcy_device_count": (C.c_int, [P(C.c_int)]),

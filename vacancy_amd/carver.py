@@ -299,9 +299,36 @@ def halo_allgather(carvers):
     (vcy_halo_allgather) installs every slab's two halo slices."""
     lib = capi.load()
     arr = (C.c_void_p * len(carvers))(*[c.ctx for c in carvers])
-    if lib.vcy_halo_allgather(arr, len(carvers)) != 0:
-        raise RuntimeError(last_error())
+    rc = lib.vcy_halo_allgather(arr, len(carvers))
+    if rc != 0:
+        e = RuntimeError(last_error())
+        e.rc = rc
+        raise e
     return lib.vcy_last_collective().decode()
+
+
+def halo_exchange(carvers):
+    """halo_allgather, or -- only when the library reports that librccl cannot be loaded at all
+    (VCY_ERR_UNSUPPORTED) -- the explicit alternative: peer-to-peer copies slab by slab
+    (vcy_halo_copy_from).  Returns what was done as a dict for the benchmark record."""
+    lib = capi.load()
+    try:
+        text = halo_allgather(carvers)
+    except RuntimeError as e:
+        if getattr(e, "rc", 0) != -6:  # VCY_ERR_UNSUPPORTED
+            raise
+        nbytes = 0
+        for below, c in zip([None] + list(carvers[:-1]), carvers):
+            if lib.vcy_halo_copy_from(c.ctx, below.ctx if below is not None else None) != 0:
+                raise RuntimeError(last_error())
+            nbytes += int(lib.vcy_halo_bytes(c.ctx)) if below is not None else 0
+        return {"backend": "peer copies (vcy_halo_copy_from): librccl could not be loaded", "op": "hipMemcpyPeerAsync",
+                "ranks": len({c._device for c in carvers}), "bytes_total": nbytes, "slabs": len(carvers),
+                "note": str(e)[:160]}
+    info = dict(kv.split("=", 1) for kv in text.split() if "=" in kv)
+    return {"backend": "rccl (native, vcy_halo_allgather)", "op": info.get("op"), "ranks": int(info.get("ranks", 0)),
+            "bytes_per_rank": int(info.get("bytes_per_rank", 0)), "rccl_version": int(info.get("version", 0)),
+            "slabs": len(carvers)}
 
 
 def measure_bandwidth(device_id=0, nbytes=1 << 31, reps=3):

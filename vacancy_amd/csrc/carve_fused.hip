@@ -67,6 +67,8 @@ constexpr int kTileBig = 512;            // (in float4 units)
 constexpr int kBigPixels = 4 * kTileBig;
 
 constexpr int kWmaxPlanes = 2;           // window sizes 4 and 8
+constexpr int64_t kRecordBytesMax = (int64_t)1 << 30;  // footprint records of one carve launch (see launch_carve_fused)
+
 
 // tuning knobs of the select-free view loop (development builds override them, profiles/tools/build_variant.sh)
 #ifndef VCY_FAST_GROUP
@@ -492,7 +494,8 @@ __global__ __launch_bounds__(256) void wmax_k8_kernel(const FusedView* __restric
   wmax_store4(const_cast<float*>(in) + (size_t)fv.wmax_plane + (size_t)y * w, x0, w, vec, o);
 }
 
-// Prologue of the fused kernel, out of line so that its registers do not add to the main loop's:
+// Footprint of one brick in one view: the tile of SDF pixels its samples read, whether every sample provably
+// lies inside it (`sure`), and bounds of those samples (TileInfo).
 // The brick is convex, so the exact projections of its voxels lie in the hull of the exact
 // projections of its 8 corners.  Corners and voxels are both COMPUTED with a few float operations;
 // the rectangle is only trusted when an explicit first-order bound of those errors (err_u, err_w
@@ -500,203 +503,143 @@ __global__ __launch_bounds__(256) void wmax_k8_kernel(const FusedView* __restric
 // arithmetic of the samples: corners come from the linear form p000 + {0,ax} + {0,ay} + {0,az} and
 // an approximate reciprocal.
 template <bool SAMEF, int TQ, bool GEN>
-__device__ __attribute__((noinline)) float brick_footprints(const FusedView* __restrict__ views, int nviews, int lane,
-                                                            float xl, float xh, float yl, float yh, float zl_, float zh,
-                                                            bool is_ortho, bool outside_max, bool want_bound,
-                                                            bool want_lower, lds_u32* tinfo_lds) {
-  float ub_lane = INFINITY;
-  if (lane < nviews) {
-    const int vi = lane;
-    // The whole record at once (ten 16-byte loads in flight, one wait): fields fetched where they are first
-    // needed cost a memory round trip each, behind every branch of this function.
-    // (Pinned by the empty asm: the compiler would otherwise sink every load to its first use again.)
-    static_assert(sizeof(FusedView) % 4 == 0, "FusedView is fetched dword by dword");
-    constexpr int kViewDwords = (int)(sizeof(FusedView) / 4);
-    typedef const uint32_t __attribute__((address_space(1))) * gu32_ptr;
-    gu32_ptr src = (gu32_ptr)views + (size_t)vi * kViewDwords;
-    uint32_t raw[kViewDwords];
+__device__ __forceinline__ TileInfo footprint_of(const FusedView& fv, float xl, float xh, float yl, float yh, float zl_,
+                                                 float zh, bool is_ortho, bool outside_max, bool want_bound,
+                                                 bool want_lower) {
+  const ViewParams& v = fv.v;
+  const float xa = fmaxf(fabsf(xl), fabsf(xh)), ya = fmaxf(fabsf(yl), fabsf(yh)), za = fmaxf(fabsf(zl_), fabsf(zh));
+  const bool ortho = GEN && is_ortho;
+  float p0[3], ax[3], ay[3], az[3], mag[3];
 #pragma unroll
-    for (int q = 0; q < kViewDwords; ++q) raw[q] = src[q];
+  for (int i = 0; i < 3; ++i) {
+    p0[i] = v.t[i] + (v.r[i][0] * xl + (v.r[i][1] * yl + v.r[i][2] * zl_));
+    ax[i] = v.r[i][0] * (xh - xl);
+    ay[i] = v.r[i][1] * (yh - yl);
+    az[i] = v.r[i][2] * (zh - zl_);
+    // magnitude of the terms of pc[i]: its computed value is within ~2^-21 * mag[i] of the exact one
+    mag[i] = fabsf(v.t[i]) + (fabsf(v.r[i][0]) * xa + (fabsf(v.r[i][1]) * ya + fabsf(v.r[i][2]) * za));
+  }
+  float umin = INFINITY, umax = -INFINITY, wmin = INFINITY, wmax_ = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+  int bad = 0;
+  const float fx = v.fx, fy = SAMEF ? v.fx : v.fy;
+  float pxy[4][3];  // p0, p0 + ax, p0 + ay, p0 + ax + ay
 #pragma unroll
-    for (int q = 0; q < kViewDwords; ++q) asm volatile("" : "+v"(raw[q]));
-    FusedView fv;
-    __builtin_memcpy(&fv, raw, sizeof(FusedView));
-    const ViewParams& v = fv.v;
-    const float xa = fmaxf(fabsf(xl), fabsf(xh)), ya = fmaxf(fabsf(yl), fabsf(yh)), za = fmaxf(fabsf(zl_), fabsf(zh));
-    const bool ortho = GEN && is_ortho;
-    float p0[3], ax[3], ay[3], az[3], mag[3];
+  for (int i = 0; i < 3; ++i) {
+    pxy[0][i] = p0[i];
+    pxy[1][i] = p0[i] + ax[i];
+    pxy[2][i] = p0[i] + ay[i];
+    pxy[3][i] = pxy[1][i] + ay[i];
+  }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      p0[i] = v.t[i] + (v.r[i][0] * xl + (v.r[i][1] * yl + v.r[i][2] * zl_));
-      ax[i] = v.r[i][0] * (xh - xl);
-      ay[i] = v.r[i][1] * (yh - yl);
-      az[i] = v.r[i][2] * (zh - zl_);
-      // magnitude of the terms of pc[i]: its computed value is within ~2^-21 * mag[i] of the exact one
-      mag[i] = fabsf(v.t[i]) + (fabsf(v.r[i][0]) * xa + (fabsf(v.r[i][1]) * ya + fabsf(v.r[i][2]) * za));
+  for (int corner = 0; corner < 8; ++corner) {
+    float pc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pc[i] = (corner & 4) ? pxy[corner & 3][i] + az[i] : pxy[corner & 3][i];
+    float u = pc[0], w = pc[1];
+    if (!ortho) {
+      bad |= !in_fast_div_range(pc[2]);  // in front of the camera, reciprocal finite and normal
+      const float rz = __builtin_amdgcn_rcpf(pc[2]);
+      u = __builtin_fmaf(fx * rz, pc[0], v.cx);
+      w = __builtin_fmaf(fy * rz, pc[1], v.cy);
     }
-    float umin = INFINITY, umax = -INFINITY, wmin = INFINITY, wmax_ = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
-    int bad = 0;
-    const float fx = v.fx, fy = SAMEF ? v.fx : v.fy;
-    float pxy[4][3];  // p0, p0 + ax, p0 + ay, p0 + ax + ay
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      pxy[0][i] = p0[i];
-      pxy[1][i] = p0[i] + ax[i];
-      pxy[2][i] = p0[i] + ay[i];
-      pxy[3][i] = pxy[1][i] + ay[i];
-    }
-#pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {
-      float pc[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) pc[i] = (corner & 4) ? pxy[corner & 3][i] + az[i] : pxy[corner & 3][i];
-      float u = pc[0], w = pc[1];
-      if (!ortho) {
-        bad |= !in_fast_div_range(pc[2]);  // in front of the camera, reciprocal finite and normal
-        const float rz = __builtin_amdgcn_rcpf(pc[2]);
-        u = __builtin_fmaf(fx * rz, pc[0], v.cx);
-        w = __builtin_fmaf(fy * rz, pc[1], v.cy);
-      }
-      umin = fminf(umin, u);
-      umax = fmaxf(umax, u);
-      wmin = fminf(wmin, w);
-      wmax_ = fmaxf(wmax_, w);
-      zmin = fminf(zmin, pc[2]);
-      zmax = fmaxf(zmax, pc[2]);
-    }
-    // finite inputs (NaN / huge values anywhere end up in mag), image coordinates of sane size
-    bad |= !(mag[0] < 0x1p60f) || !(mag[1] < 0x1p60f) || !(mag[2] < 0x1p60f);
-    bad |= !(umin > -1.0e6f) || !(umax < 1.0e6f) || !(wmin > -1.0e6f) || !(wmax_ < 1.0e6f);
-    const float uabs = fmaxf(fabsf(umin), fabsf(umax)), wabs = fmaxf(fabsf(wmin), fabsf(wmax_));
-    // |computed - exact| of an image coordinate, corner or voxel (first order, constants rounded up):
-    //   pinhole  u = fx * X / Z + cx:  fx * dX / Z + |u - cx| * dZ / Z + rounding of the last operations,
-    //            with dX <= 2^-21 mag_x, dZ <= 2^-21 mag_z and Z >= zmin;
-    //   ortho    u = X:                dX.
-    float err_u, err_w;
-    if (ortho) {
-      err_u = 0x1p-21f * mag[0];
-      err_w = 0x1p-21f * mag[1];
-    } else {
-      bad |= !(zmin * 4.0f >= zmax);
-      const float iz = 0x1p-21f * __builtin_amdgcn_rcpf(zmin) * 1.0001f;
-      err_u = iz * (fx * mag[0] + (uabs + fabsf(v.cx)) * mag[2]) + 0x1p-21f * (uabs + fabsf(v.cx));
-      err_w = iz * (fy * mag[1] + (wabs + fabsf(v.cy)) * mag[2]) + 0x1p-21f * (wabs + fabsf(v.cy));
-    }
-    const float margin = 0.125f;
-    bad |= !(err_u <= 0.03125f) || !(err_w <= 0.03125f);  // corner error + voxel error <= margin / 2
-    TileInfo ti;
-    ti.lo_x = ti.lo_y = INFINITY;  // nothing passes the tile test
-    ti.hi_x = ti.hi_y = -INFINITY;
-    ti.pitchf = 0.0f;
-    ti.base = 0;
-    ti.tx0 = ti.ty0 = ti.tw = ti.nq = ti.th = 0;
-    ti.inv_tw = 1.0f;
-    ti.ub = INFINITY;  // never dropped
-    ti.sure = 0;
-    if (!bad) {
-      const int tx0 = max((int)floorf(umin - margin), v.roi_min_xi);
-      const int ty0 = max((int)floorf(wmin - margin), v.roi_min_yi);
-      const int tx1 = min((int)floorf(umax + margin), v.roi_max_xi);
-      const int ty1 = min((int)floorf(wmax_ + margin), v.roi_max_yi);
-      const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
-      constexpr bool kRaw = TQ == kTileRaw;
-      if (tw > 0 && th > 0 && (kRaw ? (tw <= 15 && th <= 15) : ((tw + 1) * (th + 1) <= kBigPixels))) {
-        // Every computed (u, w) of the brick is within corner error + voxel error < margin of the corner
-        // hull, so when the ROI clipped nothing it lies in [tx0, tx1 + 1) x [ty0, ty1 + 1); the depth
-        // guard keeps every computed pc.z within a factor 2 of the corner range, inside div_fast's.
-        const bool unclipped = (int)floorf(umin - margin) >= v.roi_min_xi && (int)floorf(wmin - margin) >= v.roi_min_yi &&
-                               (int)floorf(umax + margin) < v.roi_max_xi && (int)floorf(wmax_ + margin) < v.roi_max_yi;
-        const bool depth_ok = 0x1p-20f * mag[2] <= 0.25f * zmin && zmin >= 0x1p-58f && zmax <= 0x1p58f;
-        // (|16 base| < 2^22: the fast path forms LDS addresses in the float pipeline, carve_view_fast)
-        const int pitch = kRaw ? 16 : tw + 1;  // pixels per tile row
-        const bool small_base = ty0 * pitch + tx0 < (1 << 18);
-        // orthographic: no division, and the only depth test is the reference's `pc.z < 0` skip
-        // (voxel_carver.cc:456): every computed pc.z of the brick is >= zmin - 2^-20 mag_z
-        const bool depth_ok_ortho = zmin > 0x1p-20f * mag[2];
-        ti.sure = (unclipped && (ortho ? depth_ok_ortho : depth_ok) && small_base) ? 1 : 0;
-        ti.tx0 = tx0;
-        ti.ty0 = ty0;
-        ti.tw = tw;
-        ti.th = th;
-        ti.nq = tw * th;
-        ti.inv_tw = 1.0f / (float)pitch;
-        ti.pitchf = (float)pitch;
-        ti.base = -(ty0 * pitch + tx0);
-        ti.lo_x = (float)tx0;
-        ti.lo_y = (float)ty0;
-        // taps exist for floor(u) in [tx0, tx1]; at the ROI edge u == roi_max is still inside
-        ti.hi_x = (tx1 == v.roi_max_xi) ? v.roi_max_x
-                                        : __uint_as_float(__float_as_uint((float)(tx1 + 1)) - 1u);
-        ti.hi_y = (ty1 == v.roi_max_yi) ? v.roi_max_y
-                                        : __uint_as_float(__float_as_uint((float)(ty1 + 1)) - 1u);
-        if (want_bound) {
-          // maximum over every pixel a tap of this tile can read
-          const int pw = min(tx1 + 1, v.roi_max_xi) - tx0 + 1;
-          const int ph = min(ty1 + 1, v.roi_max_yi) - ty0 + 1;
-          float m = -INFINITY;
-          int has_nan = 0;
-          gfloat_ptr wm = (gfloat_ptr)fv.wmax;
-          // window maxima: k = 8 when both sides reach 8, else 4; nxw x nyw windows placed inside the rectangle
-          // (a side shorter than k gets one window that sticks out of it: a maximum over more pixels is still
-          // an upper bound, and the planes are filled well beyond any footprint, FusedView::wrect)
-          const int L = min(pw, ph) >= 8 ? 3 : 2;
-          const int k = 1 << L;
-          const int nxw = (pw + k - 1) >> L, nyw = (ph + k - 1) >> L;
-          // the largest window counts (up to 3) among the lanes that take the 3 x 3 path below: wave-uniform
-          const bool small = nxw <= 3 && nyw <= 3;
-          const int ux = __any(small && nxw >= 3) ? 3 : (__any(small && nxw >= 2) ? 2 : 1);
-          const int uy = __any(small && nyw >= 3) ? 3 : (__any(small && nyw >= 2) ? 2 : 1);
-          if (wm != nullptr) {
-            gfloat_ptr lvl = wm + (L == 3 ? (size_t)fv.wmax_plane : (size_t)0);
-            if (nxw <= 3 && nyw <= 3) {
-              // the usual case (footprints up to 24 pixels wide): as many lookups as the widest footprint among
-              // the wave's views needs (uniform counts ux x uy, typically 2 x 2; narrower ones repeat their last
-              // window), all requested before the first is used.  As a per-lane loop each load waited for the one
-              // before; nine unconditional ones cost the memory system twice what is needed (measured at
-              // 2048^3 x 64: 157 ms instead of 108).
-              float t[9];
-#pragma unroll
-              for (int bq = 0; bq < 3; ++bq) {
-                const unsigned ro = (unsigned)v.width * (unsigned)(ty0 + min(bq << L, max(ph - k, 0))) + (unsigned)tx0;
-#pragma unroll
-                for (int aq = 0; aq < 3; ++aq) {
-                  t[3 * bq + aq] = -INFINITY;
-                  if (aq < ux && bq < uy) t[3 * bq + aq] = lvl[ro + (unsigned)min(aq << L, max(pw - k, 0))];
-                }
-              }
-#pragma unroll
-              for (int q = 0; q < 9; ++q) m = fmaxf(m, t[q]);
-            } else {
-              for (int bq = 0; bq < nyw; ++bq) {
-                gfloat_ptr row = lvl + (unsigned)v.width * (unsigned)(ty0 + min(bq << L, max(ph - k, 0)));
-                for (int aq = 0; aq < nxw; ++aq) m = fmaxf(m, row[tx0 + min(aq << L, max(pw - k, 0))]);
-              }
-            }
-          } else {  // no planes (out of memory for them): scan the rectangle
-            gfloat_ptr img = (gfloat_ptr)v.sdf;
-            for (int j = 0; j < ph; ++j) {
-              gfloat_ptr row = img + ((unsigned)v.width * (unsigned)(ty0 + j) + (unsigned)tx0);
-              for (int i = 0; i < pw; ++i) {
-                const float t = row[i];
-                has_nan |= !(fabsf(t) <= 3.402823466e+38f);  // NaN or +-inf: 0 * inf = NaN samples
-                m = fmaxf(m, t);
-              }
-            }
-          }
-          // voxels projecting outside the ROI sample max_sdf instead (voxel_carver.cc:469-471)
-          // (not in a `sure` tile: every sample of the brick lies inside it, hence inside the ROI)
-          if (outside_max && !ti.sure) {
-            has_nan |= !(fabsf(v.max_sdf) <= 3.402823466e+38f);
-            m = fmaxf(m, v.max_sdf);
-          }
-          ti.ub = has_nan ? INFINITY : (__builtin_fmaf(fabsf(m), 0x1p-20f, m) + 1.0e-30f);
-          // Lower bound of the samples, by the mirrored argument: with every tap >= mn the sample is
-          // >= mn - 2^-22 |mn|.  If that is >= -1 no voxel of this tile is skipped by the truncation test
-          // (`dist < -1`, voxel_carver.cc:478) and the test is compiled out of the run over it (sure bit 1).
-          // Voxels outside the ROI are not an issue: a `sure` tile has none.
-          if (want_lower && ti.sure && wm != nullptr && fv.has_lower && nxw <= 3 && nyw <= 3) {
-            gfloat_ptr lvl = wm + 2 * (size_t)fv.wmax_plane + (L == 3 ? (size_t)fv.wmax_plane : (size_t)0);
-            float t[9], mneg = -INFINITY;  // max of -g = -(min of g)
+    umin = fminf(umin, u);
+    umax = fmaxf(umax, u);
+    wmin = fminf(wmin, w);
+    wmax_ = fmaxf(wmax_, w);
+    zmin = fminf(zmin, pc[2]);
+    zmax = fmaxf(zmax, pc[2]);
+  }
+  // finite inputs (NaN / huge values anywhere end up in mag), image coordinates of sane size
+  bad |= !(mag[0] < 0x1p60f) || !(mag[1] < 0x1p60f) || !(mag[2] < 0x1p60f);
+  bad |= !(umin > -1.0e6f) || !(umax < 1.0e6f) || !(wmin > -1.0e6f) || !(wmax_ < 1.0e6f);
+  const float uabs = fmaxf(fabsf(umin), fabsf(umax)), wabs = fmaxf(fabsf(wmin), fabsf(wmax_));
+  // |computed - exact| of an image coordinate, corner or voxel (first order, constants rounded up):
+  //   pinhole  u = fx * X / Z + cx:  fx * dX / Z + |u - cx| * dZ / Z + rounding of the last operations,
+  //            with dX <= 2^-21 mag_x, dZ <= 2^-21 mag_z and Z >= zmin;
+  //   ortho    u = X:                dX.
+  float err_u, err_w;
+  if (ortho) {
+    err_u = 0x1p-21f * mag[0];
+    err_w = 0x1p-21f * mag[1];
+  } else {
+    bad |= !(zmin * 4.0f >= zmax);
+    const float iz = 0x1p-21f * __builtin_amdgcn_rcpf(zmin) * 1.0001f;
+    err_u = iz * (fx * mag[0] + (uabs + fabsf(v.cx)) * mag[2]) + 0x1p-21f * (uabs + fabsf(v.cx));
+    err_w = iz * (fy * mag[1] + (wabs + fabsf(v.cy)) * mag[2]) + 0x1p-21f * (wabs + fabsf(v.cy));
+  }
+  const float margin = 0.125f;
+  bad |= !(err_u <= 0.03125f) || !(err_w <= 0.03125f);  // corner error + voxel error <= margin / 2
+  TileInfo ti;
+  ti.lo_x = ti.lo_y = INFINITY;  // nothing passes the tile test
+  ti.hi_x = ti.hi_y = -INFINITY;
+  ti.pitchf = 0.0f;
+  ti.base = 0;
+  ti.tx0 = ti.ty0 = ti.tw = ti.nq = ti.th = 0;
+  ti.inv_tw = 1.0f;
+  ti.ub = INFINITY;  // never dropped
+  ti.sure = 0;
+  if (!bad) {
+    const int tx0 = max((int)floorf(umin - margin), v.roi_min_xi);
+    const int ty0 = max((int)floorf(wmin - margin), v.roi_min_yi);
+    const int tx1 = min((int)floorf(umax + margin), v.roi_max_xi);
+    const int ty1 = min((int)floorf(wmax_ + margin), v.roi_max_yi);
+    const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
+    constexpr bool kRaw = TQ == kTileRaw;
+    if (tw > 0 && th > 0 && (kRaw ? (tw <= 15 && th <= 15) : ((tw + 1) * (th + 1) <= kBigPixels))) {
+      // Every computed (u, w) of the brick is within corner error + voxel error < margin of the corner
+      // hull, so when the ROI clipped nothing it lies in [tx0, tx1 + 1) x [ty0, ty1 + 1); the depth
+      // guard keeps every computed pc.z within a factor 2 of the corner range, inside div_fast's.
+      const bool unclipped = (int)floorf(umin - margin) >= v.roi_min_xi && (int)floorf(wmin - margin) >= v.roi_min_yi &&
+                             (int)floorf(umax + margin) < v.roi_max_xi && (int)floorf(wmax_ + margin) < v.roi_max_yi;
+      const bool depth_ok = 0x1p-20f * mag[2] <= 0.25f * zmin && zmin >= 0x1p-58f && zmax <= 0x1p58f;
+      // (|16 base| < 2^22: the fast path forms LDS addresses in the float pipeline, carve_view_fast)
+      const int pitch = kRaw ? 16 : tw + 1;  // pixels per tile row
+      const bool small_base = ty0 * pitch + tx0 < (1 << 18);
+      // orthographic: no division, and the only depth test is the reference's `pc.z < 0` skip
+      // (voxel_carver.cc:456): every computed pc.z of the brick is >= zmin - 2^-20 mag_z
+      const bool depth_ok_ortho = zmin > 0x1p-20f * mag[2];
+      ti.sure = (unclipped && (ortho ? depth_ok_ortho : depth_ok) && small_base) ? 1 : 0;
+      ti.tx0 = tx0;
+      ti.ty0 = ty0;
+      ti.tw = tw;
+      ti.th = th;
+      ti.nq = tw * th;
+      ti.inv_tw = 1.0f / (float)pitch;
+      ti.pitchf = (float)pitch;
+      ti.base = -(ty0 * pitch + tx0);
+      ti.lo_x = (float)tx0;
+      ti.lo_y = (float)ty0;
+      // taps exist for floor(u) in [tx0, tx1]; at the ROI edge u == roi_max is still inside
+      ti.hi_x = (tx1 == v.roi_max_xi) ? v.roi_max_x
+                                      : __uint_as_float(__float_as_uint((float)(tx1 + 1)) - 1u);
+      ti.hi_y = (ty1 == v.roi_max_yi) ? v.roi_max_y
+                                      : __uint_as_float(__float_as_uint((float)(ty1 + 1)) - 1u);
+      if (want_bound) {
+        // maximum over every pixel a tap of this tile can read
+        const int pw = min(tx1 + 1, v.roi_max_xi) - tx0 + 1;
+        const int ph = min(ty1 + 1, v.roi_max_yi) - ty0 + 1;
+        float m = -INFINITY;
+        int has_nan = 0;
+        gfloat_ptr wm = (gfloat_ptr)fv.wmax;
+        // window maxima: k = 8 when both sides reach 8, else 4; nxw x nyw windows placed inside the rectangle
+        // (a side shorter than k gets one window that sticks out of it: a maximum over more pixels is still
+        // an upper bound, and the planes are filled well beyond any footprint, FusedView::wrect)
+        const int L = min(pw, ph) >= 8 ? 3 : 2;
+        const int k = 1 << L;
+        const int nxw = (pw + k - 1) >> L, nyw = (ph + k - 1) >> L;
+        // the largest window counts (up to 3) among the lanes that take the 3 x 3 path below: wave-uniform
+        const bool small = nxw <= 3 && nyw <= 3;
+        const int ux = __any(small && nxw >= 3) ? 3 : (__any(small && nxw >= 2) ? 2 : 1);
+        const int uy = __any(small && nyw >= 3) ? 3 : (__any(small && nyw >= 2) ? 2 : 1);
+        if (wm != nullptr) {
+          gfloat_ptr lvl = wm + (L == 3 ? (size_t)fv.wmax_plane : (size_t)0);
+          if (nxw <= 3 && nyw <= 3) {
+            // the usual case (footprints up to 24 pixels wide): as many lookups as the widest footprint among
+            // the wave's views needs (uniform counts ux x uy, typically 2 x 2; narrower ones repeat their last
+            // window), all requested before the first is used.  As a per-lane loop each load waited for the one
+            // before; nine unconditional ones cost the memory system twice what is needed (measured at
+            // 2048^3 x 64: 157 ms instead of 108).
+            float t[9];
 #pragma unroll
             for (int bq = 0; bq < 3; ++bq) {
               const unsigned ro = (unsigned)v.width * (unsigned)(ty0 + min(bq << L, max(ph - k, 0))) + (unsigned)tx0;
@@ -707,23 +650,179 @@ __device__ __attribute__((noinline)) float brick_footprints(const FusedView* __r
               }
             }
 #pragma unroll
-            for (int q = 0; q < 9; ++q) mneg = fmaxf(mneg, t[q]);
-            const float neg_lb = __builtin_fmaf(fabsf(mneg), 0x1p-20f, mneg);  // -(lower bound); +inf: none
-            if (neg_lb <= 1.0f) ti.sure |= 2;
+            for (int q = 0; q < 9; ++q) m = fmaxf(m, t[q]);
+          } else {
+            for (int bq = 0; bq < nyw; ++bq) {
+              gfloat_ptr row = lvl + (unsigned)v.width * (unsigned)(ty0 + min(bq << L, max(ph - k, 0)));
+              for (int aq = 0; aq < nxw; ++aq) m = fmaxf(m, row[tx0 + min(aq << L, max(pw - k, 0))]);
+            }
           }
+        } else {  // no planes (out of memory for them): scan the rectangle
+          gfloat_ptr img = (gfloat_ptr)v.sdf;
+          for (int j = 0; j < ph; ++j) {
+            gfloat_ptr row = img + ((unsigned)v.width * (unsigned)(ty0 + j) + (unsigned)tx0);
+            for (int i = 0; i < pw; ++i) {
+              const float t = row[i];
+              has_nan |= !(fabsf(t) <= 3.402823466e+38f);  // NaN or +-inf: 0 * inf = NaN samples
+              m = fmaxf(m, t);
+            }
+          }
+        }
+        // voxels projecting outside the ROI sample max_sdf instead (voxel_carver.cc:469-471)
+        // (not in a `sure` tile: every sample of the brick lies inside it, hence inside the ROI)
+        if (outside_max && !ti.sure) {
+          has_nan |= !(fabsf(v.max_sdf) <= 3.402823466e+38f);
+          m = fmaxf(m, v.max_sdf);
+        }
+        ti.ub = has_nan ? INFINITY : (__builtin_fmaf(fabsf(m), 0x1p-20f, m) + 1.0e-30f);
+        // Lower bound of the samples, by the mirrored argument: with every tap >= mn the sample is
+        // >= mn - 2^-22 |mn|.  If that is >= -1 no voxel of this tile is skipped by the truncation test
+        // (`dist < -1`, voxel_carver.cc:478) and the test is compiled out of the run over it (sure bit 1).
+        // Voxels outside the ROI are not an issue: a `sure` tile has none.
+        // (not looked up for a tile the upper bound already drops: `ub < -1`, the view is never processed)
+        if (want_lower && ti.sure && !(ti.ub < -1.0f) && wm != nullptr && fv.has_lower && nxw <= 3 && nyw <= 3) {
+          gfloat_ptr lvl = wm + 2 * (size_t)fv.wmax_plane + (L == 3 ? (size_t)fv.wmax_plane : (size_t)0);
+          float t[9], mneg = -INFINITY;  // max of -g = -(min of g)
+#pragma unroll
+          for (int bq = 0; bq < 3; ++bq) {
+            const unsigned ro = (unsigned)v.width * (unsigned)(ty0 + min(bq << L, max(ph - k, 0))) + (unsigned)tx0;
+#pragma unroll
+            for (int aq = 0; aq < 3; ++aq) {
+              t[3 * bq + aq] = -INFINITY;
+              if (aq < ux && bq < uy) t[3 * bq + aq] = lvl[ro + (unsigned)min(aq << L, max(pw - k, 0))];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 9; ++q) mneg = fmaxf(mneg, t[q]);
+          const float neg_lb = __builtin_fmaf(fabsf(mneg), 0x1p-20f, mneg);  // -(lower bound); +inf: none
+          if (neg_lb <= 1.0f) ti.sure |= 2;
         }
       }
     }
-    // (through an LDS-typed pointer: ds_write_b128, not flat stores)
-    static_assert(sizeof(TileInfo) % 4 == 0, "TileInfo is stored dword by dword");
-    uint32_t w32[sizeof(TileInfo) / 4];
-    __builtin_memcpy(w32, &ti, sizeof(TileInfo));
-    lds_u32* dst = tinfo_lds + vi * (int)(sizeof(TileInfo) / 4);
+  }
+  return ti;
+}
+
+// The whole FusedView record of view `vi` at once (ten 16-byte loads in flight, one wait): fields fetched where
+// they are first needed cost a memory round trip each, behind every branch of footprint_of.
+// (Pinned by the empty asm: the compiler would otherwise sink every load to its first use again.)
+__device__ __forceinline__ FusedView load_fused_view(const FusedView* __restrict__ views, int vi) {
+  static_assert(sizeof(FusedView) % 4 == 0, "FusedView is fetched dword by dword");
+  constexpr int kViewDwords = (int)(sizeof(FusedView) / 4);
+  typedef const uint32_t __attribute__((address_space(1))) * gu32_ptr;
+  gu32_ptr src = (gu32_ptr)views + (size_t)vi * kViewDwords;
+  uint32_t raw[kViewDwords];
 #pragma unroll
-    for (int q = 0; q < (int)(sizeof(TileInfo) / 4); ++q) dst[q] = w32[q];
+  for (int q = 0; q < kViewDwords; ++q) raw[q] = src[q];
+#pragma unroll
+  for (int q = 0; q < kViewDwords; ++q) asm volatile("" : "+v"(raw[q]));
+  FusedView fv;
+  __builtin_memcpy(&fv, raw, sizeof(FusedView));
+  return fv;
+}
+
+// (through an LDS-typed pointer: ds_write_b128, not flat stores)
+__device__ __forceinline__ void store_tile_info(lds_u32* tinfo_lds, int vi, const TileInfo& ti) {
+  static_assert(sizeof(TileInfo) % 4 == 0, "TileInfo is stored dword by dword");
+  uint32_t w32[sizeof(TileInfo) / 4];
+  __builtin_memcpy(w32, &ti, sizeof(TileInfo));
+  lds_u32* dst = tinfo_lds + vi * (int)(sizeof(TileInfo) / 4);
+#pragma unroll
+  for (int q = 0; q < (int)(sizeof(TileInfo) / 4); ++q) dst[q] = w32[q];
+}
+
+// Prologue of the fused kernels that bound their footprints themselves (the big tile), out of line so that its
+// registers do not add to the main loop's: lane vi handles view vi of the wave brick.
+template <bool SAMEF, int TQ, bool GEN>
+__device__ __attribute__((noinline)) float brick_footprints(const FusedView* __restrict__ views, int nviews, int lane,
+                                                            float xl, float xh, float yl, float yh, float zl_, float zh,
+                                                            bool is_ortho, bool outside_max, bool want_bound,
+                                                            bool want_lower, lds_u32* tinfo_lds) {
+  float ub_lane = INFINITY;
+  if (lane < nviews) {
+    const FusedView fv = load_fused_view(views, lane);
+    const TileInfo ti = footprint_of<SAMEF, TQ, GEN>(fv, xl, xh, yl, yh, zl_, zh, is_ortho, outside_max, want_bound,
+                                                     want_lower);
+    store_tile_info(tinfo_lds, lane, ti);
     ub_lane = ti.ub;
   }
   return ub_lane;
+}
+
+// ---- footprint records (raw-tile kernels) ------------------------------------------------------
+// What footprint_of finds for a (wave brick, view) pair does not depend on the voxel state, and inside the carve
+// kernel it is the worst kind of work: one lane per view (half the wave idle at 32 views, 63 of 64 lanes for a
+// single view), two dependent memory round trips before the wave can do anything else, and registers the run loops
+// then have to live with.  The raw-tile kernels therefore take it from a pre-pass at full occupancy
+// (footprint_records_kernel: one thread per pair, lane = brick along x, the view wave-uniform, so the view
+// constants are scalar operands and the window lookups of neighbouring lanes fall into the same cache lines) that
+// leaves 8 bytes per pair in memory, [view][brick]; the carve kernel's prologue is one 8-byte load per lane.
+//   word 0: bits 31..6 upper bound of the samples (a float rounded UP to 26 bits: still a bound),
+//           bits 3..0 th, bit 4 / 5: the tile ends at the ROI's last column / row (TileInfo::hi_x / hi_y)
+//   word 1: bits 12..0 tx0, 25..13 ty0, 29..26 tw (0: no tile), 31..30 TileInfo::sure
+// (raw tiles: tw, th <= 15; images up to 8192 x 8192: fused_eligible)
+struct FootprintRecord {
+  uint32_t w0, w1;
+};
+
+__device__ __forceinline__ FootprintRecord pack_footprint(const TileInfo& ti, const ViewParams& v) {
+  uint32_t b = __float_as_uint(ti.ub);
+  if (!(fabsf(ti.ub) <= 3.402823466e+38f)) b = 0x7f800000u;       // +inf / NaN: no bound
+  else if (b & 0x80000000u) b &= ~63u;                            // negative: towards zero is up
+  else b = (b + 63u) & ~63u;                                      // (may carry into +inf: no bound)
+  FootprintRecord r;
+  const int tx1 = ti.tx0 + ti.tw - 1, ty1 = ti.ty0 + ti.th - 1;
+  r.w0 = b | (uint32_t)ti.th | (ti.nq && tx1 == v.roi_max_xi ? 16u : 0u) | (ti.nq && ty1 == v.roi_max_yi ? 32u : 0u);
+  r.w1 = ti.nq ? ((uint32_t)ti.tx0 | ((uint32_t)ti.ty0 << 13) | ((uint32_t)ti.tw << 26) | ((uint32_t)ti.sure << 30)) : 0u;
+  return r;
+}
+
+__device__ __forceinline__ TileInfo unpack_footprint(const FootprintRecord r) {
+  TileInfo ti;
+  const int tw = (int)((r.w1 >> 26) & 15u), th = (int)(r.w0 & 15u);
+  const int tx0 = (int)(r.w1 & 8191u), ty0 = (int)((r.w1 >> 13) & 8191u);
+  ti.ub = __uint_as_float(r.w0 & ~63u);
+  ti.sure = (int)(r.w1 >> 30);
+  ti.tx0 = tx0, ti.ty0 = ty0, ti.tw = tw, ti.th = (tw ? th : 0), ti.nq = tw * th;
+  ti.pitchf = tw ? 16.0f : 0.0f;
+  ti.inv_tw = tw ? 0.0625f : 1.0f;
+  ti.base = tw ? -(ty0 * 16 + tx0) : 0;
+  if (tw) {
+    const int tx1 = tx0 + tw - 1, ty1 = ty0 + th - 1;
+    ti.lo_x = (float)tx0, ti.lo_y = (float)ty0;
+    // taps exist for floor(u) in [tx0, tx1]; at the ROI edge u == roi_max (== tx1) is still inside
+    ti.hi_x = (r.w0 & 16u) ? (float)tx1 : __uint_as_float(__float_as_uint((float)(tx1 + 1)) - 1u);
+    ti.hi_y = (r.w0 & 32u) ? (float)ty1 : __uint_as_float(__float_as_uint((float)(ty1 + 1)) - 1u);
+  } else {
+    ti.lo_x = ti.lo_y = INFINITY;  // nothing passes the tile test
+    ti.hi_x = ti.hi_y = -INFINITY;
+    ti.ub = INFINITY;
+    ti.sure = 0;
+  }
+  return ti;
+}
+
+// Pre-pass of the raw-tile carve kernels: blockIdx.y = view, thread = wave brick (linear, x fastest: the carve
+// kernel's wave (bx, wave) of brick row (by, bz) is brick (bz * nby + by) * nbw + 4 bx + wave).
+template <bool SAMEF, bool GEN>
+__global__ __launch_bounds__(256) void footprint_records_kernel(GridParams g, const FusedView* __restrict__ views,
+                                                                int nbw, int nby, int64_t nbricks, ModeParams mode,
+                                                                int want_bound, int want_lower,
+                                                                FootprintRecord* __restrict__ records) {
+  const int64_t brick = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (brick >= nbricks) return;
+  const int vi = blockIdx.y;
+  const int bxw = (int)(brick % nbw);
+  const int64_t rowb = brick / nbw;
+  const int by = (int)(rowb % nby), bz = (int)(rowb / nby);
+  const int x_lo = min(bxw * WX, g.nx - 1), x_hi = min(bxw * WX + WX - 1, g.nx - 1);
+  const int y_hi = min(by * BY + BY - 1, g.ny - 1), z_hi = min(bz * BZ + BZ - 1, g.nz_local - 1);
+  // (the view is uniform: its record arrives through scalar loads)
+  const FusedView& fv = views[vi];
+  const TileInfo ti = footprint_of<SAMEF, kTileRaw, GEN>(fv, g.px[x_lo], g.px[x_hi], g.py[by * BY], g.py[y_hi],
+                                                          g.pz[g.z0 + bz * BZ], g.pz[g.z0 + z_hi], mode.ortho != 0,
+                                                          mode.outside == VCY_OUTSIDE_MAX, want_bound != 0, want_lower != 0);
+  records[(int64_t)vi * nbricks + brick] = pack_footprint(ti, fv.v);
 }
 
 // GEN: nearest-neighbour sampling and/or an orthographic camera, selected at run time from `mode`
@@ -735,7 +834,15 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
                                                           const FusedView* __restrict__ views,
                                                           const float* __restrict__ c0_all,
                                                           int nviews, ModeParams mode, int nbx,
-                                                          int nby, int cull_enabled, int state_flags) {
+                                                          int nby, int cull_enabled, int state_flags,
+                                                          const FootprintRecord* __restrict__ records,
+                                                          int64_t nbricks, float* __restrict__ brick_min) {
+  // brick_min[wave brick] (or null): min(sdf) over the brick as the carve kernels left it -- lowest() while a
+  // voxel of it is untouched.  Written by every fused launch; READ (state_flags bit 2: every write to the state
+  // since the slab was fresh went through a fused launch) to drop views before the state is loaded: a wave
+  // whose every view is dropped returns without reading or writing anything, which is what makes the
+  // reference's `Carve(); Extract(); Carve(); ...` pattern of single-view launches cheap.  Marching cubes skips
+  // bricks that lie entirely outside the iso-surface with it (mc_bits).
   // state_flags: bit 0 = the slab is fresh (known sdf = lowest(), update_num = 0, never written);
   //              bit 1 = update_num == 0 implies sdf == lowest() (no vcy_upload since the fill)
   const int fresh = state_flags & 1;
@@ -791,6 +898,11 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   const int nxp = (g.nx + WX - 1) & ~(WX - 1);
   const bool want_bound = kNeedBound && cull_enabled;
 
+  // This wave brick's index in the launch (fewer than 2^31: launch_carve_fused).  Computed HERE, in uniform control
+  // flow: a uniform value first computed inside a divergent branch (`if (lane < nviews)` below) reaches later uses
+  // through a phi that the compiler must treat as divergent -- it then lives in a VGPR, and so did the address of the
+  // c0 records that shares `nxp / WX` with it: the scalar loads of the run loops had become vector loads (-15 %).
+  const int brick_lin = (bz * nby + by) * (nxp / WX) + (x_first / WX);
   // ---- prologue: lane vi bounds the footprint of the wave brick in view vi (brick_footprints) -------
   float ub_lane;
 #ifdef VCY_PHASE_TIMING
@@ -800,7 +912,20 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     pt_acc[12] += t_ - pt_last;
   }
 #endif
-  {
+  if constexpr (kRaw) {
+    // raw tiles: the footprints come from the pre-pass (footprint_records_kernel), 8 bytes per view
+    ub_lane = INFINITY;
+    if (lane < nviews) {
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      typedef const u32x2 __attribute__((address_space(1))) * grec_ptr;
+      const u32x2 raw = ((grec_ptr)records)[(int64_t)lane * nbricks + brick_lin];
+      FootprintRecord rec;
+      rec.w0 = raw.x, rec.w1 = raw.y;
+      const TileInfo ti = unpack_footprint(rec);
+      store_tile_info((lds_u32*)tinfo, lane, ti);
+      ub_lane = ti.ub;
+    }
+  } else {
     const int x_lo = min(x_first, g.nx - 1), x_hi = min(x_first + WX - 1, g.nx - 1);
     const int y_hi = min(by * BY + BY - 1, g.ny - 1);
     const int z_hi = min(zl0 + BZ - 1, g.nz_local - 1);
@@ -810,6 +935,23 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
                                                want_bound && TRUNC && UPDATE != VCY_UPDATE_MAX, (lds_u32*)tinfo);
   }
   wave_lds_fence();
+  const unsigned long long view_mask = (nviews >= 64) ? ~0ull : ((1ull << nviews) - 1ull);
+  // (a launch covers fewer than 2^31 wave bricks: launch_carve_fused)
+  // Views that cannot change this brick whatever its voxels hold now: every sample below the truncation limit, or
+  // (kMax) not above the brick's minimum as the previous launch left it.  All of them: nothing to read or write.
+#ifndef VCY_NO_EARLY_EXIT
+  if (want_bound && !fresh) {
+    const bool have_min = UPDATE == VCY_UPDATE_MAX && (state_flags & 4) != 0 && brick_min != nullptr;
+    if (TRUNC || have_min) {
+      bool drop0 = TRUNC && ub_lane < -1.0f;
+      if (have_min) {
+        const float smin0 = ((cfloat_ptr)brick_min)[brick_lin];  // (uniform: a scalar load)
+        drop0 = drop0 || ub_lane <= smin0;  // (a brick with an untouched voxel holds lowest(): never true)
+      }
+      if ((__ballot(!drop0) & view_mask) == 0ull) return;
+    }
+  }
+#endif
 #ifdef VCY_PHASE_TIMING
   {
     asm volatile("" ::"v"(ub_lane));
@@ -817,7 +959,6 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     pt_acc[13] += t_ - pt_last;  // (includes slot 12)
   }
 #endif
-  const unsigned long long view_mask = (nviews >= 64) ? ~0ull : ((1ull << nviews) - 1ull);
 
   // ---- load the wave brick's state ----------------------------------------------------------
   CountT* __restrict__ cnt = (CountT*)g.cnt;
@@ -1215,11 +1356,25 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
 
   // ---- write back what changed (update_num grows with every change) ----------------------------
   leave_uniform();
+#ifndef VCY_NO_BRICK_MIN_WRITE
+  if (brick_min != nullptr && implied) {  // (lanes outside the grid hold copies of voxels inside it)
+    float m = s[0];
+#pragma unroll
+    for (int k = 1; k < WX; ++k) m = fminf(m, s[k]);
+    const float smin = wave_min(m);
+    if (lane == 0) brick_min[brick_lin] = smin;
+  }
+#endif
   if (lane_valid) {
     if (vec_io) {
       bool changed = fresh != 0;  // (a fresh slab has never been written: every voxel is stored)
 #ifdef VCY_FLOOR_NO_STORES  // development build (issue floor): results stay live, nothing is stored
-      changed = s[0] == 1.2345e-30f && s[7] == 5.4321e-30f && (int)n[3] == 77;
+      {  // (every value stays live: a dead s[k] would take its whole update chain with it)
+        float ssum = 0.0f, nsum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < WX; ++k) ssum += s[k], nsum += (float)n[k];
+        changed = ssum == 1.2345e-30f && nsum == 777.25f;
+      }
       if (false) {
 #else
       if (!fresh) {
@@ -1255,12 +1410,13 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
 
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF>
 void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const GridParams& g, const FusedView* dv,
-                    const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh) {
+                    const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh,
+                    const FootprintRecord* recs, int64_t nbricks, float* bmin) {
   const bool gen = m.ortho != 0 || m.interp == VCY_INTERP_NN;
 #define VCY_FUSED(CM, TQ_, GEN_, DIV_)                                                                           \
   hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, CM, TQ_, GEN_, DIV_>), grid, dim3(64 * kWgWaves), \
                      (size_t)kWgWaves * tile_f4_per_wave<TQ_>() * sizeof(float4) + (size_t)kWgWaves * nv * sizeof(TileInfo), s, \
-                     g, dv, c2, nv, m, nbx, nby, cull, fresh)
+                     g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin)
 #define VCY_FUSED_G(CM, TQ_)                                                                                     \
   do {                                                                                                           \
     if (gen) VCY_FUSED(CM, TQ_, true, 0);                                                                        \
@@ -1290,25 +1446,27 @@ void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const Gri
 
 template <typename CountT, int UPDATE>
 void launch_fused_2(bool big, bool trunc, bool samef, bool checkmax, dim3 grid, hipStream_t s, const GridParams& g,
-                    const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh) {
+                    const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh,
+                    const FootprintRecord* recs, int64_t nbricks, float* bmin) {
   if (trunc) {
-    if (samef) launch_fused_4<CountT, UPDATE, true, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
-    else launch_fused_4<CountT, UPDATE, true, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
+    if (samef) launch_fused_4<CountT, UPDATE, true, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin);
+    else launch_fused_4<CountT, UPDATE, true, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin);
   } else {
-    if (samef) launch_fused_4<CountT, UPDATE, false, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
-    else launch_fused_4<CountT, UPDATE, false, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
+    if (samef) launch_fused_4<CountT, UPDATE, false, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin);
+    else launch_fused_4<CountT, UPDATE, false, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin);
   }
 }
 
 template <typename CountT>
 void launch_fused_1(bool big, int update, bool trunc, bool samef, bool checkmax, dim3 grid, hipStream_t s,
-                    const GridParams& g, const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh) {
+                    const GridParams& g, const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh,
+                    const FootprintRecord* recs, int64_t nbricks, float* bmin) {
   if (update == VCY_UPDATE_MAX)
-    launch_fused_2<CountT, VCY_UPDATE_MAX>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
+    launch_fused_2<CountT, VCY_UPDATE_MAX>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin);
   else if (g.weight == 1.0f)
-    launch_fused_2<CountT, kUpdateWaUnitWeight>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
+    launch_fused_2<CountT, kUpdateWaUnitWeight>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin);
   else
-    launch_fused_2<CountT, VCY_UPDATE_WEIGHTED_AVERAGE>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh);
+    launch_fused_2<CountT, VCY_UPDATE_WEIGHTED_AVERAGE>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin);
 }
 
 // Exhaustive check of the short division sequences for ONE numerator: every significand of the
@@ -1506,8 +1664,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     }
   }
   const int nbx = (c->nx + BX - 1) / BX, nby = (c->ny + BY - 1) / BY, nbz = (nzl + BZ - 1) / BZ;
-  const int64_t nblocks = (int64_t)nbx * nby * nbz;
-  if (nblocks > 0x7fffffffLL) {
+  if ((int64_t)nbx * nby * nbz > 0x7fffffffLL) {
     set_error("slab too large for one launch");
     return VCY_ERR_TOO_MANY_VOXELS;
   }
@@ -1524,7 +1681,6 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   c->last_div_level = m.div_level;
   // update_num can only exceed voxel_max_update_num after more than that many views
   const bool checkmax = c->views_carved + n_views > (int64_t)u.voxel_max_update_num;
-  const dim3 grid((unsigned)nblocks);
   // Tile kind: footprint of an 8x8x8 wave brick in pixels ~ (8*sqrt(3)*pixels_per_voxel + 3)^2.  The raw
   // 16 x 16 pixel tile covers voxels up to ~0.85 px; the 2048-pixel tile filled in place up to ~3 px; wider
   // footprints take the generic path inside the kernel either way.
@@ -1547,15 +1703,69 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     if (c->tile_mode == 1) big = false;
     if (c->tile_mode == 2) big = true;
   }
-  const int state_flags = (c->fresh ? 1 : 0) | (c->cnt_implied ? 2 : 0);
-  if (c->cnt_bytes == 1)
-    launch_fused_1<uint8_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, g, d_views,
-                            d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, state_flags);
-  else
-    launch_fused_1<uint16_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, g, d_views,
-                             d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, state_flags);
-  VCY_HIP_CHECK(hipGetLastError());
-  c->fresh = false;  // the launch stores every voxel of a fresh slab
+  // min(sdf) per wave brick (vcy_ctx::d_brick_min): 4 bytes per 512 voxels, allocated on first use; without it
+  // nothing is dropped before the state is read and marching cubes reads every brick
+  if (!c->d_brick_min) {
+    const size_t bytes = sizeof(float) * (size_t)nbw * nby * nbz;
+    if (hipMalloc(&c->d_brick_min, bytes) != hipSuccess) {
+      c->d_brick_min = nullptr;
+      (void)hipGetLastError();
+    }
+    c->brick_min_valid = false;
+  }
+  if (!c->cnt_implied) c->brick_min_valid = false;
+  const int state_flags = (c->fresh ? 1 : 0) | (c->cnt_implied ? 2 : 0) | (c->brick_min_valid && !c->fresh ? 4 : 0);
+  // Raw tiles: the footprint records of every (wave brick, view) pair come from a pre-pass (footprint_records_kernel),
+  // 8 bytes per pair.  The slab is carved in chunks of whole brick layers so that the records of a chunk stay
+  // below kRecordBytesMax (1024^3 x 32 views: 0.5 GiB, one chunk; 2048^3 x 64: nine).
+  const int64_t layer_bricks = (int64_t)nbw * nby;
+  int chunk_layers = nbz;
+  if (!big) {
+    const int64_t per_layer = layer_bricks * n_views * (int64_t)sizeof(FootprintRecord);
+    chunk_layers = (int)std::max<int64_t>(1, std::min<int64_t>(nbz, kRecordBytesMax / std::max<int64_t>(per_layer, 1)));
+    const size_t need = (size_t)(per_layer * chunk_layers);
+    if (c->records_bytes < need) {
+      VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+      if (c->d_records) (void)hipFree(c->d_records);
+      c->d_records = nullptr;
+      c->records_bytes = 0;
+      VCY_HIP_CHECK(hipMalloc(&c->d_records, need));
+      c->records_bytes = need;
+    }
+  }
+  const bool gen = m.ortho != 0 || m.interp == VCY_INTERP_NN;
+  const bool want_lower = need_bound && u.use_truncation && u.voxel_update != VCY_UPDATE_MAX;
+  for (int l0 = 0; l0 < nbz; l0 += chunk_layers) {
+    const int layers = std::min(chunk_layers, nbz - l0);
+    GridParams gc = g;  // this chunk: brick layers [l0, l0 + layers)
+    gc.sdf = g.sdf + (int64_t)l0 * BZ * c->slice;
+    gc.cnt = (char*)g.cnt + (int64_t)l0 * BZ * c->slice * c->cnt_bytes;
+    gc.z0 = g.z0 + l0 * BZ;
+    gc.nz_local = std::min(layers * BZ, nzl - l0 * BZ);
+    const int64_t nbricks = layer_bricks * layers;
+    FootprintRecord* recs = (FootprintRecord*)c->d_records;
+    float* bmin = c->d_brick_min ? c->d_brick_min + (int64_t)l0 * layer_bricks : nullptr;
+    if (!big) {
+      const dim3 pgrid((unsigned)((nbricks + 255) / 256), (unsigned)n_views);
+#define VCY_PREPASS(SF, GN)                                                                                       \
+  hipLaunchKernelGGL((footprint_records_kernel<SF, GN>), pgrid, dim3(256), 0, c->stream, gc, d_views, nbw, nby,   \
+                     nbricks, m, need_bound ? 1 : 0, want_lower ? 1 : 0, recs)
+      if (samef) { if (gen) VCY_PREPASS(true, true); else VCY_PREPASS(true, false); }
+      else { if (gen) VCY_PREPASS(false, true); else VCY_PREPASS(false, false); }
+#undef VCY_PREPASS
+      VCY_HIP_CHECK(hipGetLastError());
+    }
+    const dim3 grid((unsigned)((int64_t)nbx * nby * layers));
+    if (c->cnt_bytes == 1)
+      launch_fused_1<uint8_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, gc, d_views,
+                              d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin);
+    else
+      launch_fused_1<uint16_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, gc, d_views,
+                               d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin);
+    VCY_HIP_CHECK(hipGetLastError());
+  }
+  c->fresh = false;  // the launches store every voxel of a fresh slab
+  c->brick_min_valid = c->d_brick_min != nullptr && c->cnt_implied;  // (every wave that did not return early wrote its entry)
   return VCY_OK;
 }
 

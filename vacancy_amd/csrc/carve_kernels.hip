@@ -216,6 +216,7 @@ int launch_carve(vcy_ctx* c, int n_views, const vcy_view* views, const float* co
       c->views_carved += m;
     }
   } else {
+    c->brick_min_valid = false;  // (the per-view kernel does not keep the brick minima)
     for (int i = 0; i < n_views; ++i) {
       ModeParams m{u.voxel_update, u.sdf_interp, u.update_outside, u.use_truncation ? 1 : 0,
                    views[i].is_ortho ? 1 : 0, 0};

@@ -105,6 +105,21 @@ bool load_rccl() {
     }                                                                                         \
   } while (0)
 
+// Communicators, streams and staging of one device set (also the error path of get_group).
+void destroy_group(HaloGroup* g) {
+  for (size_t d = 0; d < g->devices.size(); ++d) {
+    (void)hipSetDevice(g->devices[d]);
+    if (d < g->streams.size() && g->streams[d]) {
+      (void)hipStreamSynchronize(g->streams[d]);
+      (void)hipStreamDestroy(g->streams[d]);
+    }
+    if (d < g->send.size() && g->send[d]) (void)hipFree(g->send[d]);
+    if (d < g->recv.size() && g->recv[d]) (void)hipFree(g->recv[d]);
+    if (d < g->comms.size() && g->comms[d]) (void)g_rccl.CommDestroy(g->comms[d]);
+  }
+  delete g;
+}
+
 int get_group(const std::vector<int>& devices, HaloGroup** out) {
   for (HaloGroup* g : g_groups)
     if (g->devices == devices) {
@@ -125,8 +140,13 @@ int get_group(const std::vector<int>& devices, HaloGroup** out) {
     return VCY_ERR_HIP;
   }
   for (int d = 0; d < nd; ++d) {
-    VCY_HIP_CHECK(hipSetDevice(devices[(size_t)d]));
-    VCY_HIP_CHECK(hipStreamCreateWithFlags(&g->streams[(size_t)d], hipStreamNonBlocking));
+    hipError_t e = hipSetDevice(devices[(size_t)d]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->streams[(size_t)d], hipStreamNonBlocking);
+    if (e != hipSuccess) {  // nothing half-built stays behind (a retry would initialise the communicators again)
+      set_error("vcy_halo_allgather: stream on device %d: %s", devices[(size_t)d], hipGetErrorString(e));
+      destroy_group(g);
+      return VCY_ERR_HIP;
+    }
   }
   g_groups.push_back(g);
   *out = g;
@@ -257,6 +277,12 @@ int vcy_halo_allgather(vcy_ctx* const* slabs, int n_slabs) {
   g_last.calls += 1;
   (void)g_rccl.GetVersion(&g_last.version);
   return VCY_OK;
+}
+
+void vcy_halo_shutdown(void) {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  for (HaloGroup* g : g_groups) destroy_group(g);
+  g_groups.clear();
 }
 
 const char* vcy_last_collective(void) {

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "vcy_internal.h"
+#include "build_id.h"  // VCY_SOURCE_HASH, written by the Makefile
 
 namespace vcy {
 
@@ -99,6 +100,7 @@ int fill_state(vcy_ctx* c) {
   c->deferred_rc = VCY_OK;
   c->deferred_msg.clear();
   c->fresh = true;  // written lazily, see vcy_ctx::fresh
+  c->brick_min_valid = false;
   c->views_carved = 0;
   c->halo_valid = false;
   c->cnt_implied = true;
@@ -155,7 +157,7 @@ using namespace vcy;
 extern "C" {
 
 const char* vcy_last_error(void) { return g_last_error.c_str(); }
-const char* vcy_version(void) { return "vacancy_amd 0.1 (gfx950)"; }
+const char* vcy_version(void) { return "vacancy_amd 0.3 (gfx950) src:" VCY_SOURCE_HASH; }
 
 int vcy_device_count(int* count) {
   int n = 0;
@@ -316,6 +318,8 @@ void vcy_destroy(vcy_ctx* c) {
   (void)hipFree(c->d_mc_cells);
   (void)hipFree(c->d_fused_scratch);
   (void)hipFree(c->d_wmax);
+  (void)hipFree(c->d_records);
+  (void)hipFree(c->d_brick_min);
   for (auto& t : c->pending) (void)hipFree(t.d_sdf);
   for (auto& t : c->sdf_pool) (void)hipFree(t.first);
   (void)hipFree(c->d_sil_scratch);
@@ -387,6 +391,10 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
     c->mc_sweep = value != 0;
     return VCY_OK;
   }
+  if (std::strcmp(name, "mcskip") == 0) {
+    c->mc_skip = value != 0;
+    return VCY_OK;
+  }
   if (std::strcmp(name, "meshkeys") == 0) {
     c->mesh_keys = value != 0;
     return VCY_OK;
@@ -404,6 +412,8 @@ int vcy_get_param(vcy_ctx* c, const char* name, int* value) {
   else if (std::strcmp(name, "shortdiv") == 0) *value = c->use_short_div ? 1 : 0;
   else if (std::strcmp(name, "div_level") == 0) *value = c->last_div_level;
   else if (std::strcmp(name, "mcsweep") == 0) *value = c->mc_sweep ? 1 : 0;
+  else if (std::strcmp(name, "mcskip") == 0) *value = c->mc_skip ? 1 : 0;
+  else if (std::strcmp(name, "brick_min_valid") == 0) *value = c->brick_min_valid && !c->fresh ? 1 : 0;
   else if (std::strcmp(name, "meshkeys") == 0) *value = c->mesh_keys ? 1 : 0;
   else {
     set_error("unknown parameter %s", name);
@@ -555,6 +565,7 @@ int vcy_upload(vcy_ctx* c, const float* sdf, const int32_t* update_num) {
   }
   c->halo_valid = false;
   c->cnt_implied = false;  // arbitrary state from outside
+  c->brick_min_valid = false;
   return VCY_OK;
 }
 

@@ -66,6 +66,7 @@ struct vcy_ctx {
   float* d_pz = nullptr;
 
   bool mesh_keys = true;              // vcy_extract_iso also returns the edge key of every vertex (vcy_set_param "meshkeys")
+  bool mc_skip = true;                // marching cubes: bricks whose kept minimum is above the iso level are not read (vcy_set_param "mcskip")
   bool mc_sweep = false;              // marching cubes: cell search in one sweep with the bit planes in LDS where the row shape allows (vcy_set_param "mcsweep")
   int tile_mode = 0;                  // 0 auto, 1 the 16 x 16 pixel tile, 2 the 2048-pixel tile filled in place (vcy_set_param "tile")
   bool use_cull = true;               // vcy_set_param("cull", 0): never drop provably idle views
@@ -97,6 +98,10 @@ struct vcy_ctx {
   void* d_fused_scratch = nullptr;    // view blocks + z tables of the fused carve kernel
   size_t fused_scratch_bytes = 0;
   bool cnt_implied = true;            // update_num == 0 implies sdf == lowest(): no vcy_upload since the fill
+  float* d_brick_min = nullptr;       // min(sdf) of every 8x8x8 wave brick of the slab [bz][by][bxw], kept by the fused carve
+  bool brick_min_valid = false;       // ... and current: no write to the state since has bypassed the fused kernel
+  void* d_records = nullptr;          // footprint records of one fused launch, 8 bytes per (wave brick, view)
+  size_t records_bytes = 0;
   float* d_wmax = nullptr;            // window-maximum planes of the views of one fused launch
   size_t wmax_bytes = 0;
   bool fused_ortho = false;           // projection model of the launch being prepared

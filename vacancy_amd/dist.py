@@ -52,11 +52,7 @@ def exchange_halo(carvers, rank, world):
         # distinct device, vcy_halo_allgather)
         if hasattr(lib, "vcy_halo_allgather"):
             from . import carver as _vc
-            text = _vc.halo_allgather(carvers)
-            info = dict(kv.split("=", 1) for kv in text.split() if "=" in kv)
-            return {"backend": "rccl (native, vcy_halo_allgather)", "op": info.get("op"),
-                    "ranks": int(info.get("ranks", 0)), "bytes_per_rank": int(info.get("bytes_per_rank", 0)),
-                    "rccl_version": int(info.get("version", 0)), "slabs": k}
+            return _vc.halo_exchange(carvers)  # (peer copies, and says so, if librccl cannot be loaded)
         packs = [c.halo_pack_host() for c in carvers]  # host stand-ins of the CPU tests
         for i, c in enumerate(carvers):
             if slab_ids[i] > 0:

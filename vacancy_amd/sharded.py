@@ -1,0 +1,174 @@
+"""ShardedVoxelCarver: several GPUs of one node driven from ONE process (Python mirror of
+vacancy::ShardedVoxelCarver, include/vacancy/sharded_voxel_carver.h -- the reference's host model
+is one process, voxel_carver.cc:516-528).
+
+The grid is cut into S = G * k z-slabs, slab s on device s % G (cyclic, as vacancy_amd.dist).  One host
+thread per device drives its slabs through the C-ABI (ctypes releases the GIL during the calls), so the
+devices carve and extract concurrently; carving needs no exchange.  Before an extraction every slab needs
+the two slices below it: ONE RCCL all-gather of every slab's boundary slices, issued by the library itself
+(vcy_halo_allgather: ncclCommInitAll over the devices, one ncclAllGather inside a group call).  No torch,
+no rendezvous, no second process: this is what `bench.py --gpus N --launch inprocess` runs, and what
+bench.py falls back to when torch.distributed.run or the nccl backend cannot start.
+
+`factory(option, device_id, z_range)` builds a slab object with the interface of
+vacancy_amd.carver.VoxelCarver; the CPU tests pass host stand-ins, which exchange halos through
+halo_pack_host / halo_install_host instead of RCCL (tests/test_dist_cpu.py).
+"""
+import threading
+import time
+
+from . import dist as vdist
+
+
+class ShardedVoxelCarver:
+    def __init__(self, option, devices, slabs_per_device=2, factory=None, nz=None):
+        if factory is None:
+            from .carver import VoxelCarver as factory  # noqa: N813
+        self.option = option
+        self.devices = list(devices) if devices else [0]
+        self.k = int(slabs_per_device)
+        self._factory = factory
+        self._nz = nz
+        self.slabs = []       # every slab of the grid, in z order
+        self.by_device = []   # [[slab objects of device g, by slab id]]
+        self.z_ranges = []    # [(z0, z1)] in z order
+        self.last_collective = None
+        self.last_kernel_ms = None   # per device, of the last carve_batch
+        self.dims = None
+
+    # -- VoxelCarver::Init on every slab (voxel_carver.cc:373-392)
+    def Init(self):
+        self.close()
+        g = len(self.devices)
+        nz = self._nz
+        if nz is None:
+            import ctypes as C
+            from . import capi
+            d = (C.c_int32 * 3)()
+            if capi.load().vcy_compute_dims(self.option.bb_min, self.option.bb_max, self.option.resolution, d) != 0:
+                return False
+            nz = d[2]
+        count = g * self.k
+        if nz < 2 * count:
+            raise ValueError("%d z slices cannot be cut into %d slabs of at least 2" % (nz, count))
+        self.by_device = [[] for _ in range(g)]
+        for s in range(count):
+            z0, z1 = vdist.slab_range(nz, s, count)
+            c = self._factory(self.option, self.devices[s % g], (z0, z1))
+            if not c.Init():
+                self.close()
+                return False
+            lead = self.by_device[s % g][0] if self.by_device[s % g] else None
+            if lead is not None and hasattr(c, "use_stream_of"):
+                c.use_stream_of(lead)  # one stream per device: its slabs run back to back
+            self.slabs.append(c)
+            self.by_device[s % g].append(c)
+            self.z_ranges.append((z0, z1))
+        self.dims = getattr(self.slabs[0], "dims", None)
+        return True
+
+    def close(self):
+        for c in reversed(self.slabs):
+            if hasattr(c, "close"):
+                c.close()
+        self.slabs, self.by_device, self.z_ranges = [], [], []
+
+    def set_param(self, name, value):
+        for c in self.slabs:
+            c.set_param(name, value)
+
+    def _per_device(self, fn):
+        """fn(device index, slabs of that device) on one thread per device; re-raises the first failure."""
+        out, err = [None] * len(self.by_device), []
+
+        def run(i):
+            try:
+                out[i] = fn(i, self.by_device[i])
+            except BaseException as e:  # noqa: BLE001 -- reported to the caller below
+                err.append(e)
+
+        threads = [threading.Thread(target=run, args=(i,)) for i in range(len(self.by_device))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if err:
+            raise err[0]
+        return out
+
+    def reset(self):
+        for c in self.slabs:
+            c.reset()
+
+    def sync(self):
+        self._per_device(lambda i, cs: [c.sync() for c in cs])
+
+    # -- Carve(vector<Camera>, ...) loop (voxel_carver.cc:516-528): `batches[g]` = prepare_batch(...) with the
+    # images resident on device g.  Returns the wall time of the slowest device in ms; per-device kernel times
+    # (HIP events on each device's stream) are left in last_kernel_ms.
+    def carve_batch(self, batches, steps=1, reset=True):
+        barrier = threading.Barrier(len(self.by_device))
+        walls = [0.0] * len(self.by_device)
+        kernel = [0.0] * len(self.by_device)
+
+        def run(i, cs):
+            lead = cs[0]
+            for c in cs:
+                c.sync()
+            barrier.wait()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                if reset:
+                    for c in cs:
+                        c.reset()
+                lead.timer_begin()
+                ok = all(c.CarveBatchDevice(batches[i]) for c in cs)
+                kernel[i] += lead.timer_end()
+                if not ok:
+                    raise RuntimeError("carve failed on device %d" % self.devices[i])
+            for c in cs:
+                c.sync()
+            walls[i] = (time.perf_counter() - t0) * 1e3
+            barrier.wait()
+
+        self._per_device(run)
+        self.last_kernel_ms = [k / max(1, steps) for k in kernel]
+        return max(walls)
+
+    # -- the exchange step of MarchingCubes() (marching_cubes.cc:93-101 reads z - 1)
+    def exchange_halo(self):
+        if len(self.slabs) == 1:
+            self.last_collective = {"backend": "none", "ranks": 1, "bytes_per_rank": 0,
+                                    "note": "one slab: nothing to exchange"}
+            return self.last_collective
+        lib = getattr(self.slabs[0], "_lib", None)
+        if lib is not None and hasattr(lib, "vcy_halo_allgather"):
+            from . import carver as _vc
+            self.last_collective = _vc.halo_exchange(self.slabs)  # (peer copies, and says so, without librccl)
+        else:  # host stand-ins
+            packs = [c.halo_pack_host() for c in self.slabs]
+            for s, c in enumerate(self.slabs):
+                if s > 0:
+                    c.halo_install_host(packs[s - 1])
+            self.last_collective = {"backend": "host", "op": "copy", "ranks": 1,
+                                    "bytes_per_rank": sum(len(p) for p in packs), "slabs": len(self.slabs)}
+        return self.last_collective
+
+    # -- ExtractIsoSurface (voxel_carver.cc:540-543): every slab on its device, then the merge by edge key
+    def extract_slabs(self, iso_level=0.0, linear_interp=True, repeat=1):
+        """[mesh of slab s] in z order (the last of `repeat` extractions each)."""
+        self.exchange_halo()
+        meshes = [None] * len(self.slabs)
+        index = {id(c): s for s, c in enumerate(self.slabs)}
+
+        def run(i, cs):
+            for c in cs:
+                for _ in range(repeat):
+                    m = c.ExtractIsoSurface(iso_level, linear_interp)
+                meshes[index[id(c)]] = m
+
+        self._per_device(run)
+        return meshes
+
+    def ExtractIsoSurface(self, iso_level=0.0, linear_interp=True):
+        return vdist.merge_meshes(self.extract_slabs(iso_level, linear_interp))
