@@ -193,24 +193,14 @@ def load_counters(key, build, path=None):
 
 
 def valu_issue_cycles(ctr):
-    """SIMD issue cycles of the VALU work of one launch: dynamic wave-instruction counts by class
-    (SQ_INSTS_VALU_*) x the cycles per wave64 instruction MEASURED on this GPU (profiles/r02/valu_ubench.txt):
-    fp32 add / mul / fma 1.95; transcendentals 7.55; conversions, 64-bit integer and every VALU instruction
-    outside the counted classes (compares, selects, min / max, floor, DPP, readlane ...) 3.5; 32-bit integer
-    2.7 (adds and logic 1.9, shifts and multiplies 3.5).  An SGPR source makes a full-rate instruction half
-    rate when it follows another half-rate one; the counters cannot see that, so this is a lower bound of the
-    issue time (the static per-opcode count is in profiles/r02/isa_histogram_carve_fused.txt)."""
+    """SIMD issue cycles of the VALU work of one launch: wave-level VALU instructions (SQ_INSTS_VALU) x 2 cycles, the
+    issue cost of a wave64 VALU instruction on a SIMD-32 (MI355X_MICROARCH.md).  A lower bound: quarter-rate
+    instructions (v_rcp_f32: 1 in 39 here) and back-to-back half-rate ones cost more.  How close the kernel is to the
+    issue floor of its own instruction stream is MEASURED instead (`issue_floor`, profiles/tools/ab_variants.sh with
+    the floor* builds: the same kernel with its tile loads and stores compiled out)."""
     if not ctr or "SQ_INSTS_VALU" not in ctr:
         return None
-    total = ctr["SQ_INSTS_VALU"]
-    fp = sum(ctr.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"))
-    trans = ctr.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
-    half = ctr.get("SQ_INSTS_VALU_CVT", 0.0) + ctr.get("SQ_INSTS_VALU_INT64", 0.0)
-    int32 = ctr.get("SQ_INSTS_VALU_INT32", 0.0)
-    if fp <= 0.0:  # class counters not collected: everything but the transcendentals at full rate
-        return 1.95 * (total - trans) + 7.55 * trans
-    other = max(0.0, total - fp - trans - half - int32)
-    return 1.95 * fp + 7.55 * trans + 3.5 * (half + other) + 2.7 * int32
+    return 2.0 * ctr["SQ_INSTS_VALU"]
 
 
 def plumbing_check(args, rank, world, dist, backend):
@@ -428,6 +418,7 @@ def main():
                 c.use_stream_of(out[0])  # one stream per GPU: slabs run back to back
             c.set_param("fused", args.batch)
             c.set_param("cull", cull)
+            c.set_param("carvetimer", 1)  # HIP events around the carve kernel itself (vcy_last_carve_ms)
             out.append(c)
         return out
 
@@ -454,8 +445,12 @@ def main():
                 raise SystemExit("carve failed: " + vc.last_error())
             if record is not None:
                 record.append(ms)
+                parts = [c.last_carve_ms() for c in carvers] if args.batch else [(0.0, ms / len(carvers))] * len(carvers)
+                kernel_only.append(sum(p[1] for p in parts))
+                prepass_only.append(sum(p[0] for p in parts))
 
-    kernel_ms = []
+    kernel_ms = []      # per step: everything between vcy_timer_begin / _end (pre-pass, window maxima, carve kernel)
+    kernel_only, prepass_only = [], []  # per step: the carve kernel(s) alone / what runs before them
     batch = vc.VoxelCarver.prepare_batch(views, d_sdf)
     run_steps(devs, batch, args.warmup)
     barrier()
@@ -494,7 +489,10 @@ def main():
     FUSED_MAX = 64  # views per fused launch (carve_fused.hip)
     views_per_launch = min(nv, FUSED_MAX) if args.batch else 1
     launches_per_step = ((nv + views_per_launch - 1) // views_per_launch) * len(devs)
-    avg_launch_ms = sum(kernel_ms) / len(kernel_ms) / launches_per_step
+    n_rec = len(kernel_ms)
+    avg_launch_ms = sum(kernel_only[:n_rec]) / n_rec / launches_per_step  # the dominant kernel alone, HIP events
+    avg_step_device_ms = sum(kernel_ms) / n_rec
+    avg_prepass_ms = sum(prepass_only[:n_rec]) / n_rec
     alg_bytes = slab_vox * views_per_launch * bytes_per_vv(args.mode, uo)
     achieved = alg_bytes / (avg_launch_ms * 1e-3) / 1e9
     ckey = "%s_%d_%d_b%d_c%d" % (args.mode, n, nv, args.batch, args.cull)
@@ -505,31 +503,45 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "carve_fused_kernel" if args.batch else "carve_view_kernel",
                 "avg_launch_ms": round(avg_launch_ms, 4),
+                "avg_launch_ms_note": "carve_fused_kernel alone (HIP events on its stream around the kernel, "
+                                      "vcy_last_carve_ms): what rocprofv3 --kernel-trace reports for it",
+                "step_device_ms": round(avg_step_device_ms, 4),
+                "prepass_ms_per_step": round(avg_prepass_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "achieved/frac use SURVEY 8(d)'s ALGORITHMIC bytes (one state read per voxel*view, the "
-                        "reference's per-view API); the fused kernel keeps the state in registers across the views, "
-                        "so its real HBM traffic is `traffic` and the roof that binds it is VALU issue: see "
-                        "hbm_real_frac and valu_issue_frac"}
+                        "reference's per-view API), so frac > 1 is not a bandwidth claim: the fused kernel keeps the state "
+                        "in registers across the views and drops views that provably change nothing.  Its real HBM traffic "
+                        "is `traffic` (hbm_real_frac of the peak); what binds it is VALU issue: valu_issue_frac_flat2 (2 "
+                        "cycles per wave instruction) and issue_floor (measured: this kernel / the same kernel without "
+                        "its tile loads and stores, for the variants whose control flow does not depend on the data)"}
     if ctr is None:
         roofline["counters_note"] = ctr_note
     # the roofs that actually bind the kernel: real HBM traffic and VALU issue slots (counters of the
     # committed PMC passes for this workload, duration measured live above)
     if traffic:
-        roofline["hbm_real_gbs"] = round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1)
-        roofline["hbm_real_frac"] = round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        t_k = ctr.get("trace_avg_ns", avg_launch_ms * 1e6) * 1e-9  # the carve kernel alone, in the profiled run
+        roofline["hbm_real_gbs"] = round(traffic / t_k / 1e9, 1)
+        roofline["hbm_real_frac"] = round(traffic / t_k / 1e9 / HBM_PEAK_GBS, 4)
+        roofline["traffic_note"] = "carve_fused_kernel alone; the footprint pre-pass moves another %s B per step" % (
+            ctr.get("prepass_hbm_bytes_per_launch", "?"))
     vcyc = valu_issue_cycles(ctr)
     if vcyc:
         roofline["bound_actual"] = "valu"
-        roofline["valu_issue_frac"] = round(vcyc / (N_SIMD * CLOCK_HZ * avg_launch_ms * 1e-3), 4)
-        # the same against the shader clock the profiled launch really ran at (GRBM_GUI_ACTIVE counts the busy
-        # cycles of each of the 8 XCDs over the launch; the 2.4 GHz above is the boost clock)
+        # against the shader clock the profiled launch really ran at (GRBM_GUI_ACTIVE counts the busy cycles of each
+        # of the 8 XCDs over the launch; 2.4 GHz is the boost clock)
+        clk = CLOCK_HZ
         if ctr.get("GRBM_GUI_ACTIVE") and ctr.get("trace_avg_ns"):
             clk = ctr["GRBM_GUI_ACTIVE"] / 8.0 / (ctr["trace_avg_ns"] * 1e-9)
             roofline["shader_clock_ghz_profiled"] = round(clk / 1e9, 3)
-            roofline["valu_issue_frac_at_profiled_clock"] = round(vcyc / (N_SIMD * clk * avg_launch_ms * 1e-3), 4)
+        # (the counters are of the carve kernel alone: its own duration in the profiled run, not the step's)
+        t_kernel = ctr.get("trace_avg_ns", avg_launch_ms * 1e6) * 1e-9
+        roofline["valu_issue_frac_flat2"] = round(vcyc / (N_SIMD * clk * t_kernel), 4)
         roofline["valu_wave_insts_per_launch"] = ctr["SQ_INSTS_VALU"]
         roofline["valu_insts_per_voxel_view"] = round(ctr["SQ_INSTS_VALU"] * 64.0 / (slab_vox * views_per_launch), 3)
         roofline["counters_source"] = ctr.get("source")
+    floor, _ = load_counters("issue_floor", build) if world == 1 else (None, None)
+    if floor:
+        roofline["issue_floor"] = {k: floor[k] for k in floor if k not in ("build",)}
     # marching cubes (second half of the metric), outside the timed region
     mc = None
     collective = {"backend": "none", "ranks": world, "bytes_per_rank": 0, "note": "one slab: nothing to exchange"}

@@ -271,11 +271,17 @@ int vcy_reset(vcy_ctx* ctx);
  * "meshkeys" (default 1): vcy_extract_iso returns vcy_mesh.edge_keys; 0 leaves it NULL (nothing is computed for
  * it or copied: a third of the mesh bytes) -- for callers that do not merge z-slabs, i.e. what the reference's
  * MarchingCubes returns.
+ * "mcskip" (default 1): vcy_extract_iso does not read bricks whose minimum -- kept per 8 x 8 x 8 brick by the fused
+ * carve kernel -- lies above the iso level (they are outside the surface whatever they hold exactly); 0 reads every brick.
+ * "livelist" (default 1): a carve launch of up to 8 views over an already carved grid first lists the workgroups in
+ * which some view can still change a voxel (bounds of the views' samples against the kept brick minima / the
+ * truncation limit) and starts only those; 0 starts every workgroup and lets each decide for itself.
  * "inject_carve_failure" (test hook, default 0): the next `value` applications of views fail with
  * VCY_ERR_INTERNAL before anything is launched -- how the tests exercise the error contract of vcy_carve. */
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
-/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep", "meshkeys"), or "div_level": the division sequence
- * the last fused launch was instantiated with (2: 4 instructions, 1: 6, 0: full IEEE expansion). */
+/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep", "mcskip", "livelist", "meshkeys"), "div_level": the
+ * division sequence the last fused launch was instantiated with (2: 4 instructions, 1: 6, 0: full IEEE expansion), or
+ * "brick_min_valid": 1 while the brick minima describe the state (every write since the fill went through the fused kernel). */
 int vcy_get_param(vcy_ctx* ctx, const char* name, int* value);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all launches. */
 int vcy_set_stream(vcy_ctx* ctx, void* hip_stream);
@@ -285,6 +291,11 @@ int vcy_sync(vcy_ctx* ctx);
  * between begin and end; vcy_timer_end synchronises and returns milliseconds. */
 int vcy_timer_begin(vcy_ctx* ctx);
 int vcy_timer_end(vcy_ctx* ctx, float* elapsed_ms);
+
+/* With vcy_set_param(ctx, "carvetimer", 1): milliseconds (HIP events on the context's stream) of the last fused
+ * carve launch, split into what runs before the carve kernel (footprint pre-pass, live-workgroup list) and the
+ * carve kernel itself -- the kernel the roofline is quoted for.  Synchronises with that launch. */
+int vcy_last_carve_ms(vcy_ctx* ctx, float* prepass_ms, float* kernel_ms);
 
 /* Device-side self test of the identities the fast paths rest on (no reference counterpart): the
  * two-instruction reciprocal used for update_num + 1 in the unit-weight weighted average equals the

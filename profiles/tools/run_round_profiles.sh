@@ -11,7 +11,7 @@ O=$R/gpurun_out/$RND
 mkdir -p "$O"
 export TMPDIR=/tmp
 CTR=$O/counters.json
-rm -f "$CTR"
+rm -f "$CTR" "$O/status.txt"
 # carve workloads: trace + counters (no marching cubes inside these runs)
 bash profiles/tools/profile_gpu.sh gpurun_out/$RND/default --no-mc
 python profiles/tools/summarize_pmc.py "$O/default" "$O/pmc_1024x32_default.json" --key default_1024_32_b1_c1 --counters "$CTR"
@@ -27,6 +27,17 @@ python profiles/tools/summarize_pmc.py "$O/mc" "$O/pmc_1024_marching_cubes.json"
 profiles/tools/ab_mc.sh prod > "$O/mc_unprofiled.txt" 2>&1
 # the one-sweep cell search against the bit planes in memory ("mcsweep" 1 / 0), alternating in one process
 profiles/tools/ab_mc_sweep.sh prod 2>&1 | grep mcsweep > "$O/mc_sweep_vs_bit_planes.txt"
+# marching cubes with / without the brick minima, the per-view call pattern with / without the live-workgroup list
+python profiles/tools/mc_skip.py 2>&1 | grep mcskip > "$O/marching_cubes_brick_minima.txt"
+for m in default tsdf; do python profiles/tools/per_view.py 1024 $m 2>&1 | grep livelist; done > "$O/per_view_launches.txt"
+# issue floor of the fused kernel: the same instruction stream without tile loads (T), without stores (S), without both
+if [ -f build/variants/floorTS/libvacancy_hip.so ]; then
+  profiles/tools/ab_variants.sh "$O/floor" devprod floorT floorS floorTS devprod floorT floorS floorTS > "$O/issue_floor.txt" 2>&1
+  python profiles/tools/summarize_floor.py "$O/issue_floor.txt" "$CTR"
+fi
+# N GPUs from one process (threads + vcy_halo_allgather): two "GPUs" on this one device
+VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --launch inprocess --steps 5 --warmup 1 > "$O/bench_inprocess_2x_one_device.json" 2> "$O/bench_inprocess_2x_one_device.err"
+echo "in-process 2 x one device rc=$?" >> "$O/status.txt"
 # phase breakdown of the fused kernel (development build with s_memtime marks)
 if [ -f build/variants/phase/libvacancy_hip.so ]; then
   VCY_HIP_LIB=build/variants/phase/libvacancy_hip.so python profiles/tools/phase_timing.py > "$O/phase_timing.log" 2>&1
@@ -34,9 +45,9 @@ if [ -f build/variants/phase/libvacancy_hip.so ]; then
 fi
 # the multi-rank path of bench.py on this one device: 2 ranks, 2 slabs each, halo exchange over gloo (RCCL refuses
 # two ranks on one device; --allow-gloo is the documented escape for exactly this check)
-VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-variants --allow-gloo > "$O/bench_2ranks_one_device_gloo.json" 2> "$O/bench_2ranks_one_device_gloo.err"
-echo "2 ranks (gloo) rc=$?" > "$O/status.txt"
-VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-variants > "$O/bench_2ranks_one_device_rccl.json" 2> "$O/bench_2ranks_one_device_rccl.err"
+VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --launch torchrun --steps 3 --warmup 1 --no-cpu-baseline --no-variants --allow-gloo > "$O/bench_2ranks_one_device_gloo.json" 2> "$O/bench_2ranks_one_device_gloo.err"
+echo "2 ranks (gloo) rc=$?" >> "$O/status.txt"
+VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --launch torchrun --steps 3 --warmup 1 --no-cpu-baseline --no-variants > "$O/bench_2ranks_one_device_rccl.json" 2> "$O/bench_2ranks_one_device_rccl.err"
 echo "2 ranks (rccl on one device, expected to be refused) rc=$?" >> "$O/status.txt"
 # the bench lines: with the counters of this session next to them
 mkdir -p profiles && cp "$CTR" profiles/counters.json

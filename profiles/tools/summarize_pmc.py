@@ -75,6 +75,10 @@ def main():
         entry = {k: v for k, v in per[kernel].items() if not k.startswith("dispatches_")}
         entry["source"] = os.path.relpath(out, os.path.dirname(os.path.dirname(os.path.abspath(cpath))))
         entry["build"] = library_build()  # bench.py only uses counters of the build it runs
+        pre = per.get("footprint_records", {})
+        if kernel == "carve_fused" and "hbm_bytes_per_launch" in pre:  # what runs in front of the carve kernel
+            entry["prepass_hbm_bytes_per_launch"] = pre["hbm_bytes_per_launch"]
+            entry["prepass_trace_avg_ns"] = pre.get("trace_avg_ns")
         allc[key] = entry
         json.dump(allc, open(cpath, "w"), indent=1, sort_keys=True)
         print("updated", cpath, key)
@@ -95,16 +99,28 @@ def main():
 
 
 def mc_entry(per):
-    """Bytes one extraction moves: every marching-cubes kernel x its launches, over the number of extractions in
-    the run (= launches of the cell search: mc_sweep, or mc_active on the bit-plane path)."""
+    """Bytes one extraction moves: every marching-cubes kernel x its launches per extraction (= launches of the cell
+    search: mc_sweep, or mc_active on the bit-plane path).  The run holds extractions of both kinds -- bricks outside
+    the surface skipped (mc_bits_bricks, the default) and every brick read (mc_bits, "mcskip" 0): the pass over the
+    state is counted once per extraction with the per-launch bytes of the kernel of that kind."""
     names = [k for k in per if re.match(r"mc_|scan_chunks|add_chunk_offsets", k) and "hbm_bytes_per_launch" in per[k]]
     calls = per.get("mc_sweep", per.get("mc_active", {})).get("dispatches_FETCH_SIZE", 0)
     if not calls:
         return None
-    total = sum(per[k]["hbm_bytes_per_launch"] * per[k]["dispatches_FETCH_SIZE"] for k in names)
-    return {"hbm_bytes_per_call": int(total / calls), "extractions_in_run": calls,
-            "kernels": {k: {"launches_per_call": per[k]["dispatches_FETCH_SIZE"] / calls,
-                            "hbm_bytes_per_launch": per[k]["hbm_bytes_per_launch"]} for k in sorted(names)}}
+    state_pass = {"mc_bits", "mc_bits_bricks"}
+    rest = sum(per[k]["hbm_bytes_per_launch"] * per[k]["dispatches_FETCH_SIZE"] for k in names if k not in state_pass) / calls
+    entry = {"extractions_in_run": calls,
+             "kernels": {k: {"launches_per_call": per[k]["dispatches_FETCH_SIZE"] / calls,
+                             "hbm_bytes_per_launch": per[k]["hbm_bytes_per_launch"]} for k in sorted(names)}}
+    if "mc_bits_bricks" in per and "hbm_bytes_per_launch" in per["mc_bits_bricks"]:
+        entry["hbm_bytes_per_call"] = int(rest + per["mc_bits_bricks"]["hbm_bytes_per_launch"])
+        if "mc_bits" in per and "hbm_bytes_per_launch" in per["mc_bits"]:
+            entry["hbm_bytes_per_call_every_brick_read"] = int(rest + per["mc_bits"]["hbm_bytes_per_launch"])
+    elif "mc_bits" in per and "hbm_bytes_per_launch" in per["mc_bits"]:
+        entry["hbm_bytes_per_call"] = int(rest + per["mc_bits"]["hbm_bytes_per_launch"])
+    else:
+        entry["hbm_bytes_per_call"] = int(rest)
+    return entry
 
 
 if __name__ == "__main__":

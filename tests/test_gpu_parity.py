@@ -902,13 +902,13 @@ def test_failed_flush_is_reported_once_to_the_carve_loop():
     assert_state_equal(dev, orc, "after injected failures")
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(use_truncation=True, truncation_band=0.1),
-                                dict(voxel_update=1, use_truncation=True, truncation_band=0.1)])
-def test_single_view_launches_with_brick_minima(kw):
+@pytest.mark.parametrize("kw,livelist", [(dict(), 1), (dict(), 0), (dict(use_truncation=True, truncation_band=0.1), 1),
+                                         (dict(voxel_update=1, use_truncation=True, truncation_band=0.1), 1)])
+def test_single_view_launches_with_brick_minima(kw, livelist):
     """The reference's call pattern (examples.cc:117-149): carve ONE view, extract, carve the next ... With
     `defer` 0 every call is a launch of its own; from the second on a wave whose view provably changes nothing
     (bound against the brick minimum the previous launch left, or below the truncation limit) returns without
-    reading the state, and marching cubes skips bricks whose minimum lies above the iso level.  State and mesh
+    reading the state -- or, with the live list, is never started -- and marching cubes skips bricks whose minimum lies above the iso level.  State and mesh
     equal the oracle's after every view, on smooth and adversarial images; writes that bypass the fused kernel
     (vcy_upload, the per-view kernel) switch the minima off until the next fused launch has rebuilt them."""
     n, nv, w, h = 72, 14, 200, 150
@@ -919,6 +919,7 @@ def test_single_view_launches_with_brick_minima(kw):
     dev = vc.VoxelCarver(opt)
     assert dev.Init(), vc.last_error()
     dev.set_param("defer", 0)
+    dev.set_param("livelist", livelist)  # 1: only the workgroups with a live (brick, view) pair are started
     orc = O.OracleGrid(opt)
     base = O.make_sdf(masks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
     for i in range(nv):

@@ -156,6 +156,7 @@ def load():
         "vcy_timer_begin": (C.c_int, [vp]),
         "vcy_timer_end": (C.c_int, [vp, P(C.c_float)]),
         "vcy_selftest": (C.c_int, [vp]),
+        "vcy_last_carve_ms": (C.c_int, [vp, P(C.c_float), P(C.c_float)]),
         "vcy_measure_bandwidth": (C.c_int, [C.c_int, C.c_uint64, C.c_int, P(C.c_double), P(C.c_double)]),
         "vcy_last_error": (C.c_char_p, []),
         "vcy_version": (C.c_char_p, []),

@@ -285,6 +285,12 @@ class VoxelCarver:
         """vcy_selftest: device-side identities behind the fast paths; True when all hold."""
         return self._lib.vcy_selftest(self._ctx) == 0
 
+    def last_carve_ms(self):
+        """(pre-pass ms, carve kernel ms) of the last fused launch; needs set_param("carvetimer", 1)."""
+        a, b = C.c_float(), C.c_float()
+        assert self._lib.vcy_last_carve_ms(self._ctx, C.byref(a), C.byref(b)) == 0, last_error()
+        return a.value, b.value
+
     def timer_begin(self):
         self._lib.vcy_timer_begin(self._ctx)
 
@@ -326,9 +332,13 @@ def halo_exchange(carvers):
                 "ranks": len({c._device for c in carvers}), "bytes_total": nbytes, "slabs": len(carvers),
                 "note": str(e)[:160]}
     info = dict(kv.split("=", 1) for kv in text.split() if "=" in kv)
-    return {"backend": "rccl (native, vcy_halo_allgather)", "op": info.get("op"), "ranks": int(info.get("ranks", 0)),
-            "bytes_per_rank": int(info.get("bytes_per_rank", 0)), "rccl_version": int(info.get("version", 0)),
-            "slabs": len(carvers)}
+    ranks, per = int(info.get("ranks", 0)), int(info.get("bytes_per_rank", 0))
+    # an all-gather hands EVERY rank every pack (ranks * bytes_per_rank received per rank) although a slab only needs
+    # the pack of the slab below it: what the north star asks for, and small next to the state (10 MiB per slab at 1024^2)
+    return {"backend": "rccl (native, vcy_halo_allgather)", "op": info.get("op"), "ranks": ranks,
+            "bytes_per_rank": per, "bytes_received_per_rank": per * ranks,
+            "bytes_needed_per_slab": int(capi.load().vcy_halo_bytes(carvers[0].ctx)),
+            "rccl_version": int(info.get("version", 0)), "slabs": len(carvers)}
 
 
 def measure_bandwidth(device_id=0, nbytes=1 << 31, reps=3):

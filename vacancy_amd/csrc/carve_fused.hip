@@ -67,6 +67,7 @@ constexpr int kTileBig = 512;            // (in float4 units)
 constexpr int kBigPixels = 4 * kTileBig;
 
 constexpr int kWmaxPlanes = 2;           // window sizes 4 and 8
+constexpr int kLiveListMaxViews = 8;      // launches of up to this many views over a carved grid list their live workgroups first
 constexpr int64_t kRecordBytesMax = (int64_t)1 << 30;  // footprint records of one carve launch (see launch_carve_fused)
 
 
@@ -825,6 +826,42 @@ __global__ __launch_bounds__(256) void footprint_records_kernel(GridParams g, co
   records[(int64_t)vi * nbricks + brick] = pack_footprint(ti, fv.v);
 }
 
+// Which workgroups of a carve launch have anything to do: a (wave brick, view) pair is dropped before the state is
+// read when every sample is below the truncation limit or (kMax) not above the brick minimum the previous launch
+// left (the early return of carve_fused_kernel, same test on the same records).  For a launch of few views over a
+// carved grid -- the reference's `Carve(view); ExtractIsoSurface();` loop makes every view a launch of its own --
+// most workgroups would only start, load 8 bytes and leave; 2 M such waves cost more than the bricks that do
+// change.  This pass lists the workgroups with a live pair, list[0] = their number, list[1 ...] = their linear
+// ids (any order); the carve kernel is launched over the full range and workgroups beyond list[0] leave at once.
+__global__ __launch_bounds__(256) void live_workgroups_kernel(const FootprintRecord* __restrict__ recs, int64_t nbricks,
+                                                              int nviews, const float* __restrict__ bmin, int trunc,
+                                                              int nbx, int nby, int nbw, int nwg, int* __restrict__ list) {
+  const int wg = blockIdx.x * 256 + threadIdx.x;
+  bool live = false;
+  if (wg < nwg) {
+    const int bx = wg % nbx, r = wg / nbx;
+    const int by = r % nby, bz = r / nby;
+    for (int j = 0; j < kWgWaves; ++j) {
+      const int bxw = bx * kWgWaves + j;
+      if (bxw >= nbw) break;
+      const int64_t brick = ((int64_t)bz * nby + by) * nbw + bxw;
+      const float smin = bmin ? bmin[brick] : 0.0f;
+      for (int v = 0; v < nviews; ++v) {
+        const float ub = __uint_as_float(recs[(int64_t)v * nbricks + brick].w0 & ~63u);
+        const bool drop = (trunc && ub < -1.0f) || (bmin != nullptr && ub <= smin);
+        live = live || !drop;
+      }
+    }
+  }
+  const unsigned long long m = __ballot(live);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(&list[0], __popcll(m));
+  base = __shfl(base, 0, 64);
+  if (live) list[1 + base + __popcll(m & ((1ull << lane) - 1ull))] = wg;
+}
+
 // GEN: nearest-neighbour sampling and/or an orthographic camera, selected at run time from `mode`
 // (compiled out of the default bilinear + pinhole kernels, where the extra branches cost 16 %).
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX, int TQ, bool GEN, int DIV>
@@ -836,7 +873,8 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
                                                           int nviews, ModeParams mode, int nbx,
                                                           int nby, int cull_enabled, int state_flags,
                                                           const FootprintRecord* __restrict__ records,
-                                                          int64_t nbricks, float* __restrict__ brick_min) {
+                                                          int64_t nbricks, float* __restrict__ brick_min,
+                                                          const int* __restrict__ wg_list) {
   // brick_min[wave brick] (or null): min(sdf) over the brick as the carve kernels left it -- lowest() while a
   // voxel of it is untouched.  Written by every fused launch; READ (state_flags bit 2: every write to the state
   // since the slab was fresh went through a fused launch) to drop views before the state is loaded: a wave
@@ -877,7 +915,10 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   // that follow each other on an XCD are neighbours in x and share SDF footprint pixels and
   // z-table entries in that XCD's private L2.
   int b = blockIdx.x;
-  {
+  if (wg_list != nullptr) {  // only the workgroups live_workgroups_kernel listed (wg_list[0] of them)
+    if (b >= wg_list[0]) return;
+    b = wg_list[1 + b];
+  } else {
     const int nb = gridDim.x, per = nb >> 3;
     if (b < per * 8) b = (b & 7) * per + (b >> 3);
   }
@@ -1411,12 +1452,12 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF>
 void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const GridParams& g, const FusedView* dv,
                     const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh,
-                    const FootprintRecord* recs, int64_t nbricks, float* bmin) {
+                    const FootprintRecord* recs, int64_t nbricks, float* bmin, const int* wgl) {
   const bool gen = m.ortho != 0 || m.interp == VCY_INTERP_NN;
 #define VCY_FUSED(CM, TQ_, GEN_, DIV_)                                                                           \
-  hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, CM, TQ_, GEN_, DIV_>), grid, dim3(64 * kWgWaves), \
+  hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, CM, TQ_, GEN_, DIV_>), grid, dim3(64 * kWgWaves),  \
                      (size_t)kWgWaves * tile_f4_per_wave<TQ_>() * sizeof(float4) + (size_t)kWgWaves * nv * sizeof(TileInfo), s, \
-                     g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin)
+                     g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl)
 #define VCY_FUSED_G(CM, TQ_)                                                                                     \
   do {                                                                                                           \
     if (gen) VCY_FUSED(CM, TQ_, true, 0);                                                                        \
@@ -1447,26 +1488,26 @@ void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const Gri
 template <typename CountT, int UPDATE>
 void launch_fused_2(bool big, bool trunc, bool samef, bool checkmax, dim3 grid, hipStream_t s, const GridParams& g,
                     const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh,
-                    const FootprintRecord* recs, int64_t nbricks, float* bmin) {
+                    const FootprintRecord* recs, int64_t nbricks, float* bmin, const int* wgl) {
   if (trunc) {
-    if (samef) launch_fused_4<CountT, UPDATE, true, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin);
-    else launch_fused_4<CountT, UPDATE, true, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin);
+    if (samef) launch_fused_4<CountT, UPDATE, true, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl);
+    else launch_fused_4<CountT, UPDATE, true, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl);
   } else {
-    if (samef) launch_fused_4<CountT, UPDATE, false, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin);
-    else launch_fused_4<CountT, UPDATE, false, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin);
+    if (samef) launch_fused_4<CountT, UPDATE, false, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl);
+    else launch_fused_4<CountT, UPDATE, false, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl);
   }
 }
 
 template <typename CountT>
 void launch_fused_1(bool big, int update, bool trunc, bool samef, bool checkmax, dim3 grid, hipStream_t s,
                     const GridParams& g, const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh,
-                    const FootprintRecord* recs, int64_t nbricks, float* bmin) {
+                    const FootprintRecord* recs, int64_t nbricks, float* bmin, const int* wgl) {
   if (update == VCY_UPDATE_MAX)
-    launch_fused_2<CountT, VCY_UPDATE_MAX>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin);
+    launch_fused_2<CountT, VCY_UPDATE_MAX>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl);
   else if (g.weight == 1.0f)
-    launch_fused_2<CountT, kUpdateWaUnitWeight>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin);
+    launch_fused_2<CountT, kUpdateWaUnitWeight>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl);
   else
-    launch_fused_2<CountT, VCY_UPDATE_WEIGHTED_AVERAGE>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin);
+    launch_fused_2<CountT, VCY_UPDATE_WEIGHTED_AVERAGE>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl);
 }
 
 // Exhaustive check of the short division sequences for ONE numerator: every significand of the
@@ -1745,6 +1786,22 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     const int64_t nbricks = layer_bricks * layers;
     FootprintRecord* recs = (FootprintRecord*)c->d_records;
     float* bmin = c->d_brick_min ? c->d_brick_min + (int64_t)l0 * layer_bricks : nullptr;
+    // ("carvetimer" 1: events around the pre-pass and around the carve kernel, read by vcy_last_carve_ms)
+    const bool timed = c->time_carve && c->ev_carve[0] != nullptr;
+    if (timed && l0 == 0) {
+      c->carve_prepass_ms = c->carve_kernel_ms = 0.0f;
+      c->carve_timed_chunks = 0;
+    }
+    if (timed && c->carve_timed_chunks > 0) {  // (one event set: the previous chunk's times are collected first)
+      float a = 0.0f, b2 = 0.0f;
+      VCY_HIP_CHECK(hipEventSynchronize(c->ev_carve[2]));
+      VCY_HIP_CHECK(hipEventElapsedTime(&a, c->ev_carve[0], c->ev_carve[1]));
+      VCY_HIP_CHECK(hipEventElapsedTime(&b2, c->ev_carve[1], c->ev_carve[2]));
+      c->carve_prepass_ms += a;
+      c->carve_kernel_ms += b2;
+      c->carve_timed_chunks = 0;
+    }
+    if (timed) VCY_HIP_CHECK(hipEventRecord(c->ev_carve[0], c->stream));
     if (!big) {
       const dim3 pgrid((unsigned)((nbricks + 255) / 256), (unsigned)n_views);
 #define VCY_PREPASS(SF, GN)                                                                                       \
@@ -1756,13 +1813,53 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
       VCY_HIP_CHECK(hipGetLastError());
     }
     const dim3 grid((unsigned)((int64_t)nbx * nby * layers));
+    // few views over a carved grid: only the workgroups with a live (brick, view) pair (live_workgroups_kernel)
+    const int* wgl = nullptr;
+    const bool have_min = u.voxel_update == VCY_UPDATE_MAX && (state_flags & 4) != 0 && bmin != nullptr;
+    // (not when the list of the previous such launch held most workgroups anyway -- a weighted-average carve touches
+    // nearly every brick with every view, and the list pass is then 4 % on top; the count arrives by an asynchronous
+    // copy into page-locked memory and is only a hint: reading an older value is harmless)
+    const bool list_pays = c->h_live_hint == nullptr || c->h_live_hint[1] <= 0 ||
+                           (double)c->h_live_hint[0] < 0.6 * (double)c->h_live_hint[1];
+    ++c->live_list_age;
+    if (!big && c->use_live_list && need_bound && !c->fresh && n_views <= kLiveListMaxViews && (m.trunc != 0 || have_min) &&
+        (list_pays || c->live_list_age % 16 == 0)) {  // (every 16th launch looks again)
+      const int nwg = (int)grid.x;
+      const size_t need = sizeof(int) * ((size_t)nwg + 1);
+      if (c->wg_list_bytes < need) {
+        VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->d_wg_list) (void)hipFree(c->d_wg_list);
+        c->d_wg_list = nullptr;
+        c->wg_list_bytes = 0;
+        VCY_HIP_CHECK(hipMalloc(&c->d_wg_list, need));
+        c->wg_list_bytes = need;
+      }
+      VCY_HIP_CHECK(hipMemsetAsync(c->d_wg_list, 0, sizeof(int), c->stream));
+      hipLaunchKernelGGL(live_workgroups_kernel, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, c->stream, recs, nbricks,
+                         n_views, have_min ? bmin : nullptr, m.trunc, nbx, nby, nbw, nwg, c->d_wg_list);
+      VCY_HIP_CHECK(hipGetLastError());
+      wgl = c->d_wg_list;
+      if (!c->h_live_hint && hipHostMalloc((void**)&c->h_live_hint, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        c->h_live_hint = nullptr;
+        (void)hipGetLastError();
+      }
+      if (c->h_live_hint) {
+        c->h_live_hint[1] = nwg;
+        (void)hipMemcpyAsync(&c->h_live_hint[0], c->d_wg_list, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+      }
+    }
+    if (timed) VCY_HIP_CHECK(hipEventRecord(c->ev_carve[1], c->stream));
     if (c->cnt_bytes == 1)
       launch_fused_1<uint8_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, gc, d_views,
-                              d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin);
+                              d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin, wgl);
     else
       launch_fused_1<uint16_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, gc, d_views,
-                               d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin);
+                               d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin, wgl);
     VCY_HIP_CHECK(hipGetLastError());
+    if (timed) {
+      VCY_HIP_CHECK(hipEventRecord(c->ev_carve[2], c->stream));
+      c->carve_timed_chunks = 1;
+    }
   }
   c->fresh = false;  // the launches store every voxel of a fresh slab
   c->brick_min_valid = c->d_brick_min != nullptr && c->cnt_implied;  // (every wave that did not return early wrote its entry)

@@ -101,6 +101,7 @@ int fill_state(vcy_ctx* c) {
   c->deferred_msg.clear();
   c->fresh = true;  // written lazily, see vcy_ctx::fresh
   c->brick_min_valid = false;
+  if (c->h_live_hint) c->h_live_hint[0] = c->h_live_hint[1] = 0;
   c->views_carved = 0;
   c->halo_valid = false;
   c->cnt_implied = true;
@@ -319,6 +320,10 @@ void vcy_destroy(vcy_ctx* c) {
   (void)hipFree(c->d_fused_scratch);
   (void)hipFree(c->d_wmax);
   (void)hipFree(c->d_records);
+  (void)hipFree(c->d_wg_list);
+  if (c->h_live_hint) (void)hipHostFree(c->h_live_hint);
+  for (int k = 0; k < 3; ++k)
+    if (c->ev_carve[k]) (void)hipEventDestroy(c->ev_carve[k]);
   (void)hipFree(c->d_brick_min);
   for (auto& t : c->pending) (void)hipFree(t.d_sdf);
   for (auto& t : c->sdf_pool) (void)hipFree(t.first);
@@ -391,6 +396,18 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
     c->mc_sweep = value != 0;
     return VCY_OK;
   }
+  if (std::strcmp(name, "carvetimer") == 0) {
+    c->time_carve = value != 0;
+    if (c->time_carve && !c->ev_carve[0]) {
+      VCY_HIP_CHECK(hipSetDevice(c->device));
+      for (int k = 0; k < 3; ++k) VCY_HIP_CHECK(hipEventCreate(&c->ev_carve[k]));
+    }
+    return VCY_OK;
+  }
+  if (std::strcmp(name, "livelist") == 0) {
+    c->use_live_list = value != 0;
+    return VCY_OK;
+  }
   if (std::strcmp(name, "mcskip") == 0) {
     c->mc_skip = value != 0;
     return VCY_OK;
@@ -413,6 +430,7 @@ int vcy_get_param(vcy_ctx* c, const char* name, int* value) {
   else if (std::strcmp(name, "div_level") == 0) *value = c->last_div_level;
   else if (std::strcmp(name, "mcsweep") == 0) *value = c->mc_sweep ? 1 : 0;
   else if (std::strcmp(name, "mcskip") == 0) *value = c->mc_skip ? 1 : 0;
+  else if (std::strcmp(name, "livelist") == 0) *value = c->use_live_list ? 1 : 0;
   else if (std::strcmp(name, "brick_min_valid") == 0) *value = c->brick_min_valid && !c->fresh ? 1 : 0;
   else if (std::strcmp(name, "meshkeys") == 0) *value = c->mesh_keys ? 1 : 0;
   else {
@@ -448,6 +466,23 @@ int vcy_timer_end(vcy_ctx* c, float* ms) {
   VCY_HIP_CHECK(hipEventRecord(c->ev_end, c->stream));
   VCY_HIP_CHECK(hipEventSynchronize(c->ev_end));
   VCY_HIP_CHECK(hipEventElapsedTime(ms, c->ev_begin, c->ev_end));
+  return VCY_OK;
+}
+
+int vcy_last_carve_ms(vcy_ctx* c, float* prepass_ms, float* kernel_ms) {
+  if (!c || !prepass_ms || !kernel_ms) return VCY_ERR_INVALID_ARG;
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  if (c->carve_timed_chunks > 0) {  // the last chunk's events
+    float a = 0.0f, b = 0.0f;
+    VCY_HIP_CHECK(hipEventSynchronize(c->ev_carve[2]));
+    VCY_HIP_CHECK(hipEventElapsedTime(&a, c->ev_carve[0], c->ev_carve[1]));
+    VCY_HIP_CHECK(hipEventElapsedTime(&b, c->ev_carve[1], c->ev_carve[2]));
+    c->carve_prepass_ms += a;
+    c->carve_kernel_ms += b;
+    c->carve_timed_chunks = 0;
+  }
+  *prepass_ms = c->carve_prepass_ms;
+  *kernel_ms = c->carve_kernel_ms;
   return VCY_OK;
 }
 

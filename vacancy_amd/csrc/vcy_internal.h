@@ -100,6 +100,15 @@ struct vcy_ctx {
   bool cnt_implied = true;            // update_num == 0 implies sdf == lowest(): no vcy_upload since the fill
   float* d_brick_min = nullptr;       // min(sdf) of every 8x8x8 wave brick of the slab [bz][by][bxw], kept by the fused carve
   bool brick_min_valid = false;       // ... and current: no write to the state since has bypassed the fused kernel
+  int* d_wg_list = nullptr;           // live workgroups of a carve launch of few views ([0] = count), live_workgroups_kernel
+  size_t wg_list_bytes = 0;
+  bool time_carve = false;            // vcy_set_param("carvetimer", 1): events around pre-pass and carve kernel of a fused launch
+  hipEvent_t ev_carve[3] = {nullptr, nullptr, nullptr};
+  float carve_prepass_ms = 0.0f, carve_kernel_ms = 0.0f;  // of the last fused launch (vcy_last_carve_ms)
+  int carve_timed_chunks = 0;
+  int* h_live_hint = nullptr;         // page-locked {live workgroups, workgroups} of the last listed launch (a hint, see launch_carve_fused)
+  int64_t live_list_age = 0;
+  bool use_live_list = true;          // vcy_set_param("livelist", 0): every workgroup is launched and decides for itself
   void* d_records = nullptr;          // footprint records of one fused launch, 8 bytes per (wave brick, view)
   size_t records_bytes = 0;
   float* d_wmax = nullptr;            // window-maximum planes of the views of one fused launch

@@ -64,7 +64,8 @@ def exchange_halo(carvers, rank, world):
     on_gpu = dist.get_backend() == "nccl"
     result = {"backend": "rccl (torch.distributed nccl)" if on_gpu else "gloo (host staging)",
               "op": "all_gather_into_tensor" if on_gpu else "all_gather", "ranks": dist.get_world_size(),
-              "bytes_per_rank": nbytes * k, "slabs_per_rank": k}
+              "bytes_per_rank": nbytes * k, "bytes_received_per_rank": nbytes * k * dist.get_world_size(),
+              "bytes_needed_per_slab": nbytes, "slabs_per_rank": k}
     if on_gpu:
         send = torch.empty(nbytes * k, dtype=torch.uint8, device="cuda")
         recv = torch.empty(nbytes * k * world, dtype=torch.uint8, device="cuda")
