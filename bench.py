@@ -226,10 +226,10 @@ def plumbing_check(args, rank, world, dist, backend):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         ok = bool(t.item() == 1.0)
     if rank == 0:
-        print(json.dumps({"metric": "Mvoxel*views/s (Carve)", "value": None, "unit": "Mvoxel*views/s",
-                          "plumbing_check": True, "ok": ok, "n_gpus": world,
-                          "collective": {"backend": backend, "ranks": world, "bytes_per_rank": nbytes * k,
-                                         "op": "all_gather", "slabs_per_rank": k}}))
+        emit({"metric": "Mvoxel*views/s (Carve)", "value": None, "unit": "Mvoxel*views/s",
+              "plumbing_check": True, "ok": ok, "n_gpus": world,
+              "collective": {"backend": backend, "ranks": world, "bytes_per_rank": nbytes * k,
+                             "op": "all_gather", "slabs_per_rank": k}})
     return 0 if ok else 1
 
 
@@ -243,6 +243,7 @@ def run_inprocess(args, why=None):
     from vacancy_amd.capi import UpdateOption
     from vacancy_amd.sharded import ShardedVoxelCarver
 
+    quiet_stdout()
     n, nv, G = args.grid, args.views, args.gpus
     uo = UpdateOption(voxel_update=1, use_truncation=True, truncation_band=0.1) if args.mode == "tsdf" \
         else UpdateOption()
@@ -311,15 +312,39 @@ def run_inprocess(args, why=None):
                         "slabs_z": [list(sh.z_ranges[s]) for s in range(g, G * k, G)]} for g in range(G)]}
     if why:
         out["config"]["launch_note"] = why
-    print(json.dumps(out))
+    emit(out)
     for g, cs in enumerate(sh.by_device):
         cs[0].free_device(imgs[g])
     sh.close()
     return 0
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """Everything native code prints to fd 1 (RCCL's version banner arrives there when its stdio buffer is flushed
+    at exit, i.e. AFTER the JSON line) goes to stderr instead: stdout carries the ONE JSON line and nothing else."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" in os.environ or args.gpus == 1 or args.launch == "inprocess":
+        quiet_stdout()  # (the self-launching parent only relays its children's output)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         if args.launch == "inprocess" and not args.plumbing_check:
             raise SystemExit(run_inprocess(args))
@@ -721,7 +746,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, views, sdfs, args.cpu_seconds)
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     for p in d_sdf:
         dev.free_device(p)
     for c in reversed(devs):

@@ -238,6 +238,9 @@ __global__ __launch_bounds__(256) void mc_bits_kernel(const float* __restrict__ 
 // predicated by bits it already holds -- whole 64-voxel words of skipped bricks cost no instruction at all.
 // For rows that are whole words (nx == 64 Wr) of an owned slab whose state implies TC == OK.
 constexpr int kBricksMaxNbw = 1024;  // bricks along x (nx <= 8192)
+#ifndef VCY_BRICK_ROWS_IN_FLIGHT
+#define VCY_BRICK_ROWS_IN_FLIGHT 1   // (2 and 4 measured: no difference, the pass is not bound by requests in flight)
+#endif
 
 template <bool ISO_F32>
 __global__ __launch_bounds__(256) void mc_bits_bricks_kernel(const float* __restrict__ sdf, int ny, int nz, int Wr,
@@ -275,36 +278,49 @@ __global__ __launch_bounds__(256) void mc_bits_bricks_kernel(const float* __rest
       word_skip |= (byte == 255u ? 1u : 0u) << k;
       lane_skip |= ((byte >> (lane >> 3)) & 1u) << k;
     }
-    for (int i = 0; i < 16; ++i) {  // this wave's rows of the brick row
-      const int r = wave * 16 + i;
-      const int yy = by * 8 + (r & 7), zz = bz * 8 + (r >> 3);
-      if (yy >= ny || zz >= nz) continue;  // (uniform)
-      const int64_t row = (int64_t)zz * ny + yy;
-      const float* __restrict__ ps = sdf + row * nx + (int64_t)w0 * 64 + lane;
-      float s[16];
+    // this wave's 16 rows of the brick row, kRowsInFlight at a time: the loads of all of them are requested
+    // before the first ballot (one row alone keeps at most 16 x 256 bytes of a wave in flight, a quarter of that
+    // after the skipped bricks)
+    constexpr int kRowsInFlight = VCY_BRICK_ROWS_IN_FLIGHT;
+    for (int i0 = 0; i0 < 16; i0 += kRowsInFlight) {
+      float s[kRowsInFlight][16];
+      int64_t rows[kRowsInFlight];
+      bool valid[kRowsInFlight];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        s[k] = INFINITY;  // outside and valid
-        if (k < nw && !((word_skip >> k) & 1u)) {      // (uniform)
-          if (!((lane_skip >> k) & 1u)) s[k] = __builtin_nontemporal_load(ps + k * 64);
+      for (int q = 0; q < kRowsInFlight; ++q) {
+        const int r = wave * 16 + i0 + q;
+        const int yy = by * 8 + (r & 7), zz = bz * 8 + (r >> 3);
+        valid[q] = yy < ny && zz < nz;  // (uniform)
+        rows[q] = (int64_t)zz * ny + yy;
+        const float* __restrict__ ps = sdf + rows[q] * nx + (int64_t)w0 * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          s[q][k] = INFINITY;  // outside and valid
+          if (valid[q] && k < nw && !((word_skip >> k) & 1u)) {      // (uniform)
+            if (!((lane_skip >> k) & 1u)) s[q][k] = __builtin_nontemporal_load(ps + k * 64);
+          }
         }
       }
-      u64 m_in = 0, m_ok = ~0ull;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        if (k < nw && !((word_skip >> k) & 1u)) {      // (uniform)
-          const u64 a = __ballot(ISO_F32 ? s[k] < (float)iso : (double)s[k] < iso);
-          const u64 b = __ballot(s[k] != kInvalidSdf);
-          const bool mine = lane == k;
-          m_in = mine ? a : m_in;
-          m_ok = mine ? b : m_ok;
+      for (int q = 0; q < kRowsInFlight; ++q) {
+        if (!valid[q]) continue;
+        u64 m_in = 0, m_ok = ~0ull;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          if (k < nw && !((word_skip >> k) & 1u)) {      // (uniform)
+            const u64 a = __ballot(ISO_F32 ? s[q][k] < (float)iso : (double)s[q][k] < iso);
+            const u64 b = __ballot(s[q][k] != kInvalidSdf);
+            const bool mine = lane == k;
+            m_in = mine ? a : m_in;
+            m_ok = mine ? b : m_ok;
+          }
         }
-      }
-      if (lane < nw) {
-        const int64_t o = row * Wr + w0 + lane;
-        in[o] = m_in;
-        ok[o] = m_ok;
-        if (tc != nullptr) tc[o] = m_ok;
+        if (lane < nw) {
+          const int64_t o = rows[q] * Wr + w0 + lane;
+          in[o] = m_in;
+          ok[o] = m_ok;
+          if (tc != nullptr) tc[o] = m_ok;
+        }
       }
     }
   }
