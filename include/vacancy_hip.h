@@ -276,6 +276,8 @@ int vcy_reset(vcy_ctx* ctx);
  * "livelist" (default 1): a carve launch of up to 8 views over an already carved grid first lists the workgroups in
  * which some view can still change a voxel (bounds of the views' samples against the kept brick minima / the
  * truncation limit) and starts only those; 0 starts every workgroup and lets each decide for itself.
+ * "carvetimer" (default 0): 1 records HIP events around the pre-pass and the carve kernel of every fused launch
+ * (vcy_last_carve_ms).
  * "inject_carve_failure" (test hook, default 0): the next `value` applications of views fail with
  * VCY_ERR_INTERNAL before anything is launched -- how the tests exercise the error contract of vcy_carve. */
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
