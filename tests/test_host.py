@@ -187,3 +187,46 @@ def test_public_headers_compile_in_their_eigen_form():
                         os.path.join(root, "tests", "eigen_decl", "use_public_headers.cc")],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_run_loops_of_the_fused_kernel_fetch_their_tables_through_scalar_loads():
+    """A guard against a compiler trap that cost round 3 15 %: a wave-uniform value first computed inside a divergent
+    branch reaches later uses through a phi the compiler must treat as divergent -- it then lives in a VGPR, the
+    address of the per-view x tables with it, and the 24 scalar loads of every run loop become vector loads followed
+    by vmcnt(0) waits.  Compiles the bench instantiations of carve_fused_kernel to assembly (no GPU needed) and checks
+    every run-loop block (>= 8 ds_read2_b32): at most one vector load (the generic fallback's), none in the fast loops."""
+    import shutil
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    assert os.path.exists(hipcc), "hipcc is part of the image"
+    src = os.path.join(root, "vacancy_amd", "csrc")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "fused.s")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                            "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
+                            "-fno-slp-vectorize", "-DVCY_DEV_BENCH_KERNELS_ONLY", "-I", os.path.join(root, "include"),
+                            "-I", src, "-S", "--cuda-device-only", "-o", out, os.path.join(src, "carve_fused.hip")],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        txt = open(out).read()
+    kernels = list(re.finditer(r"^(_ZN3vcy12_GLOBAL__N_118carve_fused_kernelI\w+):", txt, re.M))
+    assert len(kernels) >= 4
+    fast_blocks = 0
+    for m in kernels:
+        body = txt[m.end():txt.index(".Lfunc_end", m.end())]
+        block = []
+        for line in body.split("\n") + [".LBB_end:"]:
+            if re.match(r"^\.LBB\w+:", line):
+                ins = [x.strip() for x in block if x.startswith("\t") and not x.strip().startswith((";", "."))]
+                if sum(i.startswith("ds_read2_b32") for i in ins) >= 8:
+                    gload = sum(i.startswith("global_load") for i in ins)
+                    assert gload <= 1, (m.group(1)[:80], gload)
+                    if gload == 0:
+                        fast_blocks += 1
+                        assert sum(i.startswith("s_load") for i in ins) >= 3, m.group(1)[:80]
+                block = []
+            else:
+                block.append(line)
+    assert fast_blocks >= 8

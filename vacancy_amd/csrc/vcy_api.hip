@@ -155,6 +155,17 @@ static int dims_from_option(const float bb_min[3], const float bb_max[3], float 
 
 using namespace vcy;
 
+namespace {
+std::mutex g_ctx_count_mutex;
+int g_ctx_count = 0;
+// idle page-locked mesh buffers are only worth keeping while a context may extract again
+void mesh_pool_trim() {
+  std::lock_guard<std::mutex> lock(g_mesh_mutex);
+  for (const HostBuf& b : g_mesh_idle) (void)hipHostFree(b.p);
+  g_mesh_idle.clear();
+}
+}  // namespace
+
 extern "C" {
 
 const char* vcy_last_error(void) { return g_last_error.c_str(); }
@@ -292,12 +303,22 @@ int vcy_create(const vcy_carver_option* o, int device_id, int z_begin, int z_end
   if (rc != VCY_OK) return fail(rc);
   VCY_TRY(hipStreamSynchronize(c->stream));
 #undef VCY_TRY
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_count_mutex);
+    ++g_ctx_count;
+    c->counted = true;
+  }
   *out = c;
   return VCY_OK;
 }
 
+
 void vcy_destroy(vcy_ctx* c) {
   if (!c) return;
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_count_mutex);
+    if (c->counted && --g_ctx_count == 0) mesh_pool_trim();
+  }
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   (void)hipFree(c->d_sdf);
@@ -1213,6 +1234,7 @@ int vcy_extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   const auto t0 = std::chrono::steady_clock::now();
   { int rcm = materialize(c); if (rcm != VCY_OK) return rcm; }
   const int rc = extract_iso(c, iso, linear_interp, out);
+  if (rc != VCY_OK) vcy_mesh_free(out);  // (whatever host arrays a failed extraction had already taken from the pool)
   c->last_extract_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return rc;
 }

@@ -43,6 +43,7 @@ constexpr float kInvalidSdf = -3.402823466e+38f;
 // reference, Voxel::on_surface belongs to ExtractVoxel (host).
 struct vcy_ctx {
   int device = 0;
+  bool counted = false;               // registered in the process-wide context count (vcy_create succeeded)
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
