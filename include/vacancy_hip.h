@@ -276,6 +276,8 @@ int vcy_reset(vcy_ctx* ctx);
  * "livelist" (default 1): a carve launch of up to 8 views over an already carved grid first lists the workgroups in
  * which some view can still change a voxel (bounds of the views' samples against the kept brick minima / the
  * truncation limit) and starts only those; 0 starts every workgroup and lets each decide for itself.
+ * "recordbytes" (default 0 = 1 GiB): bytes of footprint records one carve launch may take; a larger launch is cut into
+ * chunks of whole brick layers (2048^3 x 64 views: nine).  Small values let tests run the chunking on small grids.
  * "carvetimer" (default 0): 1 records HIP events around the pre-pass and the carve kernel of every fused launch
  * (vcy_last_carve_ms).
  * "inject_carve_failure" (test hook, default 0): the next `value` applications of views fail with

@@ -4,7 +4,7 @@ minima before any state is read, live-workgroup list on / off, several chunks of
 in between (bricks outside the surface skipped: "mcskip" 1, against 0 and against the oracle at random iso
 levels) and writes that bypass the fused kernel (vcy_upload, the per-view kernel).  State against the oracle bit
 for bit after every group, as one context and as two z-slab contexts.
-usage: python tests/fuzz/fuzz_incremental.py FIRST_SEED LAST_SEED   (round 3: seeds 0..600 on the final kernels: 0 mismatches)"""
+usage: python tests/fuzz/fuzz_incremental.py FIRST_SEED LAST_SEED   (round 3: seeds 0..520, 1 560 contexts, chunked launches mixed in from 400 on, final kernels: 0 mismatches)"""
 import sys, os, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -77,6 +77,7 @@ for seed in range(lo, hi):
         dev = vc.VoxelCarver(opt, z_range=zr) if zr else vc.VoxelCarver(opt)
         assert dev.Init()
         dev.set_param("defer", int(rng.randint(0, 2)))
+        dev.set_param("recordbytes", int(rng.choice([0, 0, 3000, 20000])))  # chunks of a few brick layers
         orc = O.OracleGrid(opt)
         n_xy = orc.dims[0] * orc.dims[1]
         sl = slice(None) if zr is None else slice(zr[0] * n_xy, zr[1] * n_xy)

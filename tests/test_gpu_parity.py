@@ -902,9 +902,10 @@ def test_failed_flush_is_reported_once_to_the_carve_loop():
     assert_state_equal(dev, orc, "after injected failures")
 
 
-@pytest.mark.parametrize("kw,livelist", [(dict(), 1), (dict(), 0), (dict(use_truncation=True, truncation_band=0.1), 1),
-                                         (dict(voxel_update=1, use_truncation=True, truncation_band=0.1), 1)])
-def test_single_view_launches_with_brick_minima(kw, livelist):
+@pytest.mark.parametrize("kw,livelist,recordbytes",
+                         [(dict(), 1, 0), (dict(), 0, 0), (dict(), 1, 2000), (dict(use_truncation=True, truncation_band=0.1), 1, 0),
+                          (dict(voxel_update=1, use_truncation=True, truncation_band=0.1), 1, 0)])
+def test_single_view_launches_with_brick_minima(kw, livelist, recordbytes):
     """The reference's call pattern (examples.cc:117-149): carve ONE view, extract, carve the next ... With
     `defer` 0 every call is a launch of its own; from the second on a wave whose view provably changes nothing
     (bound against the brick minimum the previous launch left, or below the truncation limit) returns without
@@ -920,6 +921,7 @@ def test_single_view_launches_with_brick_minima(kw, livelist):
     assert dev.Init(), vc.last_error()
     dev.set_param("defer", 0)
     dev.set_param("livelist", livelist)  # 1: only the workgroups with a live (brick, view) pair are started
+    dev.set_param("recordbytes", recordbytes)  # 2000: every launch in chunks of three brick layers (as 2048^3 x 64 is)
     orc = O.OracleGrid(opt)
     base = O.make_sdf(masks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
     for i in range(nv):

@@ -1425,12 +1425,22 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
         for (int k = 0; k < WX; ++k) changed = changed || (int)n[k] != (int)cv[k];
       }
       if (changed) {
+#ifdef VCY_FLOOR_DUMMY_STORES  // development build: the same store instructions, all into 64 rows of ONE brick row (never reach HBM)
+        const int64_t row0_ = ((int64_t)(lane >> 3) * g.ny + (lane & 7)) * g.nx;
+        const int x_first_ = (x_first & 1023);
+#define row0 row0_
+#define x_first x_first_
+#endif
         *(float4*)(g.sdf + row0 + x_first) = make_float4(s[0], s[1], s[2], s[3]);
         *(float4*)(g.sdf + row0 + x_first + 4) = make_float4(s[4], s[5], s[6], s[7]);
         CountVec cv;
 #pragma unroll
         for (int k = 0; k < WX; ++k) cv[k] = (CountT)n[k];
         *(CountVec*)(cnt + row0 + x_first) = cv;
+#ifdef VCY_FLOOR_DUMMY_STORES
+#undef row0
+#undef x_first
+#endif
       }
     } else {
 #pragma unroll
@@ -1763,7 +1773,8 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   int chunk_layers = nbz;
   if (!big) {
     const int64_t per_layer = layer_bricks * n_views * (int64_t)sizeof(FootprintRecord);
-    chunk_layers = (int)std::max<int64_t>(1, std::min<int64_t>(nbz, kRecordBytesMax / std::max<int64_t>(per_layer, 1)));
+    const int64_t cap = c->record_bytes_max > 0 ? c->record_bytes_max : kRecordBytesMax;  // ("recordbytes": tests force several chunks)
+    chunk_layers = (int)std::max<int64_t>(1, std::min<int64_t>(nbz, cap / std::max<int64_t>(per_layer, 1)));
     const size_t need = (size_t)(per_layer * chunk_layers);
     if (c->records_bytes < need) {
       VCY_HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -425,6 +425,10 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
     }
     return VCY_OK;
   }
+  if (std::strcmp(name, "recordbytes") == 0) {
+    c->record_bytes_max = value > 0 ? value : 0;
+    return VCY_OK;
+  }
   if (std::strcmp(name, "livelist") == 0) {
     c->use_live_list = value != 0;
     return VCY_OK;

@@ -110,6 +110,7 @@ struct vcy_ctx {
   int* h_live_hint = nullptr;         // page-locked {live workgroups, workgroups} of the last listed launch (a hint, see launch_carve_fused)
   int64_t live_list_age = 0;
   bool use_live_list = true;          // vcy_set_param("livelist", 0): every workgroup is launched and decides for itself
+  int64_t record_bytes_max = 0;       // vcy_set_param("recordbytes", n): footprint records per launch chunk (0: 1 GiB)
   void* d_records = nullptr;          // footprint records of one fused launch, 8 bytes per (wave brick, view)
   size_t records_bytes = 0;
   float* d_wmax = nullptr;            // window-maximum planes of the views of one fused launch
