@@ -38,6 +38,10 @@ fi
 # N GPUs from one process (threads + vcy_halo_allgather): two "GPUs" on this one device
 VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --launch inprocess --steps 5 --warmup 1 > "$O/bench_inprocess_2x_one_device.json" 2> "$O/bench_inprocess_2x_one_device.err"
 echo "in-process 2 x one device rc=$?" >> "$O/status.txt"
+# --launch auto (the default): torch.distributed.run first; RCCL refuses two ranks on one device, so the parent falls
+# back to the in-process form and says so in config.launch_note
+VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --steps 5 --warmup 1 --no-mc > "$O/bench_auto_fallback_2x_one_device.json" 2> "$O/bench_auto_fallback_2x_one_device.err"
+echo "launch auto -> in-process fallback rc=$?" >> "$O/status.txt"
 # phase breakdown of the fused kernel (development build with s_memtime marks)
 if [ -f build/variants/phase/libvacancy_hip.so ]; then
   VCY_HIP_LIB=build/variants/phase/libvacancy_hip.so python profiles/tools/phase_timing.py > "$O/phase_timing.log" 2>&1
