@@ -919,8 +919,21 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     if (b >= wg_list[0]) return;
     b = wg_list[1 + b];
   } else {
+#ifndef VCY_XCD_CONTIGUOUS
+    // ... and those eighths must cost the same.  A contiguous eighth of the brick list is a z-slab, and with view
+    // dropping the slabs through the object cost 1.6x the outer ones: six XCDs would wait for two.  So every XCD
+    // gets whole brick LAYERS, dealt cyclically -- layers xcd, xcd + 8, xcd + 16 ... -- and walks each of them in
+    // (y, x) order: neighbours in x and y still share footprint pixels in that XCD's L2, every XCD sees the same mix
+    // of empty and busy regions.  (The layers beyond a multiple of eight go round-robin as they come.)
+    const int layer = nbx * nby, nlayers = (int)gridDim.x / layer, full = (nlayers >> 3) * layer;
+    if (b < full * 8) {
+      const int xcd = b & 7, j = b >> 3;
+      b = ((j / layer) * 8 + xcd) * layer + j % layer;
+    }
+#else
     const int nb = gridDim.x, per = nb >> 3;
     if (b < per * 8) b = (b & 7) * per + (b >> 3);
+#endif
   }
   const int bx = b % nbx;
   b /= nbx;
