@@ -516,6 +516,8 @@ def main():
     launches_per_step = ((nv + views_per_launch - 1) // views_per_launch) * len(devs)
     n_rec = len(kernel_ms)
     avg_launch_ms = sum(kernel_only[:n_rec]) / n_rec / launches_per_step  # the dominant kernel alone, HIP events
+    if avg_launch_ms <= 0.0:  # (a library without the carve timer, e.g. an older kernel linked in for an A/B run)
+        avg_launch_ms = sum(kernel_ms) / n_rec / launches_per_step
     avg_step_device_ms = sum(kernel_ms) / n_rec
     avg_prepass_ms = sum(prepass_only[:n_rec]) / n_rec
     alg_bytes = slab_vox * views_per_launch * bytes_per_vv(args.mode, uo)
