@@ -4,7 +4,7 @@ minima before any state is read, live-workgroup list on / off, several chunks of
 in between (bricks outside the surface skipped: "mcskip" 1, against 0 and against the oracle at random iso
 levels) and writes that bypass the fused kernel (vcy_upload, the per-view kernel).  State against the oracle bit
 for bit after every group, as one context and as two z-slab contexts.
-usage: python tests/fuzz/fuzz_incremental.py FIRST_SEED LAST_SEED   (round 3: seeds 0..520, 1 560 contexts, chunked launches mixed in from 400 on, final kernels: 0 mismatches)"""
+usage: python tests/fuzz/fuzz_incremental.py FIRST_SEED LAST_SEED [modes]   (round 3: seeds 0..520, 1 560 contexts, chunked launches mixed in from 400 on, and 1000..1150 with the extra modes: 0 mismatches)"""
 import sys, os, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -38,8 +38,13 @@ for seed in range(lo, hi):
     half = dims / 2.0
     bb_min = (centre - half).astype(np.float32)
     bb_max = (bb_min + np.float32(1.0) * dims + np.float32(0.25)).astype(np.float32)
+    rng2 = np.random.RandomState(19000 + seed)  # (its own stream: the scenes of a seed stay what they were)
+    extra = len(sys.argv) > 3 and sys.argv[3] == "modes"  # also nearest neighbour, weights != 1, update limits in reach
     uo = UpdateOption(voxel_update=int(rng.randint(0, 2)), update_outside=int(rng.randint(0, 2)),
-                      use_truncation=bool(rng.randint(0, 2)), truncation_band=float(rng.choice([0.1, 0.35])))
+                      use_truncation=bool(rng.randint(0, 2)), truncation_band=float(rng.choice([0.1, 0.35])),
+                      sdf_interp=int(rng2.randint(0, 2)) if extra else 1,
+                      voxel_update_weight=float(rng2.choice([1.0, 1.0, 0.5, 2.25])) if extra else 1.0,
+                      voxel_max_update_num=int(rng2.choice([255, 255, 3, 6, 1000])) if extra else 255)
     opt = CarverOption(bb_min=[float(x) for x in bb_min], bb_max=[float(x) for x in bb_max], resolution=1.0, update_option=uo)
     nviews = int(rng.randint(6, 16))
     extent = float(np.linalg.norm(half))
