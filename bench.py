@@ -18,6 +18,7 @@ Prints ONE JSON line (rank 0).  value = whole-job Mvoxel*views/s.  The marching-
 (Mcells/s) is measured after the timed region and reported in the same line under "mc".
 """
 import argparse
+import datetime
 import ctypes as C
 import json
 import os
@@ -375,7 +376,8 @@ def main():
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                        timeout=datetime.timedelta(seconds=300))
                 probe = torch.ones(1, device="cuda")
                 dist.all_reduce(probe)  # fail here, on every rank alike, rather than mid-benchmark
                 torch.cuda.synchronize()
