@@ -52,7 +52,7 @@ def parse(argv=None):
     ap.add_argument("--cull", type=int, default=1,
                     help="1: drop (brick, view) pairs that provably cannot change the brick (results identical)")
     ap.add_argument("--slabs-per-gpu", type=int, default=0,
-                    help="z-slabs per GPU, dealt cyclically (0: 1 on one GPU, 2 on several -- evens out "
+                    help="z-slabs per GPU, dealt cyclically (0: 1 on one or two GPUs, 2 on more -- evens out "
                          "the data-dependent cost of view dropping)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
@@ -92,6 +92,15 @@ def self_launch(args):
     env.setdefault("OMP_NUM_THREADS", "1")
     env["VCY_BENCH_SELF_LAUNCHED"] = "1"  # a failing nccl backend is then handled by this parent (main)
     return subprocess.call(cmd, env=env)
+
+
+def default_slabs_per_gpu(n_gpus):
+    """z-slabs per GPU, dealt cyclically.  Two halves of a grid cost the same, so 2 GPUs take one slab each; from 4
+    GPUs on the slabs through the object cost 1.6x the outer ones (view dropping) and every GPU pairs an outer with a
+    central slab.  Measured slab by slab on one GPU (profiles/r03/slab_emulation.txt): 2 GPUs 1.83x (k = 1) against
+    1.71x (k = 2); 4 GPUs 3.02x / 3.23x; 8 GPUs 5.50x / 6.14x; 4 slabs per GPU are behind everywhere (every launch
+    costs about 0.1 ms of window maxima, gaps and ramp)."""
+    return 1 if n_gpus <= 2 else 2
 
 
 def usable_cores():
@@ -210,7 +219,7 @@ def plumbing_check(args, rank, world, dist, backend):
     import torch
     from vacancy_amd import dist as vdist
     n = args.grid
-    k = args.slabs_per_gpu if args.slabs_per_gpu > 0 else (1 if world == 1 else 2)
+    k = args.slabs_per_gpu if args.slabs_per_gpu > 0 else default_slabs_per_gpu(world)
     nbytes = 2 * n * n * 6  # two xy slices of (f32 sdf, u16 update_num)
     slabs = vdist.slabs_of_rank(n, rank, world, k)
     send = torch.from_numpy(np.concatenate([np.full(nbytes, s % 251, np.uint8) for s, _, _ in slabs]))
@@ -254,7 +263,7 @@ def run_inprocess(args, why=None):
     devices = list(range(G))
     if "VCY_BENCH_FORCE_DEVICE" in os.environ:  # several "GPUs" on one device (boxes with a single GPU)
         devices = [int(os.environ["VCY_BENCH_FORCE_DEVICE"])] * G
-    k = args.slabs_per_gpu if args.slabs_per_gpu > 0 else 2
+    k = args.slabs_per_gpu if args.slabs_per_gpu > 0 else default_slabs_per_gpu(G)
     sh = ShardedVoxelCarver(opt, devices, k)
     if not sh.Init():
         raise SystemExit("vcy_create failed: " + vc.last_error())
@@ -432,7 +441,7 @@ def main():
     sdf0 = vc.make_sdf(masks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
     sdfs = [sdf0] * nv  # every view sees the same centred disc; the cameras differ
 
-    k_slabs = args.slabs_per_gpu if args.slabs_per_gpu > 0 else (1 if world == 1 else 2)
+    k_slabs = args.slabs_per_gpu if args.slabs_per_gpu > 0 else default_slabs_per_gpu(world)
     my_slabs = vdist.slabs_of_rank(n, rank, world, k_slabs)
 
     def make_carvers(option, cull, slabs):

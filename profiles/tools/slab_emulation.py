@@ -19,7 +19,7 @@ def time_slab(z0, z1):
 t1, w1 = time_slab(0, n)
 print("1 GPU: %.3f ms (wall %.3f)" % (t1, w1))
 for G in (2, 4, 8):
-    for k in (1, 2):
+    for k in (1, 2, 4):
         per_rank = []
         for r in range(G):
             tot = 0.0; wtot = 0.0

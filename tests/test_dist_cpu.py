@@ -130,7 +130,7 @@ def _run_bench(extra, env_extra=None, timeout=300):
 def test_bench_self_launches_two_ranks_and_records_the_collective():
     """Without WORLD_SIZE, --gpus 2 re-executes under torch.distributed.run (one process per rank); the
     plumbing check runs the configuration's halo all-gather over gloo with rank-stamped buffers."""
-    rc, line, err = _run_bench(["--gpus", "2", "--plumbing-check", "--grid", "64"])
+    rc, line, err = _run_bench(["--gpus", "2", "--plumbing-check", "--grid", "64", "--slabs-per-gpu", "2"])
     assert rc == 0, err[-2000:]
     assert line is not None and line["plumbing_check"] and line["ok"]
     assert line["n_gpus"] == 2
