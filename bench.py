@@ -450,8 +450,8 @@ def main():
             c = vc.VoxelCarver(option, device_id=local_rank, z_range=(z0, z1))
             if not c.Init():
                 raise SystemExit("vcy_create failed: " + vc.last_error())
-            if out:
-                c.use_stream_of(out[0])  # one stream per GPU: slabs run back to back
+            # (every slab on a stream of its own: the second slab's launch fills the tail of the first one's,
+            # 0-5 % per step on a rank's two slabs, profiles/r03/two_slabs_streams.txt)
             c.set_param("fused", args.batch)
             c.set_param("cull", cull)
             c.set_param("carvetimer", 1)  # HIP events around the carve kernel itself (vcy_last_carve_ms)
@@ -463,7 +463,8 @@ def main():
     d_sdf = [dev.upload_sdf(s) for s in sdfs]  # inputs resident in HBM before the timed region
 
     def barrier():
-        dev.sync()
+        for c in devs:
+            c.sync()
         if dist is not None:
             if backend == "nccl":
                 torch.cuda.synchronize()
@@ -474,9 +475,18 @@ def main():
         for _ in range(count):
             for c in carvers:
                 c.reset()
-            lead.timer_begin()
-            ok = all(c.CarveBatchDevice(batch) for c in carvers)
-            ms = lead.timer_end()
+            if len(carvers) == 1:
+                lead.timer_begin()
+                ok = lead.CarveBatchDevice(batch)
+                ms = lead.timer_end()
+            else:  # several streams: the step is over when the last of them is
+                for c in carvers:
+                    c.sync()
+                t_step = time.perf_counter()
+                ok = all(c.CarveBatchDevice(batch) for c in carvers)
+                for c in carvers:
+                    c.sync()
+                ms = (time.perf_counter() - t_step) * 1e3
             if not ok:
                 raise SystemExit("carve failed: " + vc.last_error())
             if record is not None:

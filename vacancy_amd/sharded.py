@@ -58,9 +58,7 @@ class ShardedVoxelCarver:
             if not c.Init():
                 self.close()
                 return False
-            lead = self.by_device[s % g][0] if self.by_device[s % g] else None
-            if lead is not None and hasattr(c, "use_stream_of"):
-                c.use_stream_of(lead)  # one stream per device: its slabs run back to back
+            # (every slab keeps its own stream: a device's second slab fills the tail of its first one's launch)
             self.slabs.append(c)
             self.by_device[s % g].append(c)
             self.z_ranges.append((z0, z1))
@@ -104,8 +102,8 @@ class ShardedVoxelCarver:
         self._per_device(lambda i, cs: [c.sync() for c in cs])
 
     # -- Carve(vector<Camera>, ...) loop (voxel_carver.cc:516-528): `batches[g]` = prepare_batch(...) with the
-    # images resident on device g.  Returns the wall time of the slowest device in ms; per-device kernel times
-    # (HIP events on each device's stream) are left in last_kernel_ms.
+    # images resident on device g.  Returns the wall time of the slowest device in ms; per-device step times (HIP
+    # events for a single slab, launch-to-sync wall time for several streams) are left in last_kernel_ms.
     def carve_batch(self, batches, steps=1, reset=True):
         barrier = threading.Barrier(len(self.by_device))
         walls = [0.0] * len(self.by_device)
@@ -121,9 +119,16 @@ class ShardedVoxelCarver:
                 if reset:
                     for c in cs:
                         c.reset()
-                lead.timer_begin()
-                ok = all(c.CarveBatchDevice(batches[i]) for c in cs)
-                kernel[i] += lead.timer_end()
+                if len(cs) == 1:
+                    lead.timer_begin()
+                    ok = lead.CarveBatchDevice(batches[i])
+                    kernel[i] += lead.timer_end()
+                else:  # several streams: the step is over when the last of them is
+                    t_step = time.perf_counter()
+                    ok = all(c.CarveBatchDevice(batches[i]) for c in cs)
+                    for c in cs:
+                        c.sync()
+                    kernel[i] += (time.perf_counter() - t_step) * 1e3
                 if not ok:
                     raise RuntimeError("carve failed on device %d" % self.devices[i])
             for c in cs:
