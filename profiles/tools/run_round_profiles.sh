@@ -36,11 +36,11 @@ if [ -f build/variants/floorTS/libvacancy_hip.so ]; then
   python profiles/tools/summarize_floor.py "$O/issue_floor.txt" "$CTR"
 fi
 # N GPUs from one process (threads + vcy_halo_allgather): two "GPUs" on this one device
-VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --launch inprocess --steps 5 --warmup 1 > "$O/bench_inprocess_2x_one_device.json" 2> "$O/bench_inprocess_2x_one_device.err"
+VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --launch inprocess --slabs-per-gpu 2 --steps 5 --warmup 1 > "$O/bench_inprocess_2x_one_device.json" 2> "$O/bench_inprocess_2x_one_device.err"
 echo "in-process 2 x one device rc=$?" >> "$O/status.txt"
 # --launch auto (the default): torch.distributed.run first; RCCL refuses two ranks on one device, so the parent falls
 # back to the in-process form and says so in config.launch_note
-VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --steps 5 --warmup 1 --no-mc > "$O/bench_auto_fallback_2x_one_device.json" 2> "$O/bench_auto_fallback_2x_one_device.err"
+VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --slabs-per-gpu 2 --steps 5 --warmup 1 --no-mc > "$O/bench_auto_fallback_2x_one_device.json" 2> "$O/bench_auto_fallback_2x_one_device.err"
 echo "launch auto -> in-process fallback rc=$?" >> "$O/status.txt"
 # phase breakdown of the fused kernel (development build with s_memtime marks)
 if [ -f build/variants/phase/libvacancy_hip.so ]; then
@@ -49,7 +49,7 @@ if [ -f build/variants/phase/libvacancy_hip.so ]; then
 fi
 # the multi-rank path of bench.py on this one device: 2 ranks, 2 slabs each, halo exchange over gloo (RCCL refuses
 # two ranks on one device; --allow-gloo is the documented escape for exactly this check)
-VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --launch torchrun --steps 3 --warmup 1 --no-cpu-baseline --no-variants --allow-gloo > "$O/bench_2ranks_one_device_gloo.json" 2> "$O/bench_2ranks_one_device_gloo.err"
+VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --launch torchrun --slabs-per-gpu 2 --steps 3 --warmup 1 --no-cpu-baseline --no-variants --allow-gloo > "$O/bench_2ranks_one_device_gloo.json" 2> "$O/bench_2ranks_one_device_gloo.err"
 echo "2 ranks (gloo) rc=$?" >> "$O/status.txt"
 VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --launch torchrun --steps 3 --warmup 1 --no-cpu-baseline --no-variants > "$O/bench_2ranks_one_device_rccl.json" 2> "$O/bench_2ranks_one_device_rccl.err"
 echo "2 ranks (rccl on one device, expected to be refused) rc=$?" >> "$O/status.txt"
