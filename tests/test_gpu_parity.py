@@ -569,6 +569,16 @@ def test_native_rccl_halo_allgather_equals_host_exchange():
     # a second exchange reuses the cached communicator
     calls = lambda text: int([kv for kv in text.split() if kv.startswith("calls=")][0][6:])
     assert calls(vc.halo_allgather(a)) == calls(info) + 1
+    # vcy_halo_shutdown releases communicators, streams and staging; the next exchange builds them again and
+    # installs the same halos (halo_exchange: the record bench.py prints, with what an all-gather moves)
+    from vacancy_amd import capi
+    capi.load().vcy_halo_shutdown()
+    rec = vc.halo_exchange(a)
+    assert rec["backend"].startswith("rccl") and rec["ranks"] == 1 and rec["slabs"] == world
+    assert rec["bytes_received_per_rank"] == rec["bytes_per_rank"] * rec["ranks"]
+    assert rec["bytes_needed_per_slab"] == 2 * n * n * 6
+    for ca, cb in zip(a, b):
+        assert_mesh_equal(ca.ExtractIsoSurface(0.0, True), cb.ExtractIsoSurface(0.0, True), "after shutdown")
 
 
 def test_torch_shares_device_memory_with_the_library():
