@@ -230,8 +230,11 @@ int vcy_halo_copy_from(vcy_ctx* ctx, vcy_ctx* below);
  * process.  Every slab's pack goes into its device's send buffer, ONE ncclAllGather (one communicator
  * rank per distinct device, ncclCommInitAll; communicators and staging are cached per device list)
  * hands every device every pack, and each slab installs the pack of the slab below it.  librccl.so is
- * opened on first use; VCY_ERR_UNSUPPORTED if it cannot be loaded -- there is no silent fallback to
- * peer copies (vcy_halo_copy_from is the explicit alternative). */
+ * opened on first use; VCY_ERR_UNSUPPORTED if it cannot be loaded -- THIS function never falls back to
+ * peer copies.  vcy_halo_copy_from is the explicit alternative, and the host layers above take it on exactly
+ * that status only where they say so: Python's vacancy_amd.carver.halo_exchange (used by ShardedVoxelCarver and
+ * dist.exchange_halo) then copies slab by slab and returns "backend": "peer copies ..."; the C++
+ * ShardedVoxelCarver never does it on its own (set_halo_transport(kPeerCopy) asks for it). */
 int vcy_halo_allgather(vcy_ctx* const* slabs, int n_slabs);
 /* Releases what vcy_halo_allgather keeps between calls (communicators, streams and staging buffers per
  * device set); the next exchange builds them again.  Call when no exchange is in flight. */

@@ -960,7 +960,7 @@ def test_single_view_launches_with_brick_minima(kw, livelist, recordbytes):
                 om = orc.marching_cubes(iso, True)
                 assert_mesh_equal(m1, om, "%s view %d iso %g (bricks skipped)" % (kw, i, iso))
                 assert_mesh_equal(m0, om, "%s view %d iso %g (every brick read)" % (kw, i, iso))
-        if i == 4:  # the per-view kernel does not keep the minima; the next fused launch rebuilds them
+        if i == 4:  # the per-view kernel does not keep the minima; the next fused launch restarts them from lowest()
             dev.set_param("fused", 0)
             assert dev.Carve(views[0], base), vc.last_error()
             orc.carve(views[0], base)
@@ -972,3 +972,47 @@ def test_single_view_launches_with_brick_minima(kw, livelist, recordbytes):
             dev.upload(s2, du)
             orc.upload(s2, du)
             assert dev.get_param("brick_min_valid") == 0
+
+
+@pytest.mark.parametrize("kw", [dict(voxel_update=1, use_truncation=True, truncation_band=0.1),
+                                dict(use_truncation=True, truncation_band=0.1)])
+def test_brick_minima_after_writes_that_bypass_the_fused_kernel(kw):
+    """A fused launch does not rewrite every brick minimum: a wave whose views all lie below the truncation limit
+    returns before it has read anything, a workgroup left off the live list never starts.  After the per-view kernel
+    ("fused" 0) has changed the state the old minima are stale -- and on a slab whose first write was the per-view
+    kernel the array has never been written at all -- so the next fused launch must start every entry from lowest()
+    ("may hold an untouched voxel": never drops a view, never lets marching cubes skip the brick).  The sequence of
+    the round-3 advisor finding: fused launches, a per-view launch that pulls values below the iso level, a fused
+    truncation launch in which EVERY wave returns early, then extraction and further carving against the oracle."""
+    n, nv, w, h = 72, 8, 200, 150
+    uo = UpdateOption(**kw)
+    opt = synth.sphere_option(n, uo)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    base = O.make_sdf(masks[0], use_truncation=True, band=uo.truncation_band)
+    low = np.maximum(base - np.float32(0.9), np.float32(-1.0)).astype(np.float32)  # valid samples far below the iso level
+    nothing = np.full_like(base, -2.0)                                             # every sample < -1: no voxel changes
+    for first_fused in (True, False):
+        dev = vc.VoxelCarver(opt)
+        assert dev.Init(), vc.last_error()
+        dev.set_param("defer", 0)
+        orc = O.OracleGrid(opt)
+        steps = []
+        if first_fused:
+            steps += [(1, views[i], base) for i in range(3)]      # minima valid
+        steps += [(0, views[3], low), (0, views[4], base)]        # per-view kernel: the minima know nothing of these
+        steps += [(1, views[5], nothing)]                         # fused: every wave returns early / no workgroup is live
+        for fused, view, img in steps:
+            dev.set_param("fused", fused)
+            assert dev.Carve(view, img), vc.last_error()
+            orc.carve(view, img)
+        assert_state_equal(dev, orc, "%s first_fused=%s" % (kw, first_fused))
+        for iso in (0.0, -0.25, 0.3):
+            assert_mesh_equal(dev.ExtractIsoSurface(iso, True), orc.marching_cubes(iso, True),
+                              "%s first_fused=%s iso %g" % (kw, first_fused, iso))
+        # ... and the minima left behind must not drop views that still change something (kMax: `ub <= smin`)
+        for i in (6, 7, 0):
+            assert dev.Carve(views[i], base), vc.last_error()
+            orc.carve(views[i], base)
+        assert_state_equal(dev, orc, "%s first_fused=%s, later views" % (kw, first_fused))
+        assert_mesh_equal(dev.ExtractIsoSurface(0.0, True), orc.marching_cubes(0.0, True), "%s later" % (kw,))
+        dev.close()

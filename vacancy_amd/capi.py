@@ -10,6 +10,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VCY_HIP_LIB: another build of the same library (kernel variants under development, profiles/tools/build_variant.sh)
 LIB_PATH = os.environ.get("VCY_HIP_LIB") or os.path.join(_HERE, "csrc", "libvacancy_hip.so")
 
+# vcy_status (include/vacancy_hip.h)
+VCY_OK, VCY_ERR_INVALID_ARG, VCY_ERR_NOT_INITIALIZED, VCY_ERR_TOO_MANY_VOXELS = 0, -1, -2, -3
+VCY_ERR_HIP, VCY_ERR_NO_DEVICE, VCY_ERR_UNSUPPORTED, VCY_ERR_INTERNAL = -4, -5, -6, -7
 VCY_UPDATE_MAX, VCY_UPDATE_WEIGHTED_AVERAGE = 0, 1
 VCY_INTERP_NN, VCY_INTERP_BILINEAR = 0, 1
 VCY_OUTSIDE_NONE, VCY_OUTSIDE_MAX = 0, 1

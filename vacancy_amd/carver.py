@@ -321,7 +321,7 @@ def halo_exchange(carvers):
     try:
         text = halo_allgather(carvers)
     except RuntimeError as e:
-        if getattr(e, "rc", 0) != -6:  # VCY_ERR_UNSUPPORTED
+        if getattr(e, "rc", 0) != capi.VCY_ERR_UNSUPPORTED:
             raise
         nbytes = 0
         for below, c in zip([None] + list(carvers[:-1]), carvers):

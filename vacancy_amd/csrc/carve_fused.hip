@@ -1546,6 +1546,10 @@ __global__ __launch_bounds__(256) void div_verify_kernel(float n, unsigned* __re
   if (__any(b1) && (threadIdx.x & 63) == 0) atomicOr(&bad[1], 1u);
 }
 
+__global__ void fill_lowest_kernel(float* __restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = kInvalidSdf;
+}
+
 std::mutex g_div_mutex;
 std::map<std::pair<int, uint32_t>, int> g_div_cache;  // (device, numerator bits) -> level
 
@@ -1778,6 +1782,18 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     c->brick_min_valid = false;
   }
   if (!c->cnt_implied) c->brick_min_valid = false;
+  // Not every wave of the launches below rewrites its entry: a wave whose every view lies below the truncation limit
+  // returns before it has read anything, a workgroup left off the live list never starts.  That is harmless while the
+  // entry was valid on entry (it still is).  When it was not -- the per-view kernel or a vcy_upload has written to the
+  // state since, or the array has just been allocated over a slab that is not fresh -- every entry starts from
+  // lowest(): "a voxel of this brick may be untouched", which never drops a view and never lets marching cubes skip
+  // the brick.  (A fresh slab needs nothing: there every wave runs and stores its minimum.)
+  if (c->d_brick_min && !c->fresh && !c->brick_min_valid && c->cnt_implied) {
+    const int64_t nb = (int64_t)nbw * nby * nbz;
+    hipLaunchKernelGGL(fill_lowest_kernel, dim3((unsigned)std::min<int64_t>((nb + 255) / 256, 4096)), dim3(256), 0,
+                       c->stream, c->d_brick_min, nb);
+    VCY_HIP_CHECK(hipGetLastError());
+  }
   const int state_flags = (c->fresh ? 1 : 0) | (c->cnt_implied ? 2 : 0) | (c->brick_min_valid && !c->fresh ? 4 : 0);
   // Raw tiles: the footprint records of every (wave brick, view) pair come from a pre-pass (footprint_records_kernel),
   // 8 bytes per pair.  The slab is carved in chunks of whole brick layers so that the records of a chunk stay
@@ -1886,7 +1902,8 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     }
   }
   c->fresh = false;  // the launches store every voxel of a fresh slab
-  c->brick_min_valid = c->d_brick_min != nullptr && c->cnt_implied;  // (every wave that did not return early wrote its entry)
+  // (every wave that ran to its end wrote its entry; the others' entries were valid on entry or hold lowest(), see above)
+  c->brick_min_valid = c->d_brick_min != nullptr && c->cnt_implied;
   return VCY_OK;
 }
 

@@ -110,6 +110,17 @@ class ShardedVoxelCarver:
         kernel = [0.0] * len(self.by_device)
 
         def run(i, cs):
+            # a failure on one device must not leave the others waiting at a barrier for ever: abort it, so that
+            # every thread comes back and _per_device re-raises the real error (BrokenBarrierError is secondary)
+            try:
+                body(i, cs)
+            except threading.BrokenBarrierError:
+                pass
+            except BaseException:
+                barrier.abort()
+                raise
+
+        def body(i, cs):
             lead = cs[0]
             for c in cs:
                 c.sync()
