@@ -294,6 +294,13 @@ inline float interp_bilinear(float u, float v, const float* sdf, int width,
 
 }  // namespace
 
+// Which way the three products of a row of Affine3f * Vector3f are summed.  0 (what the oracle and the device use):
+// t + (c0 + (c1 + c2)), Eigen's unrolled redux.  1: t + ((c0 + c1) + c2).  2: ((t + c0) + c1) + c2.
+// 1 and 2 exist ONLY to measure how much rests on that unpinned assumption (tests/test_association_exposure.py,
+// tests/golden/association_exposure.json); nothing else selects them, and the product has no such switch.
+static int g_association = 0;
+void orc_set_association(int mode) { g_association = (mode == 1 || mode == 2) ? mode : 0; }
+
 double orc_carve(orc_grid* g, const vcy_view* view, const float* sdf) {
   const vcy_update_option& opt = g->opt;
   const double t0 = now_ms();
@@ -304,6 +311,7 @@ double orc_carve(orc_grid* g, const vcy_view* view, const float* sdf) {
   const int nx = g->n[0], ny = g->n[1], nz = g->n[2];
   const int32_t* roi_min = view->roi_min;
   const int32_t* roi_max = view->roi_max;
+  const int assoc = g_association;
 #pragma omp parallel for schedule(dynamic, 1)
   for (int z = 0; z < nz; z++) {
     for (int y = 0; y < ny; y++) {
@@ -320,7 +328,9 @@ double orc_carve(orc_grid* g, const vcy_view* view, const float* sdf) {
           float c0 = M[4 * i + 0] * p[0];
           float c1 = M[4 * i + 1] * p[1];
           float c2 = M[4 * i + 2] * p[2];
-          pc[i] = M[4 * i + 3] + (c0 + (c1 + c2));
+          if (assoc == 0) pc[i] = M[4 * i + 3] + (c0 + (c1 + c2));
+          else if (assoc == 1) pc[i] = M[4 * i + 3] + ((c0 + c1) + c2);   // exposure measurement only, see orc_set_association
+          else pc[i] = ((M[4 * i + 3] + c0) + c1) + c2;
         }
         if (pc[2] < 0) continue;  // :456
 

@@ -71,6 +71,11 @@ void orc_affine_to_float(const double m[12], float out[12]);
 /* PinholeCamera::set_fov_y, camera.cc:114-120 */
 float orc_focal_from_fov_y(int height, float fov_y_deg);
 
+/* TEST-ONLY: association of the 3-term row sums of Affine3f * Vector3f in orc_carve (0 = the restated Eigen order,
+ * the default; 1, 2 = the other two).  Used by tests/test_association_exposure.py to put a number on the one
+ * assumption nothing in the reference pins; see the .cc. */
+void orc_set_association(int mode);
+
 int orc_omp_max_threads(void);
 /* kEdgeTable[256] / kTriTable[256][16] as the oracle uses them (marching_cubes_lut.cc:15-298). */
 void orc_mc_tables(int* edge256, int* tri256x16);

@@ -28,6 +28,7 @@ def load():
     lib.orc_grid_create.restype = vp
     lib.orc_grid_create.argtypes = [P(CarverOption)]
     lib.orc_set_num_threads.argtypes = [C.c_int]
+    lib.orc_set_association.argtypes = [C.c_int]
     lib.orc_mc_tables.argtypes = [vp, vp]
     lib.orc_grid_destroy.argtypes = [vp]
     lib.orc_grid_from_positions.restype = vp
