@@ -281,8 +281,9 @@ int vcy_reset(vcy_ctx* ctx);
  * truncation limit) and starts only those; 0 starts every workgroup and lets each decide for itself.
  * "recordbytes" (default 0 = 1 GiB): bytes of footprint records one carve launch may take; a larger launch is cut into
  * chunks of whole brick layers (2048^3 x 64 views: nine).  Small values let tests run the chunking on small grids.
- * "carvetimer" (default 0): 1 records HIP events around the pre-pass and the carve kernel of every fused launch
- * (vcy_last_carve_ms).
+ * "carvetimer" (default 0): 1 records HIP events around what runs before the carve kernel (window maxima, pre-pass)
+ * and around the carve kernel of every fused launch (vcy_last_carve_ms, vcy_carve_log); setting it clears the log.
+ * "paircount" (default 0): 1 makes every fused launch count the (brick, view) pairs it processes (vcy_last_carve_pairs).
  * "inject_carve_failure" (test hook, default 0): the next `value` applications of views fail with
  * VCY_ERR_INTERNAL before anything is launched -- how the tests exercise the error contract of vcy_carve. */
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
@@ -303,6 +304,39 @@ int vcy_timer_end(vcy_ctx* ctx, float* elapsed_ms);
  * carve launch, split into what runs before the carve kernel (footprint pre-pass, live-workgroup list) and the
  * carve kernel itself -- the kernel the roofline is quoted for.  Synchronises with that launch. */
 int vcy_last_carve_ms(vcy_ctx* ctx, float* prepass_ms, float* kernel_ms);
+/* The whole log "carvetimer" 1 keeps since it was set (or since the last call with clear != 0): one record per chunk
+ * of every fused launch (first_chunk[i] != 0 starts a launch; a launch has one chunk unless its footprint records
+ * exceed "recordbytes"), up to 8192 records -- later launches are not recorded.  begin_ms[i] = start of record i
+ * (before its window maxima and pre-pass) since the start of record 0; prepass_ms[i] / kernel_ms[i] as for
+ * vcy_last_carve_ms.  Any of the arrays may be NULL.  Nothing synchronises while the launches are issued: a sequence
+ * of carve steps can be queued back to back and read here afterwards (this call waits for the recorded launches).
+ * No reference counterpart (the reference's Timer brackets the loop, voxel_carver.cc:435,492-493). */
+int vcy_carve_log(vcy_ctx* ctx, int max_records, float* begin_ms, float* prepass_ms, float* kernel_ms,
+                  int32_t* first_chunk, int* n_records, int clear);
+
+/* With vcy_set_param(ctx, "paircount", 1): how many (8 x 8 x 8 brick, view) pairs the last fused launch really
+ * processed -- i.e. did not drop as provably idle -- in total and per brick layer of the slab (per_layer may be NULL;
+ * *n_layers = layers of the slab), and how many pairs there are.  Synchronises with that launch.  What the scene
+ * leaves of the work is visible here (bench.py: "pairs_processed_frac"), and the slab planner's estimate is checked
+ * against it. */
+int vcy_last_carve_pairs(vcy_ctx* ctx, int64_t* processed, int64_t* total, int64_t* per_layer, int max_layers,
+                         int* n_layers);
+
+/* Multi-GPU: where to cut the grid into `n_slabs` z-slabs so that a fused carve of THESE views costs every slab the
+ * same (no reference counterpart: the reference's OpenMP loop balances itself with schedule(dynamic, 1),
+ * voxel_carver.cc:439-441; z-slabs on different GPUs cannot).  With view dropping the brick layers through the object
+ * cost about 1.6x the outer ones, so slabs of equal thickness leave the slowest of 8 GPUs 1.2x over the mean.  `ctx` is
+ * any context of the grid on the device that holds the images (typically a small planning context, vcy_create(option,
+ * device, 0, 8, ...), destroyed afterwards: only its axis tables and staging buffers are used, its slab is not touched);
+ * the estimate -- per brick layer of the WHOLE grid: brick_cost x bricks + (brick, view) pairs a carve will process,
+ * found by playing the kernel's drop decisions on upper and lower bounds of every `sample_stride`-th brick's samples
+ * (0: every 2nd in x and y) -- is returned in layer_cost[0 .. *n_layers) if not NULL.  brick_cost <= 0: the library's
+ * calibrated value.  z_bounds[0 .. n_slabs] receives the cuts (multiples of 8 slices, z_bounds[0] = 0,
+ * z_bounds[n_slabs] = nz): the contiguous partition with the smallest largest part.  The same inputs give the same
+ * cuts on every rank. */
+int vcy_plan_z_slabs(vcy_ctx* ctx, int n_views, const vcy_view* views, const float* const* sdf_device, int n_slabs,
+                     int sample_stride, float brick_cost, int32_t* z_bounds, double* layer_cost, int max_layers,
+                     int* n_layers);
 
 /* Device-side self test of the identities the fast paths rest on (no reference counterpart): the
  * two-instruction reciprocal used for update_num + 1 in the unit-weight weighted average equals the

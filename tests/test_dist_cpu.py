@@ -54,7 +54,7 @@ class FakeSlabCarver:
         self.halo = (np.frombuffer(part[:2 * self.s * 4], np.float32), np.frombuffer(part[2 * self.s * 4:], np.uint16))
 
 
-def _worker(rank, world, port, k, ret):
+def _worker(rank, world, port, k, ret, bounds=None):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -66,8 +66,10 @@ def _worker(rank, world, port, k, ret):
             g.carve(views[i], O.make_sdf(masks[i]))
         nx, ny, nz = g.dims
         sdf, cnt = g.download()
-        slabs = vdist.slabs_of_rank(nz, rank, world, k)
+        slabs = vdist.slabs_of_rank(nz, rank, world, k, bounds)
         assert [s for s, _, _ in slabs] == list(range(rank, world * k, world))
+        if bounds is not None:
+            assert [(z0, z1) for _, z0, z1 in slabs] == [(bounds[s], bounds[s + 1]) for s in range(rank, world * k, world)]
         # halo exchange through the real collective code path (gloo branch)
         fakes = [FakeSlabCarver(sdf, cnt, z0, z1, nx * ny) for _, z0, z1 in slabs]
         vdist.exchange_halo(fakes, rank, world)
@@ -107,6 +109,32 @@ def test_slab_sharded_extraction_merges_to_the_serial_mesh(world, k):
         mp.spawn(_worker, args=(world, port, k, ret), nprocs=world, join=True)
         assert ret.get("ok") is True
         assert ret["nv"] == 8672
+
+
+@pytest.mark.parametrize("world,k,bounds", [(2, 1, [0, 10, 42]), (3, 1, [0, 8, 24, 42]), (2, 2, [0, 6, 16, 30, 42]),
+                                            (2, 1, [0, 40, 42])])
+def test_unequal_slabs_merge_to_the_serial_mesh(world, k, bounds):
+    """Slabs cut where the planner predicts equal COST are of unequal thickness (vcy_plan_z_slabs; here arbitrary
+    cuts, down to the 2 slices a halo needs): same exchange, same merge, the serial mesh array for array."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, port, k, ret, bounds), nprocs=world, join=True)
+        assert ret.get("ok") is True
+        assert ret["nv"] == 8672
+
+
+def test_slabs_of_rank_with_planned_cuts():
+    b = [0, 168, 296, 408, 512, 616, 728, 864, 1024]
+    assert vdist.slabs_of_rank(1024, 3, 8, 1, b) == [(3, 408, 512)]
+    assert vdist.slabs_of_rank(1024, 1, 4, 2, b) == [(1, 168, 296), (5, 616, 728)]
+    assert vdist.equal_bounds(1024, 8) == list(range(0, 1025, 128))
+    with pytest.raises(AssertionError):
+        vdist.slabs_of_rank(1024, 0, 4, 1, b)
 
 
 # ---- bench.py launch path (no GPU): `python bench.py --gpus N` from a plain shell -------------------
@@ -255,6 +283,58 @@ def test_inprocess_sharded_carver_with_fake_devices(devices, k):
     assert np.array_equal(merged["vertices"].view(np.uint32), ref["vertices"].view(np.uint32))
     assert np.array_equal(merged["faces"], ref["faces"]) and np.array_equal(merged["keys"], ref["keys"])
     sh.close()
+
+
+def test_inprocess_sharded_carver_with_planned_cuts_and_a_failing_device():
+    """z_bounds (the planner's cuts) give slabs of unequal thickness; the merged mesh is still the serial one.  And a
+    device whose carve fails must not leave the other device threads waiting at the barrier for ever (round-3 advisor):
+    the barrier is aborted and the failure re-raised."""
+    from vacancy_amd.sharded import ShardedVoxelCarver
+    masks = B.load_masks()
+    views = B.bunny_views(lambda t, q: O.affine_inverse(O.pose_from_tum(t, q)))
+    opt = B.bunny_option(10.0)
+    full = O.OracleGrid(opt)
+    batch = [(views[i], O.make_sdf(masks[i])) for i in range(6)]
+    for v, s in batch:
+        full.carve(v, s)
+    nz = full.dims[2]
+    cuts = [0, 16, 22, 42]
+    sh = ShardedVoxelCarver(opt, [0, 1, 2], 1, factory=OracleSlab, nz=nz, z_bounds=cuts)
+    assert sh.Init()
+    assert sh.z_ranges == [(0, 16), (16, 22), (22, 42)]
+    sh.carve_batch([batch] * 3, steps=1)
+    merged = sh.ExtractIsoSurface(0.0, True)
+    ref = full.marching_cubes()
+    assert np.array_equal(merged["vertices"].view(np.uint32), ref["vertices"].view(np.uint32))
+    assert np.array_equal(merged["faces"], ref["faces"]) and np.array_equal(merged["keys"], ref["keys"])
+    with pytest.raises(ValueError):
+        ShardedVoxelCarver(opt, [0, 1], 1, factory=OracleSlab, nz=nz, z_bounds=[0, 41, 42]).Init()
+
+    class Failing(OracleSlab):
+        def CarveBatchDevice(self, batch):
+            if self.device == 1:
+                return False
+            return OracleSlab.CarveBatchDevice(self, batch)
+
+    import threading
+    sh2 = ShardedVoxelCarver(opt, [0, 1, 2], 1, factory=Failing, nz=nz)
+    assert sh2.Init()
+    result = {}
+
+    def go():
+        try:
+            sh2.carve_batch([batch] * 3, steps=1)
+            result["r"] = "returned"
+        except RuntimeError as e:
+            result["r"] = str(e)
+
+    t = threading.Thread(target=go, daemon=True)
+    t.start()
+    t.join(120)
+    assert not t.is_alive(), "carve_batch hangs when one device fails"
+    assert "carve failed on device 1" in result["r"]
+    sh.close()
+    sh2.close()
 
 
 def test_bench_inprocess_launch_is_selected_without_torch_distributed():

@@ -291,6 +291,40 @@ class VoxelCarver:
         assert self._lib.vcy_last_carve_ms(self._ctx, C.byref(a), C.byref(b)) == 0, last_error()
         return a.value, b.value
 
+    def last_carve_pairs(self):
+        """(processed, total, per-layer array) of the last fused launch; needs set_param("paircount", 1)."""
+        a, b, n = C.c_int64(), C.c_int64(), C.c_int()
+        per = np.zeros(4096, np.int64)
+        rc = self._lib.vcy_last_carve_pairs(self._ctx, C.byref(a), C.byref(b), _p(per), len(per), C.byref(n))
+        if rc != 0:
+            raise RuntimeError(last_error())
+        return int(a.value), int(b.value), per[: n.value].copy()
+
+    def plan_z_slabs(self, views, sdf_devs, n_slabs, stride=0, brick_cost=0.0):
+        """vcy_plan_z_slabs: (z_bounds [n_slabs + 1], layer_cost [brick layers of the grid]) for a fused carve of these
+        views; `views, sdf_devs` as for CarveBatchDevice (or a prepared batch as `views`)."""
+        n, arr, ptrs = views if sdf_devs is None else self.prepare_batch(views, sdf_devs)
+        bounds = np.zeros(n_slabs + 1, np.int32)
+        cost = np.zeros(8192, np.float64)
+        nl = C.c_int()
+        rc = self._lib.vcy_plan_z_slabs(self._ctx, n, arr, ptrs, int(n_slabs), int(stride), float(brick_cost),
+                                        _p(bounds), _p(cost), len(cost), C.byref(nl))
+        if rc != 0:
+            raise RuntimeError(last_error())
+        return [int(z) for z in bounds], cost[: nl.value].copy()
+
+    def carve_log(self, clear=True, max_records=8192):
+        """[(begin_ms, prepass_ms, kernel_ms, first_chunk)] of every chunk of every fused launch since "carvetimer" was
+        set / the log was cleared (vcy_carve_log); waits for those launches, nothing synchronised in between."""
+        b = np.empty(max_records, np.float32)
+        p = np.empty(max_records, np.float32)
+        k = np.empty(max_records, np.float32)
+        f = np.empty(max_records, np.int32)
+        n = C.c_int(0)
+        rc = self._lib.vcy_carve_log(self._ctx, max_records, _p(b), _p(p), _p(k), _p(f), C.byref(n), int(clear))
+        assert rc == 0, last_error()
+        return [(float(b[i]), float(p[i]), float(k[i]), int(f[i])) for i in range(n.value)]
+
     def timer_begin(self):
         self._lib.vcy_timer_begin(self._ctx)
 

@@ -114,6 +114,39 @@ static void launch_view(vcy_ctx* c, const GridParams& g, const ViewParams& v, co
   }
 }
 
+// The views as the kernels read them: max over the whole SDF buffer resolved (voxel_carver.cc:436; only
+// update_outside = kMax reads it).
+static int resolve_views(vcy_ctx* c, int n_views, const vcy_view* views, const float* const* sdf_dev,
+                         std::vector<ViewParams>* out) {
+  const vcy_update_option& u = c->opt.update_option;
+  // max over the whole SDF buffer (voxel_carver.cc:436); only update_outside = kMax reads it
+  std::vector<float> max_sdf((size_t)n_views, 0.0f);
+  if (u.update_outside == VCY_OUTSIDE_MAX) {
+    float* d_max = nullptr;
+    VCY_HIP_CHECK(hipMalloc(&d_max, sizeof(float) * (size_t)n_views * (1 + kMaxReduceBlocks)));
+    float* d_part = d_max + n_views;
+    for (int i = 0; i < n_views; ++i) {
+      const int64_t npx = (int64_t)views[i].width * views[i].height;
+      hipLaunchKernelGGL(max_reduce_kernel, dim3(kMaxReduceBlocks), dim3(256), 0, c->stream, sdf_dev[i], npx,
+                         d_part + (size_t)i * kMaxReduceBlocks);
+      hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, c->stream, d_part + (size_t)i * kMaxReduceBlocks,
+                         (int64_t)kMaxReduceBlocks, d_max + i);
+    }
+    hipError_t e = hipMemcpyAsync(max_sdf.data(), d_max, sizeof(float) * (size_t)n_views,
+                                  hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_max);
+    if (e != hipSuccess) {
+      set_error("max reduce failed: %s", hipGetErrorString(e));
+      return VCY_ERR_HIP;
+    }
+  }
+  out->resize((size_t)n_views);
+  for (int i = 0; i < n_views; ++i) fill_view(views[i], sdf_dev[i], max_sdf[i], &(*out)[(size_t)i]);
+  return VCY_OK;
+}
+
+
 // Applies the views queued by the per-view entry points, in order, as one batch.  `from_carve`: the caller is
 // a carve entry point, whose own return value carries a failure to the `if (!Carve())` of the host loop; any
 // other caller (an extraction, a download ...) cannot, so the failure is kept for the next carve call.
@@ -176,30 +209,11 @@ int launch_carve(vcy_ctx* c, int n_views, const vcy_view* views, const float* co
     return VCY_ERR_TOO_MANY_VOXELS;
   }
 
-  // max over the whole SDF buffer (voxel_carver.cc:436); only update_outside = kMax reads it
-  std::vector<float> max_sdf((size_t)n_views, 0.0f);
-  if (u.update_outside == VCY_OUTSIDE_MAX) {
-    float* d_max = nullptr;
-    VCY_HIP_CHECK(hipMalloc(&d_max, sizeof(float) * (size_t)n_views * (1 + kMaxReduceBlocks)));
-    float* d_part = d_max + n_views;
-    for (int i = 0; i < n_views; ++i) {
-      const int64_t npx = (int64_t)views[i].width * views[i].height;
-      hipLaunchKernelGGL(max_reduce_kernel, dim3(kMaxReduceBlocks), dim3(256), 0, c->stream, sdf_dev[i], npx,
-                         d_part + (size_t)i * kMaxReduceBlocks);
-      hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, c->stream, d_part + (size_t)i * kMaxReduceBlocks,
-                         (int64_t)kMaxReduceBlocks, d_max + i);
-    }
-    hipError_t e = hipMemcpyAsync(max_sdf.data(), d_max, sizeof(float) * (size_t)n_views,
-                                  hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_max);
-    if (e != hipSuccess) {
-      set_error("max reduce failed: %s", hipGetErrorString(e));
-      return VCY_ERR_HIP;
-    }
+  std::vector<ViewParams> vp;
+  {
+    const int rcv = resolve_views(c, n_views, views, sdf_dev, &vp);
+    if (rcv != VCY_OK) return rcv;
   }
-  std::vector<ViewParams> vp((size_t)n_views);
-  for (int i = 0; i < n_views; ++i) fill_view(views[i], sdf_dev[i], max_sdf[i], &vp[i]);
 
   const bool fused = c->use_fused && fused_eligible(c, n_views, views);
   if (!fused) {
@@ -228,6 +242,64 @@ int launch_carve(vcy_ctx* c, int n_views, const vcy_view* views, const float* co
     }
   }
   c->halo_valid = false;
+  return VCY_OK;
+}
+
+// Cuts the grid into n_slabs z-slabs of equal PREDICTED carve cost for these views (vcy_plan_z_slabs).  Boundaries are
+// whole brick layers (8 slices): a slab that ends inside a layer pays that layer's waves in full, and so does the next.
+// cost(layer) = brick_cost * bricks + estimated (brick, view) pairs processed (plan_layer_pairs); the contiguous
+// partition that minimises the largest part -- and, among those, the sum of squares -- by dynamic programming.
+constexpr float kPlanBrickCost = 2.0f;  // a wave's fixed work (record, state, write-back) in units of one processed view
+int plan_z_slabs(vcy_ctx* c, int n_views, const vcy_view* views, const float* const* sdf_dev, int n_slabs, int stride,
+                 float brick_cost, int32_t* z_bounds, double* layer_cost, int max_layers, int* n_layers) {
+  const int L = (c->nz + 7) / 8;
+  if (n_slabs < 1 || n_slabs > L) {
+    set_error("cannot cut %d brick layers into %d slabs", L, n_slabs);
+    return VCY_ERR_INVALID_ARG;
+  }
+  std::vector<double> cost((size_t)L, 1.0);
+  if (fused_eligible(c, n_views, views) && c->use_fused && n_views <= fused_max_views()) {
+    std::vector<ViewParams> vp;
+    int rc = resolve_views(c, n_views, views, sdf_dev, &vp);
+    if (rc != VCY_OK) return rc;
+    c->fused_ortho = views[0].is_ortho != 0;
+    std::vector<double> pairs;
+    int64_t bricks = 0;
+    rc = plan_layer_pairs(c, n_views, vp.data(), stride > 0 ? stride : 2, &pairs, &bricks);
+    if (rc != VCY_OK) return rc;
+    const double bc = brick_cost > 0.0f ? brick_cost : kPlanBrickCost;
+    for (int l = 0; l < L; ++l) cost[(size_t)l] = bc * (double)bricks + pairs[(size_t)l];
+    // (a last layer of fewer than 8 slices costs its waves in full: nothing to scale)
+  }  // (else: the per-view kernel, whose cost does not depend on the scene -- equal layers)
+  if (layer_cost)
+    for (int l = 0; l < std::min(L, max_layers); ++l) layer_cost[l] = cost[(size_t)l];
+  if (n_layers) *n_layers = L;
+  std::vector<double> pre((size_t)L + 1, 0.0);
+  for (int l = 0; l < L; ++l) pre[(size_t)l + 1] = pre[(size_t)l] + cost[(size_t)l];
+  // f[s][i]: best (largest part, sum of squares) for the first i layers in s parts
+  struct Val { double mx, sq; };
+  auto better = [](const Val& a, const Val& b) { return a.mx < b.mx * (1.0 - 1e-12) || (a.mx <= b.mx * (1.0 + 1e-12) && a.sq < b.sq); };
+  const Val inf{1e300, 1e300};
+  std::vector<std::vector<Val>> f((size_t)n_slabs + 1, std::vector<Val>((size_t)L + 1, inf));
+  std::vector<std::vector<int>> from((size_t)n_slabs + 1, std::vector<int>((size_t)L + 1, -1));
+  f[0][0] = Val{0.0, 0.0};
+  for (int sidx = 1; sidx <= n_slabs; ++sidx)
+    for (int i = sidx; i <= L - (n_slabs - sidx); ++i)
+      for (int j = sidx - 1; j < i; ++j) {
+        if (f[(size_t)sidx - 1][(size_t)j].mx >= 1e299) continue;
+        const double part = pre[(size_t)i] - pre[(size_t)j];
+        const Val v{std::max(f[(size_t)sidx - 1][(size_t)j].mx, part), f[(size_t)sidx - 1][(size_t)j].sq + part * part};
+        if (better(v, f[(size_t)sidx][(size_t)i])) {
+          f[(size_t)sidx][(size_t)i] = v;
+          from[(size_t)sidx][(size_t)i] = j;
+        }
+      }
+  int i = L;
+  z_bounds[n_slabs] = c->nz;
+  for (int sidx = n_slabs; sidx >= 1; --sidx) {
+    i = from[(size_t)sidx][(size_t)i];
+    z_bounds[sidx - 1] = i * 8;
+  }
   return VCY_OK;
 }
 

@@ -1,5 +1,6 @@
 // C-ABI entry points of libvacancy_hip.so: lifetime, state access, halo, helpers.
 // The carving and extraction kernels live in carve_kernels.hip / mc_kernels.hip.
+#include <algorithm>
 #include <cstdarg>
 #include <cstring>
 #include <chrono>
@@ -124,6 +125,28 @@ int materialize(vcy_ctx* c) {
   return VCY_OK;
 }
 
+// Next slot of the carve timer's event log (vcy_set_param "carvetimer"); the events of a slot are created once and
+// re-used after the log has been cleared.  -1 when the log is full (the launch is then simply not recorded) or an
+// event cannot be created.
+constexpr int kCarveLogMax = 8192;
+int carve_log_open(vcy_ctx* c, bool first_chunk) {
+  if (c->carve_log_n >= kCarveLogMax) return -1;
+  if ((size_t)c->carve_log_n == c->carve_log.size()) {
+    vcy_ctx::CarveStamp st{{nullptr, nullptr, nullptr}, false};
+    for (int k = 0; k < 3; ++k)
+      if (hipEventCreate(&st.ev[k]) != hipSuccess) {
+        (void)hipGetLastError();
+        for (int q = 0; q < k; ++q) (void)hipEventDestroy(st.ev[q]);
+        return -1;
+      }
+    c->carve_log.push_back(st);
+  }
+  const int i = c->carve_log_n++;
+  c->carve_log[(size_t)i].first_chunk = first_chunk;
+  if (first_chunk) c->carve_log_last = i;
+  return i;
+}
+
 static int dims_from_option(const float bb_min[3], const float bb_max[3], float res, int32_t n[3]) {
   // VoxelGrid::Init, reference voxel_carver.cc:278-301
   if (res < std::numeric_limits<float>::min()) {
@@ -167,6 +190,8 @@ void mesh_pool_trim() {
 }  // namespace
 
 extern "C" {
+
+static int check_view_static(const vcy_view* v);
 
 const char* vcy_last_error(void) { return g_last_error.c_str(); }
 const char* vcy_version(void) { return "vacancy_amd 0.3 (gfx950) src:" VCY_SOURCE_HASH; }
@@ -342,9 +367,11 @@ void vcy_destroy(vcy_ctx* c) {
   (void)hipFree(c->d_wmax);
   (void)hipFree(c->d_records);
   (void)hipFree(c->d_wg_list);
+  (void)hipFree(c->d_pair_count);
   if (c->h_live_hint) (void)hipHostFree(c->h_live_hint);
-  for (int k = 0; k < 3; ++k)
-    if (c->ev_carve[k]) (void)hipEventDestroy(c->ev_carve[k]);
+  for (auto& st : c->carve_log)
+    for (int k = 0; k < 3; ++k)
+      if (st.ev[k]) (void)hipEventDestroy(st.ev[k]);
   (void)hipFree(c->d_brick_min);
   for (auto& t : c->pending) (void)hipFree(t.d_sdf);
   for (auto& t : c->sdf_pool) (void)hipFree(t.first);
@@ -419,10 +446,11 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
   }
   if (std::strcmp(name, "carvetimer") == 0) {
     c->time_carve = value != 0;
-    if (c->time_carve && !c->ev_carve[0]) {
-      VCY_HIP_CHECK(hipSetDevice(c->device));
-      for (int k = 0; k < 3; ++k) VCY_HIP_CHECK(hipEventCreate(&c->ev_carve[k]));
-    }
+    c->carve_log_n = c->carve_log_last = 0;  // (the log starts over)
+    return VCY_OK;
+  }
+  if (std::strcmp(name, "paircount") == 0) {
+    c->count_pairs = value != 0;
     return VCY_OK;
   }
   if (std::strcmp(name, "recordbytes") == 0) {
@@ -497,18 +525,82 @@ int vcy_timer_end(vcy_ctx* c, float* ms) {
 int vcy_last_carve_ms(vcy_ctx* c, float* prepass_ms, float* kernel_ms) {
   if (!c || !prepass_ms || !kernel_ms) return VCY_ERR_INVALID_ARG;
   VCY_HIP_CHECK(hipSetDevice(c->device));
-  if (c->carve_timed_chunks > 0) {  // the last chunk's events
+  *prepass_ms = *kernel_ms = 0.0f;
+  for (int i = c->carve_log_last; i < c->carve_log_n; ++i) {  // the chunks of the last launch
+    const vcy_ctx::CarveStamp& st = c->carve_log[(size_t)i];
     float a = 0.0f, b = 0.0f;
-    VCY_HIP_CHECK(hipEventSynchronize(c->ev_carve[2]));
-    VCY_HIP_CHECK(hipEventElapsedTime(&a, c->ev_carve[0], c->ev_carve[1]));
-    VCY_HIP_CHECK(hipEventElapsedTime(&b, c->ev_carve[1], c->ev_carve[2]));
-    c->carve_prepass_ms += a;
-    c->carve_kernel_ms += b;
-    c->carve_timed_chunks = 0;
+    VCY_HIP_CHECK(hipEventSynchronize(st.ev[2]));
+    VCY_HIP_CHECK(hipEventElapsedTime(&a, st.ev[0], st.ev[1]));
+    VCY_HIP_CHECK(hipEventElapsedTime(&b, st.ev[1], st.ev[2]));
+    *prepass_ms += a;
+    *kernel_ms += b;
   }
-  *prepass_ms = c->carve_prepass_ms;
-  *kernel_ms = c->carve_kernel_ms;
   return VCY_OK;
+}
+
+int vcy_carve_log(vcy_ctx* c, int max_records, float* begin_ms, float* prepass_ms, float* kernel_ms,
+                  int32_t* first_chunk, int* n_records, int clear) {
+  if (!c || !n_records || max_records < 0) return VCY_ERR_INVALID_ARG;
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  const int n = std::min(max_records, c->carve_log_n);
+  for (int i = 0; i < n; ++i) {
+    const vcy_ctx::CarveStamp& st = c->carve_log[(size_t)i];
+    float t0 = 0.0f, a = 0.0f, b = 0.0f;
+    VCY_HIP_CHECK(hipEventSynchronize(st.ev[2]));
+    if (i > 0) VCY_HIP_CHECK(hipEventElapsedTime(&t0, c->carve_log[0].ev[0], st.ev[0]));
+    VCY_HIP_CHECK(hipEventElapsedTime(&a, st.ev[0], st.ev[1]));
+    VCY_HIP_CHECK(hipEventElapsedTime(&b, st.ev[1], st.ev[2]));
+    if (begin_ms) begin_ms[i] = t0;
+    if (prepass_ms) prepass_ms[i] = a;
+    if (kernel_ms) kernel_ms[i] = b;
+    if (first_chunk) first_chunk[i] = st.first_chunk ? 1 : 0;
+  }
+  *n_records = n;
+  if (clear) c->carve_log_n = c->carve_log_last = 0;
+  return VCY_OK;
+}
+
+int vcy_last_carve_pairs(vcy_ctx* c, int64_t* processed, int64_t* total, int64_t* per_layer, int max_layers, int* n_layers) {
+  if (!c) return VCY_ERR_NOT_INITIALIZED;
+  if (!c->count_pairs || !c->d_pair_count) {
+    set_error("vcy_last_carve_pairs: no fused launch since vcy_set_param(\"paircount\", 1)");
+    return VCY_ERR_INVALID_ARG;
+  }
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  const int nbz = (c->nz_local() + 7) / 8;
+  std::vector<unsigned long long> h((size_t)nbz, 0ull);
+  VCY_HIP_CHECK(hipMemcpyAsync(h.data(), c->d_pair_count, sizeof(unsigned long long) * (size_t)nbz, hipMemcpyDeviceToHost, c->stream));
+  VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+  int64_t sum = 0;
+  for (int l = 0; l < nbz; ++l) {
+    sum += (int64_t)h[(size_t)l];
+    if (per_layer && l < max_layers) per_layer[l] = (int64_t)h[(size_t)l];
+  }
+  if (processed) *processed = sum;
+  if (total) *total = (int64_t)((c->nx + 7) / 8) * ((c->ny + 7) / 8) * nbz * c->pair_count_views;
+  if (n_layers) *n_layers = nbz;
+  return VCY_OK;
+}
+
+int vcy_plan_z_slabs(vcy_ctx* c, int n_views, const vcy_view* views, const float* const* sdf_device, int n_slabs,
+                     int sample_stride, float brick_cost, int32_t* z_bounds, double* layer_cost, int max_layers,
+                     int* n_layers) {
+  if (!c) return VCY_ERR_NOT_INITIALIZED;
+  if (n_views <= 0 || !views || !sdf_device || !z_bounds) {
+    set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  for (int i = 0; i < n_views; ++i) {
+    const int rc = check_view_static(&views[i]);
+    if (rc != VCY_OK) return rc;
+    if (!sdf_device[i]) {
+      set_error("null SDF pointer");
+      return VCY_ERR_INVALID_ARG;
+    }
+  }
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  return plan_z_slabs(c, n_views, views, sdf_device, n_slabs, sample_stride, brick_cost, z_bounds, layer_cost,
+                      max_layers, n_layers);
 }
 
 int vcy_selftest(vcy_ctx* c) {
@@ -739,19 +831,7 @@ int vcy_halo_unpack(vcy_ctx* c, const void* gathered, int rank, int world) {
 
 /* ---- carving entry points ------------------------------------------------ */
 
-static int check_view(const vcy_ctx* c, const vcy_view* v) {
-  if (!c) {
-    set_error("VoxelCarver::Carve voxel grid has not been initialized");
-    return VCY_ERR_NOT_INITIALIZED;
-  }
-  if (c->deferred_rc != VCY_OK) {  // views queued by earlier calls failed to apply (see vcy_ctx::deferred_rc)
-    vcy_ctx* m = const_cast<vcy_ctx*>(c);
-    const int rc = m->deferred_rc;
-    set_error("an earlier queued view failed: %s", m->deferred_msg.c_str());
-    m->deferred_rc = VCY_OK;
-    m->deferred_msg.clear();
-    return rc;
-  }
+static int check_view_static(const vcy_view* v) {
   if (!v || v->width <= 0 || v->height <= 0) {
     set_error("invalid view");
     return VCY_ERR_INVALID_ARG;
@@ -765,6 +845,22 @@ static int check_view(const vcy_ctx* c, const vcy_view* v) {
     return VCY_ERR_INVALID_ARG;
   }
   return VCY_OK;
+}
+
+static int check_view(const vcy_ctx* c, const vcy_view* v) {
+  if (!c) {
+    set_error("VoxelCarver::Carve voxel grid has not been initialized");
+    return VCY_ERR_NOT_INITIALIZED;
+  }
+  if (c->deferred_rc != VCY_OK) {  // views queued by earlier calls failed to apply (see vcy_ctx::deferred_rc)
+    vcy_ctx* m = const_cast<vcy_ctx*>(c);
+    const int rc = m->deferred_rc;
+    set_error("an earlier queued view failed: %s", m->deferred_msg.c_str());
+    m->deferred_rc = VCY_OK;
+    m->deferred_msg.clear();
+    return rc;
+  }
+  return check_view_static(v);
 }
 
 int vcy_carve_batch_device(vcy_ctx* c, int n_views, const vcy_view* views,

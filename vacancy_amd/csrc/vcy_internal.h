@@ -103,22 +103,33 @@ struct vcy_ctx {
   bool brick_min_valid = false;       // ... and current: no write to the state since has bypassed the fused kernel
   int* d_wg_list = nullptr;           // live workgroups of a carve launch of few views ([0] = count), live_workgroups_kernel
   size_t wg_list_bytes = 0;
-  bool time_carve = false;            // vcy_set_param("carvetimer", 1): events around pre-pass and carve kernel of a fused launch
-  hipEvent_t ev_carve[3] = {nullptr, nullptr, nullptr};
-  float carve_prepass_ms = 0.0f, carve_kernel_ms = 0.0f;  // of the last fused launch (vcy_last_carve_ms)
-  int carve_timed_chunks = 0;
+  bool time_carve = false;            // vcy_set_param("carvetimer", 1): events around pre-pass and carve kernel of every fused launch
+  struct CarveStamp {                 // one chunk of one fused launch
+    hipEvent_t ev[3];                 // before window maxima / pre-pass, before the carve kernel, after it
+    bool first_chunk;
+  };
+  std::vector<CarveStamp> carve_log;  // event triplets, created on demand (vcy_carve_log, vcy_last_carve_ms)
+  int carve_log_n = 0;                // triplets recorded since the log was last cleared
+  int carve_log_last = 0;             // index of the first chunk of the last launch
   int* h_live_hint = nullptr;         // page-locked {live workgroups, workgroups} of the last listed launch (a hint, see launch_carve_fused)
   int64_t live_list_age = 0;
   bool use_live_list = true;          // vcy_set_param("livelist", 0): every workgroup is launched and decides for itself
+  bool count_pairs = false;           // vcy_set_param("paircount", 1): the fused kernel counts the (brick, view) pairs it processes
+  unsigned long long* d_pair_count = nullptr;  // ... per brick layer of the slab, of the last fused launch (vcy_last_carve_pairs)
+  int pair_count_layers = 0, pair_count_views = 0;
   int64_t record_bytes_max = 0;       // vcy_set_param("recordbytes", n): footprint records per launch chunk (0: 1 GiB)
   void* d_records = nullptr;          // footprint records of one fused launch, 8 bytes per (wave brick, view)
   size_t records_bytes = 0;
   float* d_wmax = nullptr;            // window-maximum planes of the views of one fused launch
   size_t wmax_bytes = 0;
   bool fused_ortho = false;           // projection model of the launch being prepared
-  bool fused_cache_valid = false;     // host mirror of what d_fused_scratch holds
-  std::vector<char> fused_cache_views;
-  std::vector<float> fused_cache_c2;
+  bool fused_cache_valid = false;     // d_fused_scratch holds what these view parameters give (launch_carve_fused)
+  std::vector<char> fused_cache_vp;   // the ViewParams of the launch that filled it
+  const float* fused_cache_wmax = nullptr;
+  void* fused_cache_at = nullptr;
+  bool fused_cache_bound = false, fused_cache_lower = false, fused_cache_ortho = false, fused_cache_samef = true;
+  int fused_cache_max_quads = 0;
+  int fused_cache_z[2] = {0, 0};
   void* d_stream_pool = nullptr;      // staging of vcy_carve_batch_silhouettes (masks, SDFs, scratch)
   size_t stream_pool_bytes = 0;
   hipStream_t aux_stream = nullptr;   // producer stream of the streamed batch (uploads + SDF build)
@@ -156,8 +167,13 @@ struct ViewParams;
 bool fused_eligible(const vcy_ctx* ctx, int n_views, const vcy_view* views);
 int launch_carve_fused(vcy_ctx* ctx, const GridParams& g, int n_views, const ViewParams* vp);
 int fused_max_views();
+int plan_layer_pairs(vcy_ctx* ctx, int n_views, const ViewParams* vp, int stride, std::vector<double>* pairs,
+                     int64_t* bricks_per_layer);  // the slab planner's estimate (carve_fused.hip)
+int plan_z_slabs(vcy_ctx* ctx, int n_views, const vcy_view* views, const float* const* sdf_dev, int n_slabs, int stride,
+                 float brick_cost, int32_t* z_bounds, double* layer_cost, int max_layers, int* n_layers);  // carve_kernels.hip
 int selftest_fused(hipStream_t stream);
 int flush_pending(vcy_ctx* ctx, bool from_carve = false);   // applies vcy_ctx::pending (no-op when empty)
+int carve_log_open(vcy_ctx* ctx, bool first_chunk);          // next slot of vcy_ctx::carve_log, or -1 (vcy_api.hip)
 // mc_kernels.hip
 int extract_iso(vcy_ctx* ctx, double iso, int linear_interp, vcy_mesh* out);
 // sdf2d.hip

@@ -21,7 +21,7 @@ from . import dist as vdist
 
 
 class ShardedVoxelCarver:
-    def __init__(self, option, devices, slabs_per_device=2, factory=None, nz=None):
+    def __init__(self, option, devices, slabs_per_device=1, factory=None, nz=None, z_bounds=None):
         if factory is None:
             from .carver import VoxelCarver as factory  # noqa: N813
         self.option = option
@@ -29,11 +29,14 @@ class ShardedVoxelCarver:
         self.k = int(slabs_per_device)
         self._factory = factory
         self._nz = nz
+        self.z_bounds = list(z_bounds) if z_bounds is not None else None  # cuts of equal predicted cost (plan)
+        self.plan_info = None
         self.slabs = []       # every slab of the grid, in z order
         self.by_device = []   # [[slab objects of device g, by slab id]]
         self.z_ranges = []    # [(z0, z1)] in z order
         self.last_collective = None
-        self.last_kernel_ms = None   # per device, of the last carve_batch
+        self.last_kernel_ms = None   # per device, of the last carve_batch: device ms per step
+        self.last_stats = None       # per device: {"prepass_ms", "kernel_ms", "period_ms", "idle_ms"} per step
         self.dims = None
 
     # -- VoxelCarver::Init on every slab (voxel_carver.cc:373-392)
@@ -51,9 +54,13 @@ class ShardedVoxelCarver:
         count = g * self.k
         if nz < 2 * count:
             raise ValueError("%d z slices cannot be cut into %d slabs of at least 2" % (nz, count))
+        bounds = self.z_bounds if self.z_bounds is not None else vdist.equal_bounds(nz, count)
+        if len(bounds) != count + 1 or bounds[0] != 0 or bounds[-1] != nz or \
+                any(b1 - b0 < 2 for b0, b1 in zip(bounds[:-1], bounds[1:])):
+            raise ValueError("z_bounds %s do not cut %d slices into %d slabs of at least 2" % (bounds, nz, count))
         self.by_device = [[] for _ in range(g)]
         for s in range(count):
-            z0, z1 = vdist.slab_range(nz, s, count)
+            z0, z1 = bounds[s], bounds[s + 1]
             c = self._factory(self.option, self.devices[s % g], (z0, z1))
             if not c.Init():
                 self.close()
@@ -64,6 +71,13 @@ class ShardedVoxelCarver:
             self.z_ranges.append((z0, z1))
         self.dims = getattr(self.slabs[0], "dims", None)
         return True
+
+    # -- where to cut: slabs of equal predicted carve cost for these views (vcy_plan_z_slabs), before Init()
+    def plan(self, views, sdf_host_images, stride=0, brick_cost=0.0):
+        bounds, _, info = vdist.plan_bounds(self.option, self.devices[0], views, sdf_host_images,
+                                            len(self.devices) * self.k, stride, brick_cost)
+        self.z_bounds, self.plan_info = bounds, info
+        return bounds
 
     def close(self):
         for c in reversed(self.slabs):
@@ -102,12 +116,14 @@ class ShardedVoxelCarver:
         self._per_device(lambda i, cs: [c.sync() for c in cs])
 
     # -- Carve(vector<Camera>, ...) loop (voxel_carver.cc:516-528): `batches[g]` = prepare_batch(...) with the
-    # images resident on device g.  Returns the wall time of the slowest device in ms; per-device step times (HIP
-    # events for a single slab, launch-to-sync wall time for several streams) are left in last_kernel_ms.
+    # images resident on device g.  The steps of a device are QUEUED back to back (nothing synchronises in between;
+    # a device that idles between launches drops its clocks) and the device is waited for once at the end.  Returns
+    # the wall time of the slowest device in ms; per device, the mean per step of what the library's event log
+    # ("carvetimer") holds is left in last_stats: pre-pass, carve kernel, step period, and idle = period - both.
     def carve_batch(self, batches, steps=1, reset=True):
         barrier = threading.Barrier(len(self.by_device))
         walls = [0.0] * len(self.by_device)
-        kernel = [0.0] * len(self.by_device)
+        stats = [None] * len(self.by_device)
 
         def run(i, cs):
             # a failure on one device must not leave the others waiting at a barrier for ever: abort it, so that
@@ -121,8 +137,10 @@ class ShardedVoxelCarver:
                 raise
 
         def body(i, cs):
-            lead = cs[0]
+            logged = all(hasattr(c, "carve_log") for c in cs)
             for c in cs:
+                if logged:
+                    c.set_param("carvetimer", 1)  # (clears the log)
                 c.sync()
             barrier.wait()
             t0 = time.perf_counter()
@@ -130,25 +148,26 @@ class ShardedVoxelCarver:
                 if reset:
                     for c in cs:
                         c.reset()
-                if len(cs) == 1:
-                    lead.timer_begin()
-                    ok = lead.CarveBatchDevice(batches[i])
-                    kernel[i] += lead.timer_end()
-                else:  # several streams: the step is over when the last of them is
-                    t_step = time.perf_counter()
-                    ok = all(c.CarveBatchDevice(batches[i]) for c in cs)
-                    for c in cs:
-                        c.sync()
-                    kernel[i] += (time.perf_counter() - t_step) * 1e3
-                if not ok:
+                if not all(c.CarveBatchDevice(batches[i]) for c in cs):
                     raise RuntimeError("carve failed on device %d" % self.devices[i])
             for c in cs:
                 c.sync()
             walls[i] = (time.perf_counter() - t0) * 1e3
             barrier.wait()
+            if logged:
+                pre = ker = 0.0
+                for c in cs:
+                    log = c.carve_log()
+                    pre += sum(r[1] for r in log)
+                    ker += sum(r[2] for r in log)
+                n = float(max(1, steps))
+                stats[i] = {"prepass_ms": pre / n, "kernel_ms": ker / n, "period_ms": walls[i] / n,
+                            "idle_ms": max(0.0, (walls[i] - pre - ker) / n)}
 
         self._per_device(run)
-        self.last_kernel_ms = [k / max(1, steps) for k in kernel]
+        self.last_stats = stats
+        self.last_kernel_ms = [(st["kernel_ms"] + st["prepass_ms"]) if st else w / max(1, steps)
+                               for st, w in zip(stats, walls)]
         return max(walls)
 
     # -- the exchange step of MarchingCubes() (marching_cubes.cc:93-101 reads z - 1)

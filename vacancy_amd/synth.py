@@ -104,3 +104,35 @@ def sphere_views(n, n_views, width, height, fov_y_deg=60.0):
         views.append(make_view(w2c, f, f, cx, cy, width, height))
         masks.append(mask)
     return views, masks
+
+
+def blob_views(n, n_views, width, height, fov_y_deg=60.0):
+    """A harder scene than the centred sphere, same cameras: two overlapping OFF-CENTRE spheres of different size (their
+    union is concave where they meet), so every view sees a different silhouette -- a distinct SDF image per view.
+    Returns (views, masks)."""
+    dist = 2.0 * n
+    f = focal_from_fov_y(height, fov_y_deg)
+    cx = np.float32(np.float32(width) * np.float32(0.5) - np.float32(0.5))
+    cy = np.float32(np.float32(height) * np.float32(0.5) - np.float32(0.5))
+    balls = [((0.16 * n, 0.10 * n, -0.12 * n), 0.24 * n), ((-0.17 * n, -0.08 * n, 0.10 * n), 0.17 * n)]
+    uu = (np.arange(width, dtype=np.float64) - float(cx)) / float(f)
+    vv = (np.arange(height, dtype=np.float64) - float(cy)) / float(f)
+    dx, dy = np.meshgrid(uu, vv)               # ray direction (dx, dy, 1) in camera coordinates
+    inv_len2 = 1.0 / (dx * dx + dy * dy + 1.0)
+    views, masks = [], []
+    for i in range(n_views):
+        y = 1.0 - 2.0 * (i + 0.5) / n_views
+        r = math.sqrt(max(0.0, 1.0 - y * y))
+        phi = i * math.pi * (3.0 - math.sqrt(5.0))
+        d = np.array([r * math.cos(phi), y, r * math.sin(phi)])
+        c2w = lookat_c2w(dist * d, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+        w2c64 = affine_inverse(c2w)
+        views.append(make_view(w2c64.astype(np.float32), f, f, cx, cy, width, height))
+        inside = np.zeros((height, width), bool)
+        for centre, radius in balls:
+            pc = w2c64[:, :3] @ np.asarray(centre, np.float64) + w2c64[:, 3]
+            along = pc[0] * dx + pc[1] * dy + pc[2]          # pc . ray
+            perp2 = float(pc @ pc) - along * along * inv_len2  # squared distance of the centre from the ray
+            inside |= (perp2 <= radius * radius) & (along > 0)
+        masks.append(np.where(inside, 255, 0).astype(np.uint8))
+    return views, masks
