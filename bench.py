@@ -5,7 +5,17 @@ A step = one pass of the hot path over one batch of synthetic input: reset the g
 carve V silhouette SDFs (already resident in HBM) into the N^3 grid.  The headline workload is
 BASELINE.json configs[2]/[3]: 1024^3 voxels x 32 views at 1280x720, default update mode (kMax,
 bilinear); with --gpus G the grid is sharded by z-slab across G ranks (one process per GPU,
-no collective in the carve path, so total work is fixed: strong scaling).
+no collective in the carve path, so total work is fixed: strong scaling).  The cuts between the slabs are
+placed where the library's planner predicts equal carve COST for these views (vcy_plan_z_slabs;
+`--partition equal` for slabs of equal thickness).
+
+Timing.  W warm-up steps, then K timed steps between two barriers (device sync + process barrier).  The
+steps of the timed region are QUEUED back to back -- nothing synchronises between two steps; per-step device
+times come from the library's event log afterwards -- and the warm-up is extended until the device has been
+busy for --settle-ms (default 60 ms): an MI355X that idles for a millisecond drops its shader clock and needs
+~40 ms of continuous load to come back (profiles/r04/clock_ramp.txt: the same 1.1 ms slab launch takes 1.29 ms
+cold), so five warm-up steps of an 8-GPU rank (5 ms) would leave that rank timed on the ramp while the one-GPU
+run (40 ms of warm-up) is not.  The JSON line says how many warm-up steps ran ("clock_settle").
 
 `python bench.py --gpus N` works from a plain shell: without WORLD_SIZE in the environment and
 N > 1 the script re-executes itself under `torch.distributed.run --nproc-per-node N` (one process
@@ -21,6 +31,7 @@ import argparse
 import datetime
 import ctypes as C
 import json
+import math
 import os
 import socket
 import subprocess
@@ -52,8 +63,13 @@ def parse(argv=None):
     ap.add_argument("--cull", type=int, default=1,
                     help="1: drop (brick, view) pairs that provably cannot change the brick (results identical)")
     ap.add_argument("--slabs-per-gpu", type=int, default=0,
-                    help="z-slabs per GPU, dealt cyclically (0: 1 on one or two GPUs, 2 on more -- evens out "
-                         "the data-dependent cost of view dropping)")
+                    help="z-slabs per GPU, dealt cyclically (0 = 1: one slab per GPU, cut by predicted cost)")
+    ap.add_argument("--partition", default="planned", choices=["planned", "equal"],
+                    help="where the z-slabs are cut: planned = equal predicted carve cost for these views "
+                         "(vcy_plan_z_slabs), equal = equal thickness")
+    ap.add_argument("--settle-ms", type=float, default=60.0,
+                    help="the warm-up is extended (same step, untimed) until the device has been busy this long: "
+                         "the shader clock needs ~40 ms of continuous load to settle (0: exactly --warmup steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
@@ -95,12 +111,10 @@ def self_launch(args):
 
 
 def default_slabs_per_gpu(n_gpus):
-    """z-slabs per GPU, dealt cyclically.  Two halves of a grid cost the same, so 2 GPUs take one slab each; from 4
-    GPUs on the slabs through the object cost 1.6x the outer ones (view dropping) and every GPU pairs an outer with a
-    central slab.  Measured slab by slab on one GPU (profiles/r03/slab_emulation.txt): 2 GPUs 1.83x (k = 1) against
-    1.71x (k = 2); 4 GPUs 3.02x / 3.23x; 8 GPUs 5.50x / 6.14x; 4 slabs per GPU are behind everywhere (every launch
-    costs about 0.1 ms of window maxima, gaps and ramp)."""
-    return 1 if n_gpus <= 2 else 2
+    """z-slabs per GPU.  One: the cuts are placed where the planner predicts equal cost (vcy_plan_z_slabs), which
+    balances the ranks without the second launch per step that round 3's pairing of an outer with a central slab of
+    equal thickness cost (profiles/r04/slab_emulation.txt: 8 GPUs 7.3x with planned cuts, 6.4x with equal ones)."""
+    return 1
 
 
 def usable_cores():
@@ -265,6 +279,8 @@ def run_inprocess(args, why=None):
         devices = [int(os.environ["VCY_BENCH_FORCE_DEVICE"])] * G
     k = args.slabs_per_gpu if args.slabs_per_gpu > 0 else default_slabs_per_gpu(G)
     sh = ShardedVoxelCarver(opt, devices, k)
+    if args.partition == "planned" and G * k > 1:
+        sh.plan(views, [sdf0] * nv)  # cuts of equal predicted cost (vcy_plan_z_slabs on the first device)
     if not sh.Init():
         raise SystemExit("vcy_create failed: " + vc.last_error())
     sh.set_param("fused", args.batch)
@@ -272,21 +288,31 @@ def run_inprocess(args, why=None):
     # inputs resident in HBM of every device before the timed region
     imgs = [cs[0].upload_sdf(sdf0) for cs in sh.by_device]
     batches = [vc.VoxelCarver.prepare_batch(views, [imgs[g]] * nv) for g in range(G)]
-    sh.carve_batch(batches, steps=args.warmup)
+    warm_steps, warm_ms = 0, 0.0
+    if args.warmup > 0:
+        warm_ms = sh.carve_batch(batches, steps=args.warmup)
+        warm_steps = args.warmup
+        if args.settle_ms > 0 and warm_ms < args.settle_ms:  # until the clocks have settled (see the module docstring)
+            extra = int(math.ceil((args.settle_ms - warm_ms) / (warm_ms / args.warmup)))
+            warm_ms += sh.carve_batch(batches, steps=extra)
+            warm_steps += extra
     wall_ms = sh.carve_batch(batches, steps=args.steps)
-    kernel_ms = list(sh.last_kernel_ms)
+    stats = list(sh.last_stats)
+    kernel_ms = [st["kernel_ms"] for st in stats]
     value = float(n) ** 3 * nv * args.steps / (wall_ms * 1e-3) / 1e6
     bpv = 4.0 if args.mode == "default" else 4.0 + (1 if uo.voxel_max_update_num <= 254 else 2)
     views_per_launch = min(nv, 64) if args.batch else 1
     launches = ((nv + views_per_launch - 1) // views_per_launch) * k
-    slab_vox = float(n) ** 3 / (G * k)
-    avg_launch_ms = max(kernel_ms) / launches
+    slowest = max(range(G), key=lambda g: kernel_ms[g])
+    slab_vox = sum(c.slab_voxels for c in sh.by_device[slowest]) / float(k)
+    avg_launch_ms = kernel_ms[slowest] / launches
     achieved = slab_vox * views_per_launch * bpv / (avg_launch_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "kernel": "carve_fused_kernel" if args.batch else "carve_view_kernel",
                 "avg_launch_ms": round(avg_launch_ms, 4),
-                "note": "per GPU, of the slowest device; algorithmic bytes as in the one-GPU line"}
+                "note": "per GPU, of the device whose carve kernel takes longest; algorithmic bytes as in the one-GPU "
+                        "line (4 B per voxel*view of that device's slab); what binds the kernel: see the one-GPU line"}
     mc = None
     collective = None
     if not args.no_mc:
@@ -316,9 +342,14 @@ def run_inprocess(args, why=None):
                                   % (n, nv, args.width, args.height, args.mode, G),
                       "grid": n, "views": nv, "image": [args.width, args.height], "mode": args.mode,
                       "fused_views_per_launch": views_per_launch, "view_dropping": bool(args.cull),
-                      "slabs_per_gpu": k, "launch": "inprocess", "devices": devices},
+                      "slabs_per_gpu": k, "launch": "inprocess", "devices": devices,
+                      "partition": args.partition if G * k > 1 else "one slab", "plan": sh.plan_info},
+           "clock_settle": {"warmup_steps_run": warm_steps, "warmup_device_ms": round(warm_ms, 2),
+                            "settle_ms": args.settle_ms},
            "roofline": roofline, "mc": mc, "collective": collective,
-           "per_gpu": [{"device": devices[g], "kernel_ms_per_step": round(kernel_ms[g], 3),
+           "per_gpu": [{"device": devices[g], "prepass_ms": round(stats[g]["prepass_ms"], 3),
+                        "kernel_ms": round(stats[g]["kernel_ms"], 3), "idle_ms": round(stats[g]["idle_ms"], 3),
+                        "step_ms": round(stats[g]["period_ms"], 3),
                         "slabs_z": [list(sh.z_ranges[s]) for s in range(g, G * k, G)]} for g in range(G)]}
     if why:
         out["config"]["launch_note"] = why
@@ -442,7 +473,12 @@ def main():
     sdfs = [sdf0] * nv  # every view sees the same centred disc; the cameras differ
 
     k_slabs = args.slabs_per_gpu if args.slabs_per_gpu > 0 else default_slabs_per_gpu(world)
-    my_slabs = vdist.slabs_of_rank(n, rank, world, k_slabs)
+    # where the slabs are cut: equal predicted carve cost for these views (every rank computes the same cuts on its
+    # own GPU from the same inputs: vcy_plan_z_slabs is deterministic), or equal thickness
+    bounds, plan_info = None, None
+    if world * k_slabs > 1 and args.partition == "planned":
+        bounds, _, plan_info = vdist.plan_bounds(opt, local_rank, views, sdfs, world * k_slabs)
+    my_slabs = vdist.slabs_of_rank(n, rank, world, k_slabs, bounds)
 
     def make_carvers(option, cull, slabs):
         out = []
@@ -450,11 +486,10 @@ def main():
             c = vc.VoxelCarver(option, device_id=local_rank, z_range=(z0, z1))
             if not c.Init():
                 raise SystemExit("vcy_create failed: " + vc.last_error())
-            # (every slab on a stream of its own: the second slab's launch fills the tail of the first one's,
-            # 0-5 % per step on a rank's two slabs, profiles/r03/two_slabs_streams.txt)
+            # (every slab on a stream of its own: a second slab's launch fills the tail of the first one's)
             c.set_param("fused", args.batch)
             c.set_param("cull", cull)
-            c.set_param("carvetimer", 1)  # HIP events around the carve kernel itself (vcy_last_carve_ms)
+            c.set_param("carvetimer", 1)  # HIP events around pre-pass and carve kernel of every launch (vcy_carve_log)
             out.append(c)
         return out
 
@@ -462,48 +497,86 @@ def main():
     dev = devs[0]
     d_sdf = [dev.upload_sdf(s) for s in sdfs]  # inputs resident in HBM before the timed region
 
-    def barrier():
-        for c in devs:
+    def sync_all(carvers):
+        for c in carvers:
             c.sync()
+
+    def barrier():
+        sync_all(devs)
         if dist is not None:
             if backend == "nccl":
                 torch.cuda.synchronize()
             dist.barrier()
 
-    def run_steps(carvers, batch, count, record=None):
-        lead = carvers[0]
+    def run_steps(carvers, step, count):
+        """`count` steps queued back to back: nothing synchronises in between (per-step times: the event log)."""
         for _ in range(count):
             for c in carvers:
                 c.reset()
-            if len(carvers) == 1:
-                lead.timer_begin()
-                ok = lead.CarveBatchDevice(batch)
-                ms = lead.timer_end()
-            else:  # several streams: the step is over when the last of them is
-                for c in carvers:
-                    c.sync()
-                t_step = time.perf_counter()
-                ok = all(c.CarveBatchDevice(batch) for c in carvers)
-                for c in carvers:
-                    c.sync()
-                ms = (time.perf_counter() - t_step) * 1e3
-            if not ok:
-                raise SystemExit("carve failed: " + vc.last_error())
-            if record is not None:
-                record.append(ms)
-                parts = [c.last_carve_ms() for c in carvers] if args.batch else [(0.0, ms / len(carvers))] * len(carvers)
-                kernel_only.append(sum(p[1] for p in parts))
-                prepass_only.append(sum(p[0] for p in parts))
+            for c in carvers:
+                if not step(c):
+                    raise SystemExit("carve failed: " + vc.last_error())
 
-    kernel_ms = []      # per step: everything between vcy_timer_begin / _end (pre-pass, window maxima, carve kernel)
-    kernel_only, prepass_only = [], []  # per step: the carve kernel(s) alone / what runs before them
+    def clear_logs(carvers):
+        for c in carvers:
+            c.set_param("carvetimer", 1)
+
+    def read_logs(carvers, steps):
+        """(pre-pass ms, carve kernel ms) per step, summed over the carvers' launches."""
+        pre = ker = 0.0
+        for c in carvers:
+            log = c.carve_log()
+            pre += sum(r[1] for r in log)
+            ker += sum(r[2] for r in log)
+        return pre / max(1, steps), ker / max(1, steps)
+
+    def warm_up(carvers, step, steps, settle_ms):
+        """`steps` warm-up steps, then the same step until the device has been busy for settle_ms (clock settling, see
+        the module docstring).  Returns (steps run, device-busy ms)."""
+        if steps <= 0:
+            return 0, 0.0
+        sync_all(carvers)
+        t = time.perf_counter()
+        run_steps(carvers, step, steps)
+        sync_all(carvers)
+        busy = (time.perf_counter() - t) * 1e3
+        ran = steps
+        if settle_ms > 0 and busy < settle_ms:
+            extra = int(math.ceil((settle_ms - busy) / (busy / steps)))
+            t = time.perf_counter()
+            run_steps(carvers, step, extra)
+            sync_all(carvers)
+            busy += (time.perf_counter() - t) * 1e3
+            ran += extra
+        return ran, busy
+
+    def measure(carvers, step, reps=5, settle_ms=40.0):
+        """Mean ms per step of `reps` steps queued back to back on a warm device (variants, outside the timed region);
+        also (pre-pass, kernel) ms per step from the event log."""
+        warm_up(carvers, step, 1, settle_ms)
+        clear_logs(carvers)
+        sync_all(carvers)
+        t = time.perf_counter()
+        run_steps(carvers, step, reps)
+        sync_all(carvers)
+        ms = (time.perf_counter() - t) * 1e3 / reps
+        pre, ker = read_logs(carvers, reps)
+        return ms, pre, ker
+
     batch = vc.VoxelCarver.prepare_batch(views, d_sdf)
-    run_steps(devs, batch, args.warmup)
+
+    def main_step(c):
+        return c.CarveBatchDevice(batch)
+
+    warm_steps, warm_ms = warm_up(devs, main_step, args.warmup, args.settle_ms)
+    clear_logs(devs)
     barrier()
     t0 = time.perf_counter()
-    run_steps(devs, batch, args.steps, kernel_ms)
+    run_steps(devs, main_step, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    my_elapsed_ms = elapsed * 1e3
+    avg_prepass_ms, avg_kernel_ms = read_logs(devs, args.steps) if args.batch else (0.0, my_elapsed_ms / args.steps)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -511,19 +584,24 @@ def main():
 
     total_vv = float(n) ** 3 * nv * args.steps
     value = total_vv / elapsed / 1e6
-    # per rank: device, kernel time per step (HIP events on its stream) and the z-ranges of its slabs, so that an
-    # imbalance between the ranks is visible in the line
+    # per rank: what its step is made of -- pre-pass (window maxima + footprint records), carve kernel (HIP events on its
+    # stream), and idle = the rest of its step period (launch gaps, host) -- and the z-ranges of its slabs: a bad
+    # scaling curve explains itself (an unbalanced partition shows in kernel_ms, a starved device in idle_ms)
+    my_period = my_elapsed_ms / args.steps
     per_gpu = None
     if dist is not None:
-        row = torch.zeros(world, 2 + 2 * len(my_slabs), dtype=torch.float64, device=red_dev)
+        row = torch.zeros(world, 5 + 2 * len(my_slabs), dtype=torch.float64, device=red_dev)
         row[rank, 0] = float(local_rank)
-        row[rank, 1] = sum(kernel_ms) / max(1, len(kernel_ms))
+        row[rank, 1], row[rank, 2] = avg_prepass_ms, avg_kernel_ms
+        row[rank, 3] = max(0.0, my_period - avg_prepass_ms - avg_kernel_ms)
+        row[rank, 4] = my_period
         for j, (_, z0, z1) in enumerate(my_slabs):
-            row[rank, 2 + 2 * j], row[rank, 3 + 2 * j] = float(z0), float(z1)
+            row[rank, 5 + 2 * j], row[rank, 6 + 2 * j] = float(z0), float(z1)
         dist.all_reduce(row)
         rows = row.cpu().tolist()
-        per_gpu = [{"rank": r, "device": int(rows[r][0]), "kernel_ms_per_step": round(rows[r][1], 3),
-                    "slabs_z": [[int(rows[r][2 + 2 * j]), int(rows[r][3 + 2 * j])] for j in range(len(my_slabs))]}
+        per_gpu = [{"rank": r, "device": int(rows[r][0]), "prepass_ms": round(rows[r][1], 3),
+                    "kernel_ms": round(rows[r][2], 3), "idle_ms": round(rows[r][3], 3), "step_ms": round(rows[r][4], 3),
+                    "slabs_z": [[int(rows[r][5 + 2 * j]), int(rows[r][6 + 2 * j])] for j in range(len(my_slabs))]}
                    for r in range(world)]
 
     # roofline of the dominant kernel (carve), this rank's slab: algorithmic bytes per launch /
@@ -535,12 +613,8 @@ def main():
     FUSED_MAX = 64  # views per fused launch (carve_fused.hip)
     views_per_launch = min(nv, FUSED_MAX) if args.batch else 1
     launches_per_step = ((nv + views_per_launch - 1) // views_per_launch) * len(devs)
-    n_rec = len(kernel_ms)
-    avg_launch_ms = sum(kernel_only[:n_rec]) / n_rec / launches_per_step  # the dominant kernel alone, HIP events
-    if avg_launch_ms <= 0.0:  # (a library without the carve timer, e.g. an older kernel linked in for an A/B run)
-        avg_launch_ms = sum(kernel_ms) / n_rec / launches_per_step
-    avg_step_device_ms = sum(kernel_ms) / n_rec
-    avg_prepass_ms = sum(prepass_only[:n_rec]) / n_rec
+    avg_launch_ms = avg_kernel_ms / launches_per_step  # the dominant kernel alone, HIP events around it
+    avg_step_device_ms = my_period
     alg_bytes = slab_vox * views_per_launch * bytes_per_vv(args.mode, uo)
     achieved = alg_bytes / (avg_launch_ms * 1e-3) / 1e9
     ckey = "%s_%d_%d_b%d_c%d" % (args.mode, n, nv, args.batch, args.cull)
@@ -573,7 +647,12 @@ def main():
         roofline["traffic_note"] = "carve_fused_kernel alone; the footprint pre-pass moves another %s B per step" % (
             ctr.get("prepass_hbm_bytes_per_launch", "?"))
     vcyc = valu_issue_cycles(ctr)
+    roofline["bound_contract"] = "hbm: achieved / peak / frac are SURVEY 8(d)'s algorithmic HBM figures (the contract's definition)"
     if vcyc:
+        # what binds the kernel is VALU issue, not HBM (hbm_real_frac ~ 0.13): `bound` names that roof and frac_binding is
+        # the kernel's distance from it -- the measured issue floor where the control flow does not depend on the data
+        # (cull 0, TSDF), the flat 2-cycle issue fraction for the default workload
+        roofline["bound"] = "valu"
         roofline["bound_actual"] = "valu"
         # against the shader clock the profiled launch really ran at (GRBM_GUI_ACTIVE counts the busy cycles of each
         # of the 8 XCDs over the launch; 2.4 GHz is the boost clock)
@@ -587,9 +666,17 @@ def main():
         roofline["valu_wave_insts_per_launch"] = ctr["SQ_INSTS_VALU"]
         roofline["valu_insts_per_voxel_view"] = round(ctr["SQ_INSTS_VALU"] * 64.0 / (slab_vox * views_per_launch), 3)
         roofline["counters_source"] = ctr.get("source")
+        roofline["frac_binding"] = roofline["valu_issue_frac_flat2"]
+        roofline["frac_binding_note"] = ("VALU issue cycles (2 per wave instruction) / SIMD cycles of the launch, counters "
+                                         "and shader clock of the PROFILED box (shader_clock_ghz_profiled: GRBM_GUI_ACTIVE "
+                                         "cannot be read live and a probe kernel would not run at the carve kernel's clock)")
     floor, _ = load_counters("issue_floor", build) if world == 1 else (None, None)
     if floor:
         roofline["issue_floor"] = {k: floor[k] for k in floor if k not in ("build",)}
+        key = {"default": None, "tsdf": "tsdf"}.get(args.mode) if args.cull else "cull0"
+        if key and isinstance(floor.get(key), (int, float)):
+            roofline["frac_binding"] = floor[key]
+            roofline["frac_binding_note"] = "measured: this kernel's rate / the rate of its own instruction stream without tile loads and stores"
     # marching cubes (second half of the metric), outside the timed region
     mc = None
     collective = {"backend": "none", "ranks": world, "bytes_per_rank": 0, "note": "one slab: nothing to exchange"}
@@ -664,9 +751,43 @@ def main():
 
     # the same kernel without view dropping and in TSDF mode (weighted average + truncation), measured in
     # the same run so that the headline's dependence on the scene is visible in the driver's record
+    def pairs_of(c, step):
+        """Fraction of the (8^3 brick, view) pairs one step really processes (the rest is dropped as provably idle)."""
+        c.set_param("paircount", 1)
+        c.reset()
+        proc = tot = 0
+        for st in (step if isinstance(step, (list, tuple)) else [step]):
+            if not st(c):
+                raise RuntimeError(vc.last_error())
+            a, b, _ = c.last_carve_pairs()
+            proc, tot = proc + a, tot + b
+        c.set_param("paircount", 0)
+        return round(proc / float(tot), 4) if tot else None
+
+    pairs_main = None
+    if world == 1 and args.batch:
+        try:
+            pairs_main = pairs_of(dev, main_step)
+        except Exception as e:
+            pairs_main = "%s: %s" % (type(e).__name__, e)
+
+    # The same library in other modes, on another scene and through its other entry points, measured in the same run
+    # (warm device, steps queued back to back) so that the headline's dependence on scene and call pattern is in the
+    # driver's record.
     variants = None
     if world == 1 and not args.no_variants and args.batch:
         variants = {}
+
+        def rate_record(ms, pre, ker, mode, u, extra=None):
+            bpv = bytes_per_vv(mode, u)
+            rec = {"value": round(float(n) ** 3 * nv / (ms * 1e-3) / 1e6, 1), "unit": "Mvoxel*views/s",
+                   "ms_per_step": round(ms, 3), "prepass_ms": round(pre, 3), "kernel_ms": round(ker, 3), "mode": mode,
+                   "algorithmic_frac": round(float(n) ** 3 * nv * bpv / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "algorithmic_frac_kernel_alone": round(float(n) ** 3 * nv * bpv / (ker * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                   if ker > 0 else None}
+            rec.update(extra or {})
+            return rec
+
         for name, mode, cull in (("cull0", args.mode, 0), ("tsdf", "tsdf", 1)):
             if mode == args.mode and cull == args.cull:
                 continue
@@ -680,16 +801,8 @@ def main():
                     p = cs[0].upload_sdf(s2)
                     dsdf2, own = [p] * nv, True
                 b2 = vc.VoxelCarver.prepare_batch(views, dsdf2)
-                ms2 = []
-                run_steps(cs, b2, 1)
-                run_steps(cs, b2, 3, ms2)
-                avg = sum(ms2) / len(ms2)
-                bpv = bytes_per_vv(mode, u2)
-                variants[name] = {"value": round(float(n) ** 3 * nv / (avg * 1e-3) / 1e6, 1),
-                                  "unit": "Mvoxel*views/s", "ms_per_step": round(avg, 3), "mode": mode,
-                                  "view_dropping": bool(cull),
-                                  "algorithmic_frac": round(float(n) ** 3 * nv * bpv / (avg * 1e-3) / 1e9
-                                                            / HBM_PEAK_GBS, 4)}
+                ms, pre, ker = measure(cs, lambda c: c.CarveBatchDevice(b2), reps=3)
+                variants[name] = rate_record(ms, pre, ker, mode, u2, {"view_dropping": bool(cull)})
                 if own:
                     cs[0].free_device(dsdf2[0])
                 for c in reversed(cs):
@@ -698,39 +811,82 @@ def main():
                 variants[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         roofline["value_cull0"] = variants.get("cull0", {}).get("value")
         roofline["value_tsdf"] = variants.get("tsdf", {}).get("value")
+        # a figure <= 1 that follows from SURVEY 8(d)'s formula: every voxel*view evaluated (no view dropping), the carve
+        # kernel alone
+        roofline["frac_every_voxel_view"] = variants.get("cull0", {}).get("algorithmic_frac_kernel_alone")
+
+        # (a) a harder scene: two overlapping off-centre spheres, a DISTINCT silhouette and SDF image per view, same
+        #     grid, cameras and image size; (b) the views in two batches of V/2: the second launch reads a carved state
+        #     (6.4 GB at 1024^3) instead of starting from a fresh grid.  voxel_carver.cc:442-491 costs the same whatever
+        #     the scene; this path does not, and the line says by how much.
+        try:
+            cs = make_carvers(opt, args.cull, my_slabs)
+            c0 = cs[0]
+            hv, hm = synth.blob_views(n, nv, args.width, args.height)
+            himg = [c0.make_sdf_device(m, use_truncation=bool(uo.use_truncation), band=uo.truncation_band) for m in hm]
+            hb = vc.VoxelCarver.prepare_batch(hv, himg)
+            ms, pre, ker = measure(cs, lambda c: c.CarveBatchDevice(hb), reps=5)
+            variants["hard_scene"] = rate_record(ms, pre, ker, args.mode, uo, {
+                "scene": "two overlapping off-centre spheres (radii 0.24 N and 0.17 N), %d distinct SDF images" % nv,
+                "pairs_processed_frac": pairs_of(c0, lambda c: c.CarveBatchDevice(hb))})
+            for pimg in himg:
+                c0.free_device(pimg)
+            half = nv // 2
+            ba = vc.VoxelCarver.prepare_batch(views[:half], d_sdf[:half])
+            bb = vc.VoxelCarver.prepare_batch(views[half:], d_sdf[half:])
+            ms, pre, ker = measure(cs, lambda c: c.CarveBatchDevice(ba) and c.CarveBatchDevice(bb), reps=5)
+            variants["two_batches"] = rate_record(ms, pre, ker, args.mode, uo, {
+                "batches": [half, nv - half],
+                "pairs_processed_frac": pairs_of(c0, [lambda c: c.CarveBatchDevice(ba), lambda c: c.CarveBatchDevice(bb)])})
+            for c in reversed(cs):
+                c.close()
+        except Exception as e:
+            variants.setdefault("hard_scene", {"error": "%s: %s" % (type(e).__name__, e)})
+            variants.setdefault("two_batches", {"error": "%s: %s" % (type(e).__name__, e)})
+
         # The reference's own call pattern (examples.cc:117-149): `for each view: Carve(one view); ExtractIsoSurface()`.
         # An extraction between two views means every view is a launch of its own (nothing to fuse across): the
         # single-view path, where a wave drops its view against the brick minimum the previous launch left
         # before it reads any state.  "defer" 0 so that the carve is timed by itself (HIP events around each call);
-        # per_view_defer0 is the same loop without the extractions.
-        for name, extract in (("per_view_interleaved", True), ("per_view_defer0", False)):
+        # per_view_defer0 is the same loop without the extractions, per_view_tsdf that loop in TSDF mode
+        # (VoxelUpdate::kWeightedAverage + truncation: every view changes nearly every brick).
+        for name, extract, mode in (("per_view_interleaved", True, args.mode), ("per_view_defer0", False, args.mode),
+                                    ("per_view_tsdf", False, "tsdf")):
+            if name == "per_view_tsdf" and args.mode == "tsdf":
+                continue
             try:
-                cs = make_carvers(opt, args.cull, my_slabs)
+                u2 = update_option(mode)
+                cs = make_carvers(synth.sphere_option(n, u2), args.cull, my_slabs)
                 c0 = cs[0]
                 c0.set_param("defer", 0)
                 c0.set_param("meshkeys", 0)
+                if mode == args.mode:
+                    dimg, own = d_sdf, False
+                else:
+                    s2 = vc.make_sdf(masks[0], use_truncation=bool(u2.use_truncation), band=u2.truncation_band)
+                    dimg, own = [c0.upload_sdf(s2)] * nv, True
                 carve_ms, mc_dev, mc_wall, t_wall = [], [], [], None
-                for rep in range(2):  # the second pass is the one reported (buffers allocated, sizes guessed)
+                for rep in range(2):  # the second pass is the one reported (buffers allocated, sizes guessed, clocks up)
                     c0.reset()
                     carve_ms, mc_dev, mc_wall = [], [], []
+                    c0.set_param("carvetimer", 1)
                     c0.sync()
                     tw = time.perf_counter()
                     for i in range(nv):
-                        c0.timer_begin()
-                        if not c0.CarveDevice(views[i], d_sdf[i]):
+                        if not c0.CarveDevice(views[i], dimg[i]):
                             raise RuntimeError(vc.last_error())
-                        carve_ms.append(c0.timer_end())
                         if extract:
                             mesh = c0.ExtractIsoSurface(0.0, True)
                             mc_dev.append(mesh["device_ms"])
                             mc_wall.append(mesh["wall_ms"])
                     c0.sync()
                     t_wall = (time.perf_counter() - tw) * 1e3
+                    carve_ms = [r[1] + r[2] for r in c0.carve_log()]  # per launch: pre-pass + kernel (no sync between views)
                 tot = sum(carve_ms)
-                rec = {"value": round(float(n) ** 3 * nv / (tot * 1e-3) / 1e6, 1), "unit": "Mvoxel*views/s",
+                rec = {"value": round(float(n) ** 3 * nv / (tot * 1e-3) / 1e6, 1), "unit": "Mvoxel*views/s", "mode": mode,
                        "carve_ms_total": round(tot, 3), "carve_ms_first_view": round(carve_ms[0], 3),
                        "carve_ms_per_view_after_first": round((tot - carve_ms[0]) / max(1, nv - 1), 3),
-                       "algorithmic_frac": round(float(n) ** 3 * nv * bytes_per_vv(args.mode, uo) / (tot * 1e-3) / 1e9
+                       "algorithmic_frac": round(float(n) ** 3 * nv * bytes_per_vv(mode, u2) / (tot * 1e-3) / 1e9
                                                  / HBM_PEAK_GBS, 4),
                        "loop_wall_ms": round(t_wall, 2), "launches": nv, "defer": 0}
                 if extract:
@@ -740,10 +896,41 @@ def main():
                     rec["mc_wall_ms_median"] = round(sorted(mc_wall)[len(mc_wall) // 2], 3)
                     rec["mc_mcells_per_s"] = round(cells / (med * 1e-3) / 1e6, 1)
                 variants[name] = rec
+                if own:
+                    c0.free_device(dimg[0])
                 for c in reversed(cs):
                     c.close()
             except Exception as e:
                 variants[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+        # The streamed entry point (BASELINE configs[4]: "streamed per-view SDF upload overlapped with fuse"; replaces
+        # Carve(vector<Camera>, vector<Image1b>), voxel_carver.cc:516-528 around :394-413): silhouettes in HOST memory ->
+        # page-locked staging -> DMA -> SDF build on the device -> fused carve, in chunks of 32 views with chunk i + 1
+        # produced while chunk i is carved.  Wall time of the call (PCIe inclusive: never `value`).
+        try:
+            cs = make_carvers(opt, args.cull, my_slabs)
+            c0 = cs[0]
+            walls = []
+            for rep in range(4):
+                c0.reset()
+                c0.sync()
+                tw = time.perf_counter()
+                if not c0.CarveBatchSilhouettes(views, masks):
+                    raise RuntimeError(vc.last_error())
+                walls.append(((time.perf_counter() - tw) * 1e3,) + c0.last_stream_ms())
+            wall, prod, carve, wall_lib = sorted(walls[1:])[len(walls[1:]) // 2]
+            variants["streamed_silhouettes"] = {
+                "wall_ms": round(wall, 3), "producer_ms": round(prod, 3), "carve_ms": round(carve, 3),
+                "overlap": round(max(prod, carve) / wall_lib, 4), "chunks": (nv + 31) // 32,
+                "value_pcie_inclusive": round(float(n) ** 3 * nv / (wall * 1e-3) / 1e6, 1), "unit": "Mvoxel*views/s",
+                "note": "vcy_carve_batch_silhouettes from pageable host masks; producer = staging copy + H2D + device SDF "
+                        "build per chunk of 32 views, carve = the fused launches; overlap = max(producer, carve) / wall: "
+                        "1.0 when the shorter side is hidden completely; with a single chunk (<= 32 views) nothing can "
+                        "overlap and overlap = the longer side's share of the wall time"}
+            for c in reversed(cs):
+                c.close()
+        except Exception as e:
+            variants["streamed_silhouettes"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     out = {
         "metric": "Mvoxel*views/s (Carve)", "value": round(value, 1), "unit": "Mvoxel*views/s",
@@ -754,9 +941,14 @@ def main():
                                % (n, nv, args.width, args.height, args.mode, world),
                    "grid": n, "views": nv, "image": [args.width, args.height], "mode": args.mode,
                    "fused_views_per_launch": views_per_launch, "view_dropping": bool(args.cull),
-                   "slabs_per_gpu": k_slabs,
+                   "slabs_per_gpu": k_slabs, "partition": args.partition if world * k_slabs > 1 else "one slab",
+                   "plan": plan_info, "pairs_processed_frac": pairs_main,
                    "division": {2: "rcp + 3 (verified for this focal length)", 1: "rcp + 5 (verified)",
                                 0: "full IEEE expansion"}.get(dev.get_param("div_level"), "?")},
+        "clock_settle": {"warmup_steps_run": warm_steps, "warmup_device_ms": round(warm_ms, 2),
+                         "settle_ms": args.settle_ms,
+                         "note": "the warm-up runs --warmup steps and then the same step until the device has been busy "
+                                 "for settle_ms: an idle MI355X needs ~40 ms of continuous load to settle its clocks"},
         "roofline": roofline, "mc": mc, "collective": collective,
     }
     if per_gpu is not None:

@@ -152,6 +152,12 @@ int vcy_carve_silhouette(vcy_ctx* ctx, const vcy_view* view,
 int vcy_carve_batch_silhouettes(vcy_ctx* ctx, int n_views, const vcy_view* views,
                                 const uint8_t* const* masks_host);
 
+/* Of the last vcy_carve_batch_silhouettes: milliseconds its producer side took (per chunk of 32 views: the copy of the
+ * silhouettes into page-locked staging, their DMA and the SDF build, events on the producer stream), its consumer
+ * side (the fused carve launches, events on the context's stream), both summed over the chunks, and the call's wall
+ * time.  max(produce, carve) / wall says how much of the shorter side was hidden behind the longer. */
+int vcy_last_stream_ms(vcy_ctx* ctx, float* produce_ms, float* carve_ms, float* wall_ms);
+
 /* Replaces void DistanceTransformL1(...) (voxel_carver.cc:102-167). */
 int vcy_distance_transform_l1(const uint8_t* mask, int width, int height,
                               const int32_t roi_min[2], const int32_t roi_max[2],

@@ -1016,3 +1016,98 @@ def test_brick_minima_after_writes_that_bypass_the_fused_kernel(kw):
         assert_state_equal(dev, orc, "%s first_fused=%s, later views" % (kw, first_fused))
         assert_mesh_equal(dev.ExtractIsoSurface(0.0, True), orc.marching_cubes(0.0, True), "%s later" % (kw,))
         dev.close()
+
+
+def test_slab_planner_estimate_and_planned_cuts():
+    """vcy_plan_z_slabs: (1) its per-layer estimate of the (brick, view) pairs a carve will process follows what the
+    kernel really processes ("paircount"); with view dropping off every pair is processed and every layer costs the
+    same; (2) the cuts are whole brick layers, cover the grid, and slabs carved with them merge into the whole grid's
+    mesh array for array; (3) the same inputs give the same cuts again."""
+    n, nv, w, h = 128, 12, 320, 240
+    opt = synth.sphere_option(n)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    sdf = O.make_sdf(masks[0])
+    whole = vc.VoxelCarver(opt)
+    assert whole.Init(), vc.last_error()
+    d = whole.upload_sdf(sdf)
+    batch = vc.VoxelCarver.prepare_batch(views, [d] * nv)
+    whole.set_param("paircount", 1)
+    assert whole.CarveBatchDevice(batch), vc.last_error()
+    proc, total, per_layer = whole.last_carve_pairs()
+    assert total == (n // 8) ** 3 * nv and 0 < proc < total and per_layer.sum() == proc and len(per_layer) == n // 8
+    planner = vc.VoxelCarver(opt, z_range=(0, 8))
+    assert planner.Init(), vc.last_error()
+    bounds, cost = planner.plan_z_slabs(batch, None, 4, stride=1, brick_cost=1e-9)   # (the pairs alone)
+    assert len(cost) == n // 8
+    assert np.corrcoef(cost, per_layer)[0, 1] > 0.97, (cost, per_layer)
+    assert 0.9 * proc < cost.sum() < 1.4 * proc          # an over-estimate by construction (lower bounds of the minima)
+    assert bounds[0] == 0 and bounds[-1] == n and all(b % 8 == 0 for b in bounds) and sorted(set(bounds)) == bounds
+    assert planner.plan_z_slabs(batch, None, 4, stride=1, brick_cost=1e-9)[0] == bounds
+    b2, c2 = planner.plan_z_slabs(batch, None, 4)        # default stride and brick cost
+    parts = [c2[b2[s] // 8:b2[s + 1] // 8].sum() for s in range(4)]
+    eq = [c2[s * 4:(s + 1) * 4].sum() for s in range(4)]
+    assert max(parts) <= max(eq) + 1e-9                  # never worse than equal thickness, by its own model
+    # (the object is in the middle: the planned outer slabs are thicker than the inner ones)
+    assert b2[1] - b2[0] >= b2[2] - b2[1]
+    planner.set_param("cull", 0)
+    _, flat = planner.plan_z_slabs(batch, None, 4, stride=1, brick_cost=1e-9)
+    assert np.all(flat == flat[0]) and abs(flat[0] - (n // 8) ** 2 * nv) < 1e-3
+    with pytest.raises(RuntimeError):
+        planner.plan_z_slabs(batch, None, n // 8 + 1)
+    planner.close()
+    # slabs with the planned cuts: state and merged mesh equal the whole grid's
+    from vacancy_amd import dist as vdist
+    slabs = []
+    for s in range(4):
+        c = vc.VoxelCarver(opt, z_range=(b2[s], b2[s + 1]))
+        assert c.Init(), vc.last_error()
+        assert c.CarveBatchDevice(batch), vc.last_error()
+        slabs.append(c)
+    ws, wu = whole.download()
+    assert np.array_equal(np.concatenate([c.download()[0] for c in slabs]).view(np.uint32), ws.view(np.uint32))
+    assert np.array_equal(np.concatenate([c.download()[1] for c in slabs]), wu)
+    vc.halo_exchange(slabs)
+    merged = vdist.merge_meshes([c.ExtractIsoSurface(0.0, True) for c in slabs])
+    ref = whole.ExtractIsoSurface(0.0, True)
+    assert np.array_equal(merged["vertices"].view(np.uint32), ref["vertices"].view(np.uint32))
+    assert np.array_equal(merged["faces"], ref["faces"]) and np.array_equal(merged["keys"], ref["keys"])
+    # with view dropping off the kernel processes every pair
+    whole.set_param("cull", 0)
+    whole.reset()
+    assert whole.CarveBatchDevice(batch)
+    proc0, total0, _ = whole.last_carve_pairs()
+    assert proc0 == total0 == total
+    for c in slabs:
+        c.close()
+    whole.free_device(d)
+    whole.close()
+
+
+def test_carve_log_records_queued_steps_without_synchronising():
+    """"carvetimer": one record per chunk of every fused launch, read after the fact (vcy_carve_log); setting the
+    parameter clears the log; vcy_last_carve_ms is the last launch's sum."""
+    n, nv, w, h = 64, 6, 160, 120
+    opt = synth.sphere_option(n)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init(), vc.last_error()
+    d = dev.upload_sdf(O.make_sdf(masks[0]))
+    batch = vc.VoxelCarver.prepare_batch(views, [d] * nv)
+    dev.set_param("carvetimer", 1)
+    for _ in range(5):
+        dev.reset()
+        assert dev.CarveBatchDevice(batch)
+    log = dev.carve_log(clear=False)
+    assert len(log) == 5 and all(r[3] == 1 for r in log) and log[0][0] == 0.0
+    assert all(b[0] >= a[0] + a[1] + a[2] - 1e-3 for a, b in zip(log, log[1:]))   # launches follow each other
+    pre, ker = dev.last_carve_ms()
+    assert abs(pre - log[-1][1]) < 1e-6 and abs(ker - log[-1][2]) < 1e-6 and ker > 0
+    dev.set_param("recordbytes", 600)   # several chunks per launch
+    dev.set_param("carvetimer", 1)
+    dev.reset()
+    assert dev.CarveBatchDevice(batch)
+    log = dev.carve_log()
+    assert len(log) > 1 and log[0][3] == 1 and all(r[3] == 0 for r in log[1:])
+    assert dev.carve_log() == []
+    dev.free_device(d)
+    dev.close()

@@ -101,6 +101,12 @@ class VoxelCarver:
         ptrs = (C.c_void_p * n)(*[m.ctypes.data for m in masks])
         return self._lib.vcy_carve_batch_silhouettes(self._ctx, n, arr, ptrs) == 0
 
+    def last_stream_ms(self):
+        """(producer ms, carve ms, wall ms) of the last CarveBatchSilhouettes (vcy_last_stream_ms)."""
+        a, b, w = C.c_float(), C.c_float(), C.c_float()
+        assert self._lib.vcy_last_stream_ms(self._ctx, C.byref(a), C.byref(b), C.byref(w)) == 0, last_error()
+        return a.value, b.value, w.value
+
     def download_voxels(self, ids):
         ids = np.ascontiguousarray(ids, np.int64)
         s = np.empty(len(ids), np.float32)

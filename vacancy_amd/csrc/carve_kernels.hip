@@ -249,7 +249,11 @@ int launch_carve(vcy_ctx* c, int n_views, const vcy_view* views, const float* co
 // whole brick layers (8 slices): a slab that ends inside a layer pays that layer's waves in full, and so does the next.
 // cost(layer) = brick_cost * bricks + estimated (brick, view) pairs processed (plan_layer_pairs); the contiguous
 // partition that minimises the largest part -- and, among those, the sum of squares -- by dynamic programming.
-constexpr float kPlanBrickCost = 2.0f;  // a wave's fixed work (record, state, write-back) in units of one processed view
+// A wave's fixed work (record, state, write-back) in units of one ESTIMATED processed view: a least-squares fit of
+// step time = fixed + a * bricks + b * estimated pairs over 23 slabs of 64 ... 1024 slices of the benchmark scene at
+// steady clocks gives a / b = 2.54 (2.11 against the pairs really processed; the estimate runs 12 % high), a fixed
+// 0.04 ms per launch, and the model within 2.5 % of every slab (profiles/r04/planner_fit.txt).
+constexpr float kPlanBrickCost = 2.55f;
 int plan_z_slabs(vcy_ctx* c, int n_views, const vcy_view* views, const float* const* sdf_dev, int n_slabs, int stride,
                  float brick_cost, int32_t* z_bounds, double* layer_cost, int max_layers, int* n_layers) {
   const int L = (c->nz + 7) / 8;

@@ -368,6 +368,7 @@ void vcy_destroy(vcy_ctx* c) {
   (void)hipFree(c->d_records);
   (void)hipFree(c->d_wg_list);
   (void)hipFree(c->d_pair_count);
+  for (hipEvent_t ev : c->stream_events) (void)hipEventDestroy(ev);
   if (c->h_live_hint) (void)hipHostFree(c->h_live_hint);
   for (auto& st : c->carve_log)
     for (int k = 0; k < 3; ++k)
@@ -601,6 +602,21 @@ int vcy_plan_z_slabs(vcy_ctx* c, int n_views, const vcy_view* views, const float
   VCY_HIP_CHECK(hipSetDevice(c->device));
   return plan_z_slabs(c, n_views, views, sdf_device, n_slabs, sample_stride, brick_cost, z_bounds, layer_cost,
                       max_layers, n_layers);
+}
+
+int vcy_last_stream_ms(vcy_ctx* c, float* produce_ms, float* carve_ms, float* wall_ms) {
+  if (!c || !produce_ms || !carve_ms || !wall_ms) return VCY_ERR_INVALID_ARG;
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  *produce_ms = *carve_ms = 0.0f;
+  for (int ci = 0; ci < c->stream_timed_chunks; ++ci) {
+    float a = 0.0f, b = 0.0f;
+    VCY_HIP_CHECK(hipEventElapsedTime(&a, c->stream_events[(size_t)4 * ci + 0], c->stream_events[(size_t)4 * ci + 1]));
+    VCY_HIP_CHECK(hipEventElapsedTime(&b, c->stream_events[(size_t)4 * ci + 2], c->stream_events[(size_t)4 * ci + 3]));
+    *produce_ms += a;
+    *carve_ms += b;
+  }
+  *wall_ms = c->stream_wall_ms;
+  return VCY_OK;
 }
 
 int vcy_selftest(vcy_ctx* c) {
@@ -1134,6 +1150,16 @@ int vcy_carve_batch_silhouettes(vcy_ctx* c, int n_views, const vcy_view* views,
     if (rc != VCY_OK) return rc;
   }
   hipStream_t aux = c->aux_stream;
+  // timing of the two sides (vcy_last_stream_ms): per chunk, events around its production (staging copy, H2D, SDF
+  // build; on the producer stream) and around its carve (on the context's stream)
+  const auto t_entry = std::chrono::steady_clock::now();
+  const int n_chunks_t = (n_views + chunk - 1) / chunk;
+  while ((int)c->stream_events.size() < 4 * n_chunks_t) {
+    hipEvent_t ev = nullptr;
+    if (fail_hip(hipEventCreate(&ev), "hipEventCreate")) return rc;
+    c->stream_events.push_back(ev);
+  }
+  c->stream_timed_chunks = 0;
   char* pool = (char*)c->d_stream_pool;
   char* scratch = pool + 2 * per_set * (sz_sdf + sz_mask);
   auto sdf_buf = [&](int set, int j) { return (float*)(pool + ((size_t)set * per_set + j) * sz_sdf); };
@@ -1155,6 +1181,7 @@ int vcy_carve_batch_silhouettes(vcy_ctx* c, int n_views, const vcy_view* views,
       mptr[j] = mask_buf(set, j);
       optr[j] = sdf_buf(set, j);
     }
+    fail_hip(hipEventRecord(c->stream_events[(size_t)4 * ci + 0], aux), "hipEventRecord");
     // host threads: copy silhouette j into the staging buffer, then queue its DMA
     const int n_thr = std::max(1, std::min(m, std::min(4, (int)std::thread::hardware_concurrency())));
     std::vector<hipError_t> terr((size_t)n_thr, hipSuccess);
@@ -1182,6 +1209,7 @@ int vcy_carve_batch_silhouettes(vcy_ctx* c, int n_views, const vcy_view* views,
                                      u.use_truncation != 0, u.truncation_band, scratch, sz_scr, optr.data());
       if (r2 != VCY_OK) rc = r2;
     }
+    fail_hip(hipEventRecord(c->stream_events[(size_t)4 * ci + 1], aux), "hipEventRecord");
     fail_hip(hipEventRecord(c->ev_ready[set], aux), "hipEventRecord");
   };
   if (rc == VCY_OK) produce(0);
@@ -1192,12 +1220,16 @@ int vcy_carve_batch_silhouettes(vcy_ctx* c, int n_views, const vcy_view* views,
     fail_hip(hipStreamWaitEvent(c->stream, c->ev_ready[set], 0), "hipStreamWaitEvent");
     std::vector<const float*> ptrs(m);
     for (int j = 0; j < m; ++j) ptrs[j] = sdf_buf(set, j);
+    fail_hip(hipEventRecord(c->stream_events[(size_t)4 * ci + 2], c->stream), "hipEventRecord");
     int r2 = launch_carve(c, m, views + first, ptrs.data());
     if (r2 != VCY_OK) rc = r2;
+    fail_hip(hipEventRecord(c->stream_events[(size_t)4 * ci + 3], c->stream), "hipEventRecord");
     fail_hip(hipEventRecord(c->ev_consumed[set], c->stream), "hipEventRecord");
+    if (rc == VCY_OK) c->stream_timed_chunks = ci + 1;
   }
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(aux);
+  c->stream_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
   return rc;
 }
 

@@ -134,6 +134,9 @@ struct vcy_ctx {
   size_t stream_pool_bytes = 0;
   hipStream_t aux_stream = nullptr;   // producer stream of the streamed batch (uploads + SDF build)
   hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr}, ev_uploaded[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> stream_events;  // four per chunk of the last streamed batch (vcy_last_stream_ms)
+  int stream_timed_chunks = 0;
+  float stream_wall_ms = 0.0f;
   void* h_pinned = nullptr;           // page-locked staging of the silhouettes, two sets
   size_t pinned_bytes = 0;
   void* d_mc_tables = nullptr;        // marching-cubes case tables (mc_kernels.hip)
