@@ -47,7 +47,7 @@ def plan_bounds(option, device_id, views, sdf_host_images, count, stride=0, bric
     t0 = time.perf_counter()
     p = vc.VoxelCarver(option, device_id=device_id, z_range=(0, 8))
     if not p.Init():
-        raise RuntimeError("vcy_create (planning context) failed: " + vc.last_error())
+        raise RuntimeError("vcy_create failed (planning context): " + vc.last_error())
     try:
         uniq, ptrs = {}, []
         for img in sdf_host_images:  # (the same array object for several views is uploaded once)
