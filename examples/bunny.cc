@@ -46,6 +46,7 @@ int main(int argc, char* argv[]) {
   const std::string out_dir = argc > 2 ? argv[2] : data_dir;
   const float resolution = argc > 3 ? (float)std::atof(argv[3]) : 10.0f;
   const int n_slabs = argc > 4 ? std::atoi(argv[4]) : 0;
+  const bool planned = argc > 5 && std::string(argv[5]) == "planned";
   std::vector<Eigen::Affine3d> poses;
   if (!LoadTumPoses(data_dir + "/tumpose.txt", &poses)) return 1;
 
@@ -64,7 +65,22 @@ int main(int argc, char* argv[]) {
   std::unique_ptr<vacancy::ShardedVoxelCarver> sharded;
   if (n_slabs > 0) {
     sharded.reset(new vacancy::ShardedVoxelCarver(option, {0}, n_slabs));
+    if (planned) {  // cuts of equal predicted cost for the six views about to be carved (vcy_plan_z_slabs)
+      std::vector<std::shared_ptr<vacancy::PinholeCamera>> cams;
+      std::vector<const vacancy::Camera*> cam_ptrs;
+      std::vector<vacancy::Image1b> sils(poses.size() < 6 ? poses.size() : 6);
+      for (size_t i = 0; i < sils.size(); ++i) {
+        cams.push_back(std::make_shared<vacancy::PinholeCamera>(320, 240, poses[i], Eigen::Vector2f(159.3f, 127.65f),
+                                                                Eigen::Vector2f(258.65f, 258.25f)));
+        cam_ptrs.push_back(cams.back().get());
+        if (!sils[i].Load(data_dir + "/mask_" + vacancy::zfill(i) + ".png")) return 3;
+      }
+      if (!sharded->PlanPartition(cam_ptrs, sils)) return 8;
+    }
     if (!sharded->Init()) return 5;
+    std::printf("BOUNDS");
+    for (int z : sharded->z_bounds()) std::printf(" %d", z);
+    std::printf("\n");
   }
 
   const int width = 320, height = 240;

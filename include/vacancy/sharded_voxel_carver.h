@@ -1,7 +1,9 @@
 // ShardedVoxelCarver: the VoxelCarver API over several GPUs of one node from ONE process.
 //
-// The grid is cut into z-slabs (k per device, dealt cyclically so that slabs near the object and
-// empty ones mix on every device); carving needs no exchange, extraction needs the two slices below
+// The grid is cut into z-slabs (k per device, dealt cyclically; one per device by default).  Where it is cut
+// matters: with view dropping the slabs through the object cost 1.6x the outer ones, so PlanPartition() places
+// the cuts where a carve of the given views is predicted to cost every slab the same (vcy_plan_z_slabs);
+// without it the slabs are of equal thickness.  Carving needs no exchange, extraction needs the two slices below
 // each slab -- ONE RCCL all-gather of every slab's boundary slices (vcy_halo_allgather: one
 // communicator rank per device, ncclCommInitAll) -- and the per-slab meshes are stitched by edge key
 // into exactly the mesh a single VoxelCarver returns.  (The one-process-per-GPU form of the same
@@ -17,11 +19,19 @@ namespace vacancy {
 
 class ShardedVoxelCarver {
  public:
-  ShardedVoxelCarver(VoxelCarverOption option, std::vector<int> device_ids, int slabs_per_device = 2);
+  ShardedVoxelCarver(VoxelCarverOption option, std::vector<int> device_ids, int slabs_per_device = 1);
   ~ShardedVoxelCarver();
   ShardedVoxelCarver(const ShardedVoxelCarver&) = delete;
   ShardedVoxelCarver& operator=(const ShardedVoxelCarver&) = delete;
 
+  // Before Init(): cuts of equal predicted carve cost for these views (a small planning context on the first
+  // device builds their SDF images and plays the kernel's drop decisions per brick layer; about a millisecond
+  // at 1024^3 x 32 views).  The views carved later need not be these -- a camera rig that stays put is the case it
+  // is made for.  false (and equal thickness at Init) if the plan cannot be made.
+  bool PlanPartition(const std::vector<const Camera*>& cameras, const std::vector<Image1b>& silhouettes);
+  // ... or cuts from elsewhere: slab_count + 1 increasing z values from 0 to nz, every slab >= 2 slices.
+  void set_z_bounds(const std::vector<int>& z_bounds);
+  const std::vector<int>& z_bounds() const;  // of the slabs Init() created
   bool Init();
   int slab_count() const;
   // how the halo slices travel before extraction: the RCCL all-gather (default) or explicit

@@ -117,6 +117,10 @@ int vcy_slab_range(const vcy_ctx* ctx, int32_t z_range[2]);
 int vcy_compute_dims(const float bb_min[3], const float bb_max[3],
                      float resolution, int32_t dims[3]);
 
+/* Voxel::pos along one axis (0 = x, 1 = y, 2 = z): out[i], i < dims[axis], as VoxelGrid::Init computes it
+ * (voxel_carver.cc:308-326) -- the same host arithmetic the device's axis tables are built with; needs no GPU. */
+int vcy_axis_positions(const float bb_min[3], const float bb_max[3], float resolution, int axis, float* out);
+
 /* ---- carving ------------------------------------------------------------ */
 
 /* Replaces bool VoxelCarver::Carve(const Camera&, const Vector2i& roi_min,

@@ -452,6 +452,15 @@ def test_cpp_bunny_example(tmp_path):
     # ShardedVoxelCarver (3 z-slabs, peer-copied halos, C++ merge) == single context, every view
     sh = [l.split() for l in out.splitlines() if l.startswith("SHARDED")]
     assert len(sh) == 6 and all(r[4] == "3" and r[6] == "1" for r in sh), sh
+    assert [l for l in out.splitlines() if l.startswith("BOUNDS")] == ["BOUNDS 0 14 28 42"]
+    # ... and with the cuts ShardedVoxelCarver::PlanPartition places for these six views (vcy_plan_z_slabs: whole
+    # brick layers, here 42 slices = 6 layers into 3 slabs)
+    out2 = subprocess.run([os.path.join(root, "vacancy_amd", "host", "bunny"), B.BUNNY, str(tmp_path), "10", "3", "planned"],
+                          check=True, capture_output=True, text=True).stdout
+    sh2 = [l.split() for l in out2.splitlines() if l.startswith("SHARDED")]
+    assert len(sh2) == 6 and all(r[4] == "3" and r[6] == "1" for r in sh2), sh2
+    b2 = [int(x) for x in [l for l in out2.splitlines() if l.startswith("BOUNDS")][0].split()[1:]]
+    assert b2[0] == 0 and b2[-1] == 42 and len(b2) == 4 and all(z % 8 == 0 for z in b2[:-1]) and sorted(set(b2)) == b2, b2
     gold = json.load(open(os.path.join(root, "tests", "golden", "appendix_c.json")))
     rows = [l.split() for l in out.splitlines() if l.startswith("RESULT")]
     assert len(rows) == 6

@@ -116,6 +116,7 @@ def load():
         "vcy_grid_dims": (C.c_int, [vp, P(C.c_int32)]),
         "vcy_slab_range": (C.c_int, [vp, P(C.c_int32)]),
         "vcy_compute_dims": (C.c_int, [P(C.c_float), P(C.c_float), C.c_float, P(C.c_int32)]),
+        "vcy_axis_positions": (C.c_int, [P(C.c_float), P(C.c_float), C.c_float, C.c_int, vp]),
         "vcy_carve": (C.c_int, [vp, P(View), vp]),
         "vcy_carve_device": (C.c_int, [vp, P(View), vp]),
         "vcy_carve_batch_device": (C.c_int, [vp, C.c_int, P(View), P(vp)]),

@@ -147,6 +147,16 @@ int carve_log_open(vcy_ctx* c, bool first_chunk) {
   return i;
 }
 
+// Voxel::pos along one axis, reference voxel_carver.cc:308-326:
+//   pos = diff * ((float)i / (float)n) + bb_min + resolution * 0.5f   (left to right)
+// Host IEEE arithmetic, this TU is built with -ffp-contract=off.  The ONE place the expression lives: the device's
+// axis tables (vcy_create), vcy_axis_positions and through it the C++ facade's VoxelGrid come from here.
+static void axis_positions(float bb_min, float bb_max, float resolution, int n, float* out) {
+  const float offset = resolution * 0.5f;
+  const float diff = bb_max - bb_min;
+  for (int i = 0; i < n; ++i) out[i] = diff * (static_cast<float>(i) / static_cast<float>(n)) + bb_min + offset;
+}
+
 static int dims_from_option(const float bb_min[3], const float bb_max[3], float res, int32_t n[3]) {
   // VoxelGrid::Init, reference voxel_carver.cc:278-301
   if (res < std::numeric_limits<float>::min()) {
@@ -211,6 +221,18 @@ int vcy_device_count(int* count) {
 int vcy_compute_dims(const float bb_min[3], const float bb_max[3], float resolution,
                      int32_t dims[3]) {
   return dims_from_option(bb_min, bb_max, resolution, dims);
+}
+
+int vcy_axis_positions(const float bb_min[3], const float bb_max[3], float resolution, int axis, float* out) {
+  if (!bb_min || !bb_max || !out || axis < 0 || axis > 2) {
+    set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  int32_t n[3];
+  const int rc = dims_from_option(bb_min, bb_max, resolution, n);
+  if (rc != VCY_OK) return rc;
+  axis_positions(bb_min[axis], bb_max[axis], resolution, n[axis], out);
+  return VCY_OK;
 }
 
 int vcy_create(const vcy_carver_option* o, int device_id, int z_begin, int z_end, vcy_ctx** out) {
@@ -299,16 +321,11 @@ int vcy_create(const vcy_carver_option* o, int device_id, int z_begin, int z_end
   VCY_TRY(hipMalloc(&c->d_py, sizeof(float) * n[1]));
   VCY_TRY(hipMalloc(&c->d_pz, sizeof(float) * n[2]));
 
-  // Voxel::pos per axis, reference voxel_carver.cc:308-326:
-  //   pos = diff * ((float)i / (float)n) + bb_min + resolution*0.5f   (left to right)
-  // Host IEEE arithmetic, this TU is built with -ffp-contract=off.
-  const float offset = o->resolution * 0.5f;
+  // Voxel::pos per axis (axis_positions above)
   float* d_axis[3] = {c->d_px, c->d_py, c->d_pz};
   for (int a = 0; a < 3; ++a) {
-    const float diff = o->bb_max[a] - o->bb_min[a];
     std::vector<float> p(n[a]);
-    for (int i = 0; i < n[a]; ++i)
-      p[i] = diff * (static_cast<float>(i) / static_cast<float>(n[a])) + o->bb_min[a] + offset;
+    axis_positions(o->bb_min[a], o->bb_max[a], o->resolution, n[a], p.data());
     VCY_TRY(hipMemcpy(d_axis[a], p.data(), sizeof(float) * n[a], hipMemcpyHostToDevice));
     if (a == 0) {
       c->h_px = new float[n[0]];

@@ -46,7 +46,9 @@ struct KeyHash {
 struct ShardedVoxelCarver::Impl {
   VoxelCarverOption option;
   std::vector<int> devices;
-  int per_device = 2;
+  int per_device = 1;
+  std::vector<int> wanted_bounds;  // PlanPartition / set_z_bounds; empty: equal thickness
+  std::vector<int> bounds;         // of the slabs that exist
   std::vector<vcy_ctx*> slabs;  // in z order
   bool peer_copy_halo = false;
   ~Impl() {
@@ -66,10 +68,8 @@ void ShardedVoxelCarver::set_halo_transport(HaloTransport t) { impl_->peer_copy_
 
 int ShardedVoxelCarver::slab_count() const { return static_cast<int>(impl_->slabs.size()); }
 
-bool ShardedVoxelCarver::Init() {
-  for (vcy_ctx* c : impl_->slabs) vcy_destroy(c);
-  impl_->slabs.clear();
-  const VoxelCarverOption& o = impl_->option;
+namespace {
+vcy_carver_option ToC(const VoxelCarverOption& o) {
   vcy_carver_option c;
   std::memset(&c, 0, sizeof(c));
   for (int i = 0; i < 3; ++i) {
@@ -85,6 +85,51 @@ bool ShardedVoxelCarver::Init() {
   c.update_option.voxel_update_weight = o.update_option.voxel_update_weight;
   c.update_option.use_truncation = o.update_option.use_truncation ? 1 : 0;
   c.update_option.truncation_band = o.update_option.truncation_band;
+  return c;
+}
+}  // namespace
+
+void ShardedVoxelCarver::set_z_bounds(const std::vector<int>& z_bounds) { impl_->wanted_bounds = z_bounds; }
+const std::vector<int>& ShardedVoxelCarver::z_bounds() const { return impl_->bounds; }
+
+bool ShardedVoxelCarver::PlanPartition(const std::vector<const Camera*>& cameras,
+                                       const std::vector<Image1b>& silhouettes) {
+  if (cameras.empty() || cameras.size() != silhouettes.size()) return false;
+  const vcy_carver_option c = ToC(impl_->option);
+  const int count = static_cast<int>(impl_->devices.size()) * impl_->per_device;
+  if (count < 2) return true;  // one slab: nothing to cut
+  vcy_ctx* planner = nullptr;
+  if (vcy_create(&c, impl_->devices[0], 0, 8, &planner) != VCY_OK) {  // (its 8-slice slab is never touched)
+    LOGE("%s\n", vcy_last_error());
+    return false;
+  }
+  const int n = static_cast<int>(cameras.size());
+  std::vector<vcy_view> views(n);
+  std::vector<float*> imgs(n, nullptr);
+  bool ok = true;
+  for (int i = 0; i < n && ok; ++i) {
+    views[i] = MakeView(*cameras[i], silhouettes[i].width(), silhouettes[i].height());
+    // MakeSignedDistanceField as Carve() will build it (voxel_carver.cc:405-408), on the device
+    ok = vcy_make_sdf_device(planner, silhouettes[i].data().data(), views[i].width, views[i].height, views[i].roi_min,
+                             views[i].roi_max, c.sdf_minmax_normalize, c.update_option.use_truncation,
+                             c.update_option.truncation_band, &imgs[i]) == VCY_OK;
+  }
+  std::vector<int32_t> b(static_cast<size_t>(count) + 1, 0);
+  if (ok)
+    ok = vcy_plan_z_slabs(planner, n, views.data(), imgs.data(), count, 0, 0.0f, b.data(), nullptr, 0, nullptr) == VCY_OK;
+  if (!ok) LOGE("PlanPartition: %s\n", vcy_last_error());
+  for (float* p : imgs)
+    if (p) vcy_device_free(planner, p);
+  vcy_destroy(planner);
+  if (ok) impl_->wanted_bounds.assign(b.begin(), b.end());
+  return ok;
+}
+
+bool ShardedVoxelCarver::Init() {
+  for (vcy_ctx* c : impl_->slabs) vcy_destroy(c);
+  impl_->slabs.clear();
+  impl_->bounds.clear();
+  const vcy_carver_option c = ToC(impl_->option);
   int32_t dims[3];
   if (vcy_compute_dims(c.bb_min, c.bb_max, c.resolution, dims) != VCY_OK) {
     LOGE("%s\n", vcy_last_error());
@@ -94,8 +139,18 @@ bool ShardedVoxelCarver::Init() {
   int count = ndev * impl_->per_device;
   while (count > 1 && dims[2] / count < 2) --count;  // every slab needs >= 2 slices
   const int base = dims[2] / count, rem = dims[2] % count;
+  std::vector<int> bounds(static_cast<size_t>(count) + 1, dims[2]);
+  for (int s = 0; s < count; ++s) bounds[s] = s * base + (s < rem ? s : rem);
+  {  // cuts from PlanPartition / set_z_bounds, if they fit this grid and slab count
+    const std::vector<int>& w = impl_->wanted_bounds;
+    bool fits = static_cast<int>(w.size()) == count + 1 && w.front() == 0 && w.back() == dims[2];
+    for (size_t s = 0; fits && s + 1 < w.size(); ++s) fits = w[s + 1] - w[s] >= 2;
+    if (fits) bounds = w;
+    else if (!w.empty()) LOGW("ShardedVoxelCarver: the given z bounds do not fit %d slabs of this grid; equal thickness\n", count);
+  }
+  impl_->bounds = bounds;
   for (int s = 0; s < count; ++s) {
-    const int z0 = s * base + (s < rem ? s : rem), z1 = z0 + base + (s < rem ? 1 : 0);
+    const int z0 = bounds[s], z1 = bounds[s + 1];
     vcy_ctx* ctx = nullptr;
     if (vcy_create(&c, impl_->devices[s % ndev], z0, z1, &ctx) != VCY_OK) {  // cyclic deal
       LOGE("%s\n", vcy_last_error());

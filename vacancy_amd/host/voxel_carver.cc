@@ -49,46 +49,42 @@ Voxel::~Voxel() {}
 VoxelGrid::VoxelGrid() {}
 VoxelGrid::~VoxelGrid() {}
 
-// reference voxel_carver.cc:276-345, expression for expression (the device builds the same three axis
-// tables: vcy_download_positions returns these positions bit for bit)
+// The container of reference voxel_carver.cc:276-345.  Its sizes and voxel centres come from the library -- the
+// arithmetic of VoxelGrid::Init lives in ONE place, next to the device's axis tables (vcy_compute_dims,
+// vcy_axis_positions; vcy_download_positions returns the same values bit for bit) -- and are only laid out here.
 bool VoxelGrid::Init(const Eigen::Vector3f& bb_max, const Eigen::Vector3f& bb_min, float resolution) {
-  if (resolution < std::numeric_limits<float>::min()) {
-    LOGE("resolution must be positive %f\n", resolution);
+  const float mn[3] = {bb_min.x(), bb_min.y(), bb_min.z()}, mx[3] = {bb_max.x(), bb_max.y(), bb_max.z()};
+  int32_t n[3];
+  if (vcy_compute_dims(mn, mx, resolution, n) != VCY_OK) {  // (resolution, bounding box: the reference's checks and texts)
+    LOGE("%s\n", vcy_last_error());
     return false;
   }
-  if (bb_max.x() <= bb_min.x() || bb_max.y() <= bb_min.y() || bb_max.z() <= bb_min.z()) {
-    LOGE("input bounding box is invalid\n");
+  if (static_cast<long long>(n[0]) * n[1] * n[2] > std::numeric_limits<int>::max()) {  // 32-bit ids, :298-301
+    LOGE("too many voxels\n");
     return false;
+  }
+  std::vector<float> axis[3];
+  for (int a = 0; a < 3; ++a) {
+    axis[a].resize(static_cast<size_t>(n[a]));
+    if (vcy_axis_positions(mn, mx, resolution, a, axis[a].data()) != VCY_OK) return false;
   }
   bb_max_ = bb_max;
   bb_min_ = bb_min;
   resolution_ = resolution;
-  const Eigen::Vector3f diff = bb_max_ - bb_min_;
-  for (int i = 0; i < 3; i++) voxel_num_[i] = static_cast<int>(diff[i] / resolution_);
-  if (static_cast<long long>(voxel_num_.x()) * voxel_num_.y() * voxel_num_.z() > std::numeric_limits<int>::max()) {
-    LOGE("too many voxels\n");
-    return false;
-  }
-  xy_slice_num_ = voxel_num_[0] * voxel_num_[1];
+  voxel_num_ = Eigen::Vector3i(n[0], n[1], n[2]);
+  xy_slice_num_ = n[0] * n[1];
   voxels_.clear();
-  voxels_.resize(static_cast<size_t>(voxel_num_.x()) * voxel_num_.y() * voxel_num_.z());
-  const float offset = resolution_ * 0.5f;
-  for (int z = 0; z < voxel_num_.z(); z++) {
-    const float z_pos = diff.z() * (static_cast<float>(z) / static_cast<float>(voxel_num_.z())) + bb_min_.z() + offset;
-    for (int y = 0; y < voxel_num_.y(); y++) {
-      const float y_pos =
-          diff.y() * (static_cast<float>(y) / static_cast<float>(voxel_num_.y())) + bb_min_.y() + offset;
-      for (int x = 0; x < voxel_num_.x(); x++) {
-        const float x_pos =
-            diff.x() * (static_cast<float>(x) / static_cast<float>(voxel_num_.x())) + bb_min_.x() + offset;
-        Voxel* voxel = get_ptr(x, y, z);
-        voxel->index = Eigen::Vector3i(x, y, z);
-        voxel->id = z * xy_slice_num_ + (y * voxel_num_.x() + x);
-        voxel->pos = Eigen::Vector3f(x_pos, y_pos, z_pos);
-        voxel->sdf = InvalidSdf::kVal;
+  voxels_.resize(static_cast<size_t>(n[0]) * n[1] * n[2]);
+  size_t id = 0;
+  for (int z = 0; z < n[2]; z++)
+    for (int y = 0; y < n[1]; y++)
+      for (int x = 0; x < n[0]; x++, id++) {
+        Voxel& voxel = voxels_[id];
+        voxel.index = Eigen::Vector3i(x, y, z);
+        voxel.id = static_cast<int>(id);
+        voxel.pos = Eigen::Vector3f(axis[0][x], axis[1][y], axis[2][z]);
+        voxel.sdf = InvalidSdf::kVal;
       }
-    }
-  }
   return true;
 }
 const Eigen::Vector3i& VoxelGrid::voxel_num() const { return voxel_num_; }
