@@ -45,7 +45,10 @@ namespace {
 #define VCY_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 // Waves per workgroup.  The waves never talk to each other, so 1 and 2 are just as correct; measured, they are
 // 3 % slower in the default mode (four bricks adjacent in x start together and share rows and footprints).
-constexpr int kWgWaves = 4;
+#ifndef VCY_WG_WAVES
+#define VCY_WG_WAVES 4   // (development builds: 8 is 7 % faster for single-view weighted-average launches, 7 % slower for the fused 32-view launch)
+#endif
+constexpr int kWgWaves = VCY_WG_WAVES;
 constexpr int BX = 8 * kWgWaves, BY = 8, BZ = 8;  // voxels per workgroup: kWgWaves 8x8x8 wave bricks along x
 constexpr int WX = 8;                    // wave brick is WX x BY x BZ, lane = (y & 7) | (z << 3), WX voxels per lane
 constexpr int kMaxFusedViews = 64;         // one prologue lane per view
@@ -289,14 +292,15 @@ __device__ __forceinline__ void update_max_touched(float dist, float& s, int& n,
 // (state only ever written by the fill and the carve kernels): then the first touch needs no special
 // case, (0 * sdf + dist) * 1 == dist bit for bit (0 * lowest() = -0, -0 + dist = dist).
 template <bool TRUNC>
-__device__ __forceinline__ void update_wa_unit(float dist, float& s, float& fn) {
+__device__ __forceinline__ void update_wa_unit(float dist, float& s, float& fn, unsigned long long& took) {
   const float f1 = fn + 1.0f;
   const float avg = (fn * s + dist) * rcp_count(f1);
   if (TRUNC) {
     asm("v_cmp_ngt_f32_e32 vcc, -1.0, %[d]\n\t"   // !(-1 > d)  ==  !(d < -1), true for NaN like the reference
+        "s_or_b64 %[took], %[took], vcc\n\t"
         "v_cndmask_b32_e32 %[s], %[s], %[avg], vcc\n\t"
         "v_cndmask_b32_e32 %[fn], %[fn], %[f1], vcc"
-        : [s] "+v"(s), [fn] "+v"(fn)
+        : [s] "+v"(s), [fn] "+v"(fn), [took] "+s"(took)
         : [d] "v"(dist), [avg] "v"(avg), [f1] "v"(f1)
         : "vcc");
   } else {
@@ -1130,6 +1134,10 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     return rest ? (__ffsll((long long)rest) - 1) : nviews;
   };
 
+  // Lanes whose voxels changed (update_num grows with every change), accumulated over the views: what the write-back
+  // stores.  (Round 3 re-read update_num from memory and compared: a dependent round trip in every wave's chain.  It
+  // turned out not to be what bounds a single-view launch -- see DESIGN section 8 -- but there is no reason to keep it.)
+  unsigned long long changed_lanes = 0ull;
   unsigned long long live = live_views();
   int vi = live ? (__ffsll((long long)live) - 1) : nviews;
   if (kRaw && vi < nviews) raw_prefetch(views[vi].v, tinfo[vi], lane, raw_buf(0));
@@ -1241,7 +1249,9 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
           }
         }
       }
-      return __any(moved);
+      const unsigned long long mv = __ballot(moved);
+      changed_lanes |= mv;
+      return mv != 0ull;
     };
     // ---- select-free fast path -------------------------------------------------------------
     // A `sure` tile (every sample provably inside it and inside div_view2's depth range) whose update
@@ -1353,10 +1363,13 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
             if constexpr (UPDATE == kUpdateWaUnitWeight) s[k] = (fn_v * s[k] + dist) * inv_v;
             else s[k] = (fn_v * s[k] + wgt_v * dist) * inv_v;
           } else if constexpr (kFastWa) {
-            update_wa_unit<TRUNC && !NOTRUNC>(dist, s[k], n[k]);
+            update_wa_unit<TRUNC && !NOTRUNC>(dist, s[k], n[k], took);
           }
         }
       }
+      // every lane took every sample, unless the update was conditional (kMax on a touched brick, the truncating average)
+      constexpr bool kConditional = !FIRST && !UNIFORM && (kFastMax || (kFastWa && TRUNC && !NOTRUNC));
+      changed_lanes |= kConditional ? took : ~0ull;
       return (kFastMax && !FIRST) ? took != 0ull : true;
     };
     bool brick_moved;
@@ -1452,14 +1465,9 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
         for (int k = 0; k < WX; ++k) ssum += s[k], nsum += (float)n[k];
         changed = ssum == 1.2345e-30f && nsum == 777.25f;
       }
-      if (false) {
 #else
-      if (!fresh) {
+      changed = changed || ((changed_lanes >> lane) & 1ull) != 0ull;
 #endif
-        const CountVec cv = *(const CountVec*)(cnt + row0 + x_first);
-#pragma unroll
-        for (int k = 0; k < WX; ++k) changed = changed || (int)n[k] != (int)cv[k];
-      }
       if (changed) {
 #ifdef VCY_FLOOR_DUMMY_STORES  // development build: the same store instructions, all into 64 rows of ONE brick row (never reach HBM)
         const int64_t row0_ = ((int64_t)(lane >> 3) * g.ny + (lane & 7)) * g.nx;
@@ -1483,7 +1491,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
       for (int k = 0; k < WX; ++k) {
         if (x_first + k < g.nx) {
           const int64_t idx = row0 + x_first + k;
-          if (fresh || (int)n[k] != (int)cnt[idx]) {
+          if (fresh || ((changed_lanes >> lane) & 1ull) != 0ull) {  // (unchanged voxels of a changed lane store what they hold)
             g.sdf[idx] = s[k];
             cnt[idx] = (CountT)n[k];
           }
@@ -1944,7 +1952,8 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     if (!big && c->use_live_list && need_bound && !c->fresh && n_views <= kLiveListMaxViews && (m.trunc != 0 || have_min) &&
         (list_pays || c->live_list_age % 16 == 0)) {  // (every 16th launch looks again)
       const int nwg = (int)grid.x;
-      const size_t need = sizeof(int) * ((size_t)nwg + 1);
+      const size_t need = sizeof(int) * ((size_t)nwg + 1);  // (the hint below: a race with its copy is benign, it only
+      // decides whether the NEXT launch lists its workgroups; with several chunks it reflects the last one)
       if (c->wg_list_bytes < need) {
         VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
         if (c->d_wg_list) (void)hipFree(c->d_wg_list);
