@@ -521,13 +521,19 @@ def main():
         for c in carvers:
             c.set_param("carvetimer", 1)
 
+    kernel_launches = [0]
+
     def read_logs(carvers, steps):
-        """(pre-pass ms, carve kernel ms) per step, summed over the carvers' launches."""
+        """(pre-pass ms, carve kernel ms) per step, summed over the carvers' launches; the number of carve kernel
+        launches per step (a fused launch is cut into groups of brick layers) is left in kernel_launches[0]."""
         pre = ker = 0.0
+        n = 0
         for c in carvers:
             log = c.carve_log()
             pre += sum(r[1] for r in log)
             ker += sum(r[2] for r in log)
+            n += len(log)
+        kernel_launches[0] = n / float(max(1, steps))
         return pre / max(1, steps), ker / max(1, steps)
 
     def warm_up(carvers, step, steps, settle_ms):
@@ -577,6 +583,7 @@ def main():
     elapsed = time.perf_counter() - t0
     my_elapsed_ms = elapsed * 1e3
     avg_prepass_ms, avg_kernel_ms = read_logs(devs, args.steps) if args.batch else (0.0, my_elapsed_ms / args.steps)
+    main_kernel_launches = kernel_launches[0] if args.batch else float(nv * len(devs))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -612,10 +619,12 @@ def main():
     slab_vox = sum(c.slab_voxels for c in devs) / float(len(devs))  # per launch
     FUSED_MAX = 64  # views per fused launch (carve_fused.hip)
     views_per_launch = min(nv, FUSED_MAX) if args.batch else 1
-    launches_per_step = ((nv + views_per_launch - 1) // views_per_launch) * len(devs)
+    # kernel launches per step: one per group of brick layers of every fused launch (the pre-pass of the next group runs
+    # beside the carve of this one, vcy_set_param "overlap"), counted from the event log
+    launches_per_step = max(1.0, main_kernel_launches)
     avg_launch_ms = avg_kernel_ms / launches_per_step  # the dominant kernel alone, HIP events around it
     avg_step_device_ms = my_period
-    alg_bytes = slab_vox * views_per_launch * bytes_per_vv(args.mode, uo)
+    alg_bytes = sum(c.slab_voxels for c in devs) * float(nv) * bytes_per_vv(args.mode, uo) / launches_per_step
     achieved = alg_bytes / (avg_launch_ms * 1e-3) / 1e9
     ckey = "%s_%d_%d_b%d_c%d" % (args.mode, n, nv, args.batch, args.cull)
     build = library_build()
@@ -625,8 +634,11 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "carve_fused_kernel" if args.batch else "carve_view_kernel",
                 "avg_launch_ms": round(avg_launch_ms, 4),
-                "avg_launch_ms_note": "carve_fused_kernel alone (HIP events on its stream around the kernel, "
-                                      "vcy_last_carve_ms): what rocprofv3 --kernel-trace reports for it",
+                "kernel_launches_per_step": round(launches_per_step, 2),
+                "avg_launch_ms_note": "carve_fused_kernel alone (HIP events on its stream around every launch of it, "
+                                      "vcy_carve_log): what rocprofv3 --kernel-trace reports for it; a step's fused launch is "
+                                      "kernel_launches_per_step launches (groups of brick layers), algorithmic bytes per launch "
+                                      "accordingly",
                 "step_device_ms": round(avg_step_device_ms, 4),
                 "prepass_ms_per_step": round(avg_prepass_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,

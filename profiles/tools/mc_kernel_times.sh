@@ -32,6 +32,6 @@ import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"]
     if "mc_" in n or "scan" in n or "chunk" in n:
-        import re; short = re.search(r"(mc_\w+|scan_chunks\w*|add_chunk\w*)", n).group(1); print("   %-28s calls %4s  avg %9.1f us  min %9.1f" % (short, r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
+        import re; m_ = re.search(r"(mc_\w+|scan_\w+|add_chunk\w*)", n); short = m_.group(1) if m_ else n[:28]; print("   %-28s calls %4s  avg %9.1f us  min %9.1f" % (short, r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
 PY
 done

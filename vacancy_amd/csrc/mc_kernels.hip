@@ -321,6 +321,7 @@ __global__ __launch_bounds__(256) void mc_bits_bricks_kernel(const float* __rest
           ok[o] = m_ok;
           if (tc != nullptr) tc[o] = m_ok;
         }
+
       }
     }
   }
@@ -978,10 +979,74 @@ __global__ __launch_bounds__(256) void add_chunk_offsets_kernel(u64* __restrict_
   if (i < n) data[i] += offs[i >> 10];
 }
 
+// The same in ONE launch (round 4; three launches before: chunks, their sums, the offsets added -- each a dependent
+// kernel boundary in the middle of an extraction made of short kernels): a workgroup scans its 1024 elements, publishes
+// its sum, and adds up the sums of the chunks before it, waiting for those that are not published yet.  A chunk only
+// ever waits for EARLIER chunks, which were dispatched before it and wait for nobody later: no deadlock whatever is
+// resident.  Publication is (sum, epoch): the epoch grows with every scan of a context, so the flags are never cleared.
+// Every chunk reads all its predecessors -- quadratic, which is why this form is only taken up to kChainedScanMaxChunks
+// (1024^3: 64 chunks for the word blocks, about 10 for the surface cells).
+constexpr int kChainedScanMaxChunks = 1024;
+__global__ __launch_bounds__(256) void scan_chained_kernel(u64* __restrict__ data, int64_t n, u64* __restrict__ chunk_sums,
+                                                           uint32_t* __restrict__ chunk_flags, uint32_t epoch,
+                                                           u64* __restrict__ total) {
+  __shared__ u64 sm[256];
+  __shared__ u64 sm_before;
+  const int chunk = blockIdx.x;
+  const int64_t base = (int64_t)chunk * 1024 + (int64_t)threadIdx.x * 4;
+  u64 v[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = (base + k < n) ? data[base + k] : 0ull;
+    s += v[k];
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    u64 t = (threadIdx.x >= d) ? sm[threadIdx.x - d] : 0ull;
+    __syncthreads();
+    sm[threadIdx.x] += t;
+    __syncthreads();
+  }
+  if (threadIdx.x == 255) {  // publish this chunk's sum
+    __hip_atomic_store(&chunk_sums[chunk], sm[255], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&chunk_flags[chunk], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // the sums of the chunks before this one: thread t takes chunks t, t + 256, ...
+  u64 before = 0;
+  for (int c = threadIdx.x; c < chunk; c += 256) {
+    while (__hip_atomic_load(&chunk_flags[c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+    before += __hip_atomic_load(&chunk_sums[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const u64 incl_local = sm[threadIdx.x];
+  __syncthreads();
+  sm[threadIdx.x] = before;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) sm[threadIdx.x] += sm[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sm_before = sm[0];
+  __syncthreads();
+  u64 run = sm_before + incl_local - s;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (base + k < n) data[base + k] = run;
+    run += v[k];
+  }
+  if (chunk == (int)gridDim.x - 1 && threadIdx.x == 255) *total = run;  // (the last element's inclusive value)
+}
+
 // in-place exclusive scan; *d_total (device) receives the grand total.  `scratch` holds the chunk
 // sums of every level (n/1024 + n/1024^2 + ... + a few elements).
-int exclusive_scan_u64(u64* d, int64_t n, u64* d_total, u64* scratch, hipStream_t stream) {
+int exclusive_scan_u64(u64* d, int64_t n, u64* d_total, u64* scratch, hipStream_t stream, uint32_t* flags = nullptr,
+                       uint32_t epoch = 0) {
   const int64_t nchunks = (n + 1023) / 1024;
+  if (flags != nullptr && nchunks <= kChainedScanMaxChunks) {
+    hipLaunchKernelGGL(scan_chained_kernel, dim3((unsigned)nchunks), dim3(256), 0, stream, d, n, scratch, flags, epoch, d_total);
+    VCY_HIP_CHECK(hipGetLastError());
+    return VCY_OK;
+  }
   hipLaunchKernelGGL(scan_chunks_kernel, dim3((unsigned)nchunks), dim3(256), 0, stream, d, n, scratch);
   if (nchunks > 1) {
     int rc = exclusive_scan_u64(scratch, nchunks, d_total, scratch + nchunks, stream);
@@ -1337,6 +1402,14 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   uint32_t* d_woff = (uint32_t*)base;         base += sz_woff;
   u64* d_wcounts = (u64*)base;                base += sz_counts;
   u64* d_scan = (u64*)base;                   base += sz_scan;
+  // publication flags of the chained scans (scan_chained_kernel): an allocation of their own, zeroed once -- they
+  // must never hold a FUTURE epoch, so they do not live in scratch whose layout changes with the extraction
+  if (!c->d_mc_flags) {
+    VCY_HIP_CHECK(hipMalloc(&c->d_mc_flags, sizeof(uint32_t) * 2 * (size_t)kChainedScanMaxChunks));
+    VCY_HIP_CHECK(hipMemsetAsync(c->d_mc_flags, 0, sizeof(uint32_t) * 2 * (size_t)kChainedScanMaxChunks, s));
+    c->mc_scan_epoch = 0;
+  }
+  uint32_t* d_flags = (uint32_t*)c->d_mc_flags;
   u64* d_total = (u64*)base;
   p.in = d_in;
   p.ok = d_ok;
@@ -1455,7 +1528,7 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
                        d_woff, d_wcounts, (int64_t)nblocks);
   }
   MC_TRY(hipGetLastError());
-  int rc = exclusive_scan_u64(d_wcounts, nblocks, d_total, d_scan, s);
+  int rc = exclusive_scan_u64(d_wcounts, nblocks, d_total, d_scan, s, d_flags, ++c->mc_scan_epoch);
   if (rc != VCY_OK) return rc;
 
   // ---- the surface cells ------------------------------------------------------------------------
@@ -1497,7 +1570,7 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
     hipLaunchKernelGGL(mc_owner_kernel, dim3(b.blocks), dim3(256), 0, s, p, T, d_act, b.list, d_total, cap_cells, b.info,
                        b.counts);
     MC_TRY(hipGetLastError());
-    return exclusive_scan_u64(b.counts, b.blocks, b.total, b.scan, s);
+    return exclusive_scan_u64(b.counts, b.blocks, b.total, b.scan, s, d_flags + kChainedScanMaxChunks, ++c->mc_scan_epoch);
   };
   // output staging, cached in the context and grown on demand; then the emit pass
   auto enqueue_emit = [&](const CellBuffers& b, int64_t cap_cells, int64_t cap_v, int64_t cap_f) -> int {

@@ -379,6 +379,7 @@ void vcy_destroy(vcy_ctx* c) {
     if (c->ev_uploaded[k]) (void)hipEventDestroy(c->ev_uploaded[k]);
   }
   (void)hipFree(c->d_mc_out);
+  (void)hipFree(c->d_mc_flags);
   (void)hipFree(c->d_mc_cells);
   (void)hipFree(c->d_fused_scratch);
   (void)hipFree(c->d_wmax);

@@ -142,6 +142,8 @@ struct vcy_ctx {
   void* d_mc_tables = nullptr;        // marching-cubes case tables (mc_kernels.hip)
   void* d_mc_scratch = nullptr;       // bit planes, active words, offsets, per-cell info
   size_t mc_scratch_bytes = 0;
+  void* d_mc_flags = nullptr;         // publication flags of the chained scans (mc_kernels.hip, scan_chained_kernel)
+  uint32_t mc_scan_epoch = 0;         // ... and the epoch of the last scan (flags never hold a later one)
   void* d_mc_cells = nullptr;         // per-active-cell arrays of the extraction
   size_t mc_cells_bytes = 0;
   void* d_mc_out = nullptr;           // device staging of the extracted mesh
