@@ -938,6 +938,10 @@ static bool can_defer(vcy_ctx* c, const vcy_view* view) {
   return true;
 }
 
+#ifndef VCY_STAGE_THREADS
+#define VCY_STAGE_THREADS 4   // (8 and 16 measured: the producer side of 32 silhouettes at 1280 x 720 stays at 1.45 - 1.5 ms)
+#endif
+constexpr int kStageThreads = VCY_STAGE_THREADS;  // host threads that copy silhouettes into page-locked staging and queue their DMAs
 constexpr int kMaxPendingViews = 32;  // queued images held at most (3.7 MB each at 1280x720)
 
 // Queues (view, private device image): flushes first if the queue is full or of the other projection
@@ -1201,7 +1205,7 @@ int vcy_carve_batch_silhouettes(vcy_ctx* c, int n_views, const vcy_view* views,
     }
     fail_hip(hipEventRecord(c->stream_events[(size_t)4 * ci + 0], aux), "hipEventRecord");
     // host threads: copy silhouette j into the staging buffer, then queue its DMA
-    const int n_thr = std::max(1, std::min(m, std::min(4, (int)std::thread::hardware_concurrency())));
+    const int n_thr = std::max(1, std::min(m, std::min(kStageThreads, (int)std::thread::hardware_concurrency())));
     std::vector<hipError_t> terr((size_t)n_thr, hipSuccess);
     auto worker = [&](int t) {
       (void)hipSetDevice(c->device);
