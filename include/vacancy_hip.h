@@ -348,6 +348,12 @@ int vcy_plan_z_slabs(vcy_ctx* ctx, int n_views, const vcy_view* views, const flo
                      int sample_stride, float brick_cost, int32_t* z_bounds, double* layer_cost, int max_layers,
                      int* n_layers);
 
+/* The cut itself, host arithmetic only (no GPU): the contiguous partition of `n_layers` brick layers with the given costs
+ * into `n_slabs` parts -- every part at least one layer -- that minimises the largest part and, among those, the sum of
+ * squares.  z_bounds[0 .. n_slabs] in slices (multiples of 8, the last one nz; nz in ((n_layers - 1) * 8, n_layers * 8]).
+ * What vcy_plan_z_slabs applies to its estimate; callable with measured costs as well. */
+int vcy_partition_layers(const double* layer_cost, int n_layers, int n_slabs, int nz, int32_t* z_bounds);
+
 /* Device-side self test of the identities the fast paths rest on (no reference counterpart): the
  * two-instruction reciprocal used for update_num + 1 in the unit-weight weighted average equals the
  * IEEE quotient for every count a u8 / u16 counter can hold.  VCY_OK, or VCY_ERR_INTERNAL with the

@@ -230,3 +230,40 @@ def test_run_loops_of_the_fused_kernel_fetch_their_tables_through_scalar_loads()
             else:
                 block.append(line)
     assert fast_blocks >= 8
+
+
+def test_partition_layers_is_optimal_against_brute_force():
+    """vcy_partition_layers (what vcy_plan_z_slabs cuts its estimate with; host arithmetic, no GPU): the contiguous
+    partition with the smallest largest part -- checked against every partition for small cases -- whole brick layers,
+    every slab at least one layer, the last bound = nz; and its argument checks."""
+    import ctypes as C
+    import itertools
+    lib = capi.load()
+    rng = np.random.RandomState(7)
+
+    def cut(cost, parts, nz=None):
+        cost = np.ascontiguousarray(cost, np.float64)
+        nz = len(cost) * 8 if nz is None else nz
+        b = np.zeros(parts + 1, np.int32)
+        rc = lib.vcy_partition_layers(cost.ctypes.data_as(C.c_void_p), len(cost), parts, nz, b.ctypes.data_as(C.c_void_p))
+        return rc, [int(x) for x in b]
+
+    for trial in range(60):
+        L = int(rng.randint(1, 11))
+        parts = int(rng.randint(1, L + 1))
+        cost = rng.rand(L) * (1 + 5 * (rng.rand(L) < 0.3))
+        nz = L * 8 - int(rng.randint(0, 8))
+        rc, b = cut(cost, parts, nz)
+        assert rc == 0
+        assert b[0] == 0 and b[-1] == nz and all(x % 8 == 0 for x in b[:-1]) and all(b1 > b0 for b0, b1 in zip(b, b[1:]))
+        got = max(cost[b[s] // 8:(b[s + 1] + 7) // 8].sum() for s in range(parts))
+        best = min(max(cost[i:j].sum() for i, j in zip((0,) + cuts, cuts + (L,)))
+                   for cuts in itertools.combinations(range(1, L), parts - 1))
+        assert got <= best * (1 + 1e-9), (cost, parts, b, got, best)
+    # equal costs, parts dividing the layers: equal slabs; a heavy middle: thin slabs there
+    assert cut(np.ones(16), 4)[1] == [0, 32, 64, 96, 128]
+    b = cut([1, 1, 1, 1, 6, 6, 1, 1, 1, 1], 4)[1]
+    assert b == [0, 32, 40, 48, 80]
+    for bad in ((np.ones(4), 5, None), (np.ones(4), 0, None), (np.array([1.0, np.nan]), 1, None), (np.ones(4), 2, 40),
+                (np.ones(4), 2, 24)):
+        assert cut(*bad)[0] == capi.VCY_ERR_INVALID_ARG

@@ -165,6 +165,7 @@ def load():
         "vcy_plan_z_slabs": (C.c_int, [vp, C.c_int, P(View), P(vp), C.c_int, C.c_int, C.c_float, vp, vp, C.c_int,
                                        P(C.c_int)]),
         "vcy_last_stream_ms": (C.c_int, [vp, P(C.c_float), P(C.c_float), P(C.c_float)]),
+        "vcy_partition_layers": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
         "vcy_carve_log": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, P(C.c_int), C.c_int]),
         "vcy_measure_bandwidth": (C.c_int, [C.c_int, C.c_uint64, C.c_int, P(C.c_double), P(C.c_double)]),
         "vcy_last_error": (C.c_char_p, []),

@@ -245,6 +245,39 @@ int launch_carve(vcy_ctx* c, int n_views, const vcy_view* views, const float* co
   return VCY_OK;
 }
 
+// The contiguous partition of L brick layers into n_slabs parts (every part at least one layer) that minimises the
+// largest part's cost and, among those, the sum of the squares: dynamic programming over (parts, layers), O(n_slabs L^2)
+// -- L is nz / 8, a few hundred.  z_bounds[0 .. n_slabs] in slices (layer * 8; the last one nz).  Host arithmetic only
+// (vcy_partition_layers exposes it: the CPU tests check it against brute force).
+void partition_layers(const double* cost, int L, int n_slabs, int nz, int32_t* z_bounds) {
+  std::vector<double> pre((size_t)L + 1, 0.0);
+  for (int l = 0; l < L; ++l) pre[(size_t)l + 1] = pre[(size_t)l] + cost[l];
+  // f[s][i]: best (largest part, sum of squares) for the first i layers in s parts
+  struct Val { double mx, sq; };
+  auto better = [](const Val& a, const Val& b) { return a.mx < b.mx * (1.0 - 1e-12) || (a.mx <= b.mx * (1.0 + 1e-12) && a.sq < b.sq); };
+  const Val inf{1e300, 1e300};
+  std::vector<std::vector<Val>> f((size_t)n_slabs + 1, std::vector<Val>((size_t)L + 1, inf));
+  std::vector<std::vector<int>> from((size_t)n_slabs + 1, std::vector<int>((size_t)L + 1, -1));
+  f[0][0] = Val{0.0, 0.0};
+  for (int sidx = 1; sidx <= n_slabs; ++sidx)
+    for (int i = sidx; i <= L - (n_slabs - sidx); ++i)
+      for (int j = sidx - 1; j < i; ++j) {
+        if (f[(size_t)sidx - 1][(size_t)j].mx >= 1e299) continue;
+        const double part = pre[(size_t)i] - pre[(size_t)j];
+        const Val v{std::max(f[(size_t)sidx - 1][(size_t)j].mx, part), f[(size_t)sidx - 1][(size_t)j].sq + part * part};
+        if (better(v, f[(size_t)sidx][(size_t)i])) {
+          f[(size_t)sidx][(size_t)i] = v;
+          from[(size_t)sidx][(size_t)i] = j;
+        }
+      }
+  int i = L;
+  z_bounds[n_slabs] = nz;
+  for (int sidx = n_slabs; sidx >= 1; --sidx) {
+    i = from[(size_t)sidx][(size_t)i];
+    z_bounds[sidx - 1] = i * 8;
+  }
+}
+
 // Cuts the grid into n_slabs z-slabs of equal PREDICTED carve cost for these views (vcy_plan_z_slabs).  Boundaries are
 // whole brick layers (8 slices): a slab that ends inside a layer pays that layer's waves in full, and so does the next.
 // cost(layer) = brick_cost * bricks + estimated (brick, view) pairs processed (plan_layer_pairs); the contiguous
@@ -278,32 +311,7 @@ int plan_z_slabs(vcy_ctx* c, int n_views, const vcy_view* views, const float* co
   if (layer_cost)
     for (int l = 0; l < std::min(L, max_layers); ++l) layer_cost[l] = cost[(size_t)l];
   if (n_layers) *n_layers = L;
-  std::vector<double> pre((size_t)L + 1, 0.0);
-  for (int l = 0; l < L; ++l) pre[(size_t)l + 1] = pre[(size_t)l] + cost[(size_t)l];
-  // f[s][i]: best (largest part, sum of squares) for the first i layers in s parts
-  struct Val { double mx, sq; };
-  auto better = [](const Val& a, const Val& b) { return a.mx < b.mx * (1.0 - 1e-12) || (a.mx <= b.mx * (1.0 + 1e-12) && a.sq < b.sq); };
-  const Val inf{1e300, 1e300};
-  std::vector<std::vector<Val>> f((size_t)n_slabs + 1, std::vector<Val>((size_t)L + 1, inf));
-  std::vector<std::vector<int>> from((size_t)n_slabs + 1, std::vector<int>((size_t)L + 1, -1));
-  f[0][0] = Val{0.0, 0.0};
-  for (int sidx = 1; sidx <= n_slabs; ++sidx)
-    for (int i = sidx; i <= L - (n_slabs - sidx); ++i)
-      for (int j = sidx - 1; j < i; ++j) {
-        if (f[(size_t)sidx - 1][(size_t)j].mx >= 1e299) continue;
-        const double part = pre[(size_t)i] - pre[(size_t)j];
-        const Val v{std::max(f[(size_t)sidx - 1][(size_t)j].mx, part), f[(size_t)sidx - 1][(size_t)j].sq + part * part};
-        if (better(v, f[(size_t)sidx][(size_t)i])) {
-          f[(size_t)sidx][(size_t)i] = v;
-          from[(size_t)sidx][(size_t)i] = j;
-        }
-      }
-  int i = L;
-  z_bounds[n_slabs] = c->nz;
-  for (int sidx = n_slabs; sidx >= 1; --sidx) {
-    i = from[(size_t)sidx][(size_t)i];
-    z_bounds[sidx - 1] = i * 8;
-  }
+  partition_layers(cost.data(), L, n_slabs, c->nz, z_bounds);
   return VCY_OK;
 }
 

@@ -601,6 +601,21 @@ int vcy_last_carve_pairs(vcy_ctx* c, int64_t* processed, int64_t* total, int64_t
   return VCY_OK;
 }
 
+int vcy_partition_layers(const double* layer_cost, int n_layers, int n_slabs, int nz, int32_t* z_bounds) {
+  if (!layer_cost || !z_bounds || n_layers < 1 || n_slabs < 1 || n_slabs > n_layers || nz <= (n_layers - 1) * 8 ||
+      nz > n_layers * 8) {
+    set_error("vcy_partition_layers: invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  for (int l = 0; l < n_layers; ++l)
+    if (!(layer_cost[l] >= 0.0) || !(layer_cost[l] < 1e280)) {
+      set_error("vcy_partition_layers: layer costs must be finite and non-negative");
+      return VCY_ERR_INVALID_ARG;
+    }
+  partition_layers(layer_cost, n_layers, n_slabs, nz, z_bounds);
+  return VCY_OK;
+}
+
 int vcy_plan_z_slabs(vcy_ctx* c, int n_views, const vcy_view* views, const float* const* sdf_device, int n_slabs,
                      int sample_stride, float brick_cost, int32_t* z_bounds, double* layer_cost, int max_layers,
                      int* n_layers) {

@@ -174,6 +174,7 @@ int launch_carve_fused(vcy_ctx* ctx, const GridParams& g, int n_views, const Vie
 int fused_max_views();
 int plan_layer_pairs(vcy_ctx* ctx, int n_views, const ViewParams* vp, int stride, std::vector<double>* pairs,
                      int64_t* bricks_per_layer);  // the slab planner's estimate (carve_fused.hip)
+void partition_layers(const double* cost, int n_layers, int n_slabs, int nz, int32_t* z_bounds);  // carve_kernels.hip
 int plan_z_slabs(vcy_ctx* ctx, int n_views, const vcy_view* views, const float* const* sdf_dev, int n_slabs, int stride,
                  float brick_cost, int32_t* z_bounds, double* layer_cost, int max_layers, int* n_layers);  // carve_kernels.hip
 int selftest_fused(hipStream_t stream);
