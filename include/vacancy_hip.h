@@ -289,6 +289,10 @@ int vcy_reset(vcy_ctx* ctx);
  * "livelist" (default 1): a carve launch of up to 8 views over an already carved grid first lists the workgroups in
  * which some view can still change a voxel (bounds of the views' samples against the kept brick minima / the
  * truncation limit) and starts only those; 0 starts every workgroup and lets each decide for itself.
+ * "coopstore" (default -1): how a fused launch over an already carved grid writes the state back.  1: the four waves
+ * of a workgroup exchange their bricks through LDS and store whole 128-byte row segments; 0: every wave stores its own
+ * 16-byte pieces; -1: the first for launches of up to 8 views in a weighted-average mode (which read and rewrite
+ * nearly the whole state), the second otherwise.  Results are identical.
  * "recordbytes" (default 0 = 1 GiB): bytes of footprint records one carve launch may take; a larger launch is cut into
  * chunks of whole brick layers (2048^3 x 64 views: nine).  Small values let tests run the chunking on small grids.
  * "carvetimer" (default 0): 1 records HIP events around what runs before the carve kernel (window maxima, pre-pass)
@@ -297,7 +301,7 @@ int vcy_reset(vcy_ctx* ctx);
  * "inject_carve_failure" (test hook, default 0): the next `value` applications of views fail with
  * VCY_ERR_INTERNAL before anything is launched -- how the tests exercise the error contract of vcy_carve. */
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
-/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep", "mcskip", "livelist", "meshkeys"), "div_level": the
+/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep", "mcskip", "livelist", "coopstore", "meshkeys"), "div_level": the
  * division sequence the last fused launch was instantiated with (2: 4 instructions, 1: 6, 0: full IEEE expansion), or
  * "brick_min_valid": 1 while the brick minima describe the state (every write since the fill went through the fused kernel). */
 int vcy_get_param(vcy_ctx* ctx, const char* name, int* value);

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs ON the GPU box: per-kernel times (rocprofv3 --kernel-trace --stats) of marching cubes at 1024^3 for each
-# build named on the command line ("prod" = vacancy_amd/csrc/libvacancy_hip.so); MCSWEEP=1 for the one-sweep cell search.
+# build named on the command line ("prod" = vacancy_amd/csrc/libvacancy_hip.so); MCSWEEP=1 for the one-sweep cell search;
+# N=512 NV=16 MODE=tsdf for BASELINE configs[1].
 R=$(pwd -P); O=$R/gpurun_out/mck; mkdir -p $O
 cat > /tmp/mc_drive.py <<'PY'
 import os, sys
@@ -8,14 +9,18 @@ sys.path.insert(0, os.environ["VCY_ROOT"])
 from vacancy_amd import synth
 from vacancy_amd import carver as vc
 from vacancy_amd.capi import UpdateOption
-n, nv = 1024, 32
-opt = synth.sphere_option(n, UpdateOption())
-views, masks = synth.sphere_views(n, nv, 1280, 720)
-sdf0 = vc.make_sdf(masks[0])
+n, nv = int(os.environ.get("N", "1024")), int(os.environ.get("NV", "32"))
+tsdf = os.environ.get("MODE", "default") == "tsdf"
+uo = UpdateOption(voxel_update=1, use_truncation=True, truncation_band=0.1) if tsdf else UpdateOption()
+opt = synth.sphere_option(n, uo)
+w, h = (640, 480) if n <= 512 else (1280, 720)
+views, masks = synth.sphere_views(n, nv, w, h)
+sdf0 = vc.make_sdf(masks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
 c = vc.VoxelCarver(opt)
 assert c.Init()
 d = [c.upload_sdf(sdf0)] * nv
 assert c.CarveBatchDevice(vc.VoxelCarver.prepare_batch(views, d))
+c.set_param("meshkeys", 0)
 c.set_param("mcsweep", int(os.environ.get("MCSWEEP", "0")))
 for it in range(6):
     m = c.ExtractIsoSurface(0.0, True)

@@ -921,17 +921,25 @@ def test_failed_flush_is_reported_once_to_the_carve_loop():
     assert_state_equal(dev, orc, "after injected failures")
 
 
-@pytest.mark.parametrize("kw,livelist,recordbytes",
-                         [(dict(), 1, 0), (dict(), 0, 0), (dict(), 1, 2000), (dict(use_truncation=True, truncation_band=0.1), 1, 0),
-                          (dict(voxel_update=1, use_truncation=True, truncation_band=0.1), 1, 0)])
-def test_single_view_launches_with_brick_minima(kw, livelist, recordbytes):
+_TSDF = dict(voxel_update=1, use_truncation=True, truncation_band=0.1)
+_TRUNC = dict(use_truncation=True, truncation_band=0.1)
+
+
+# (image 160 x 120: voxels of 0.72 px, the raw 16 x 16 tiles with footprint records, live list and cooperative
+# write-back; 200 x 150: 0.9 px, the big tiles, which bound their footprints in the kernel and know none of those)
+@pytest.mark.parametrize("kw,livelist,recordbytes,coopstore,img",
+                         [(dict(), 1, 0, -1, (160, 120)), (dict(), 0, 0, -1, (160, 120)), (dict(), 1, 2000, -1, (160, 120)),
+                          (_TRUNC, 1, 0, -1, (160, 120)), (_TSDF, 1, 0, -1, (160, 120)), (_TSDF, 1, 0, 0, (160, 120)),
+                          (_TSDF, 0, 2000, 1, (160, 120)), (dict(), 1, 0, 1, (160, 120)), (_TRUNC, 0, 2000, 1, (160, 120)),
+                          (dict(), 1, 0, -1, (200, 150)), (_TSDF, 1, 0, -1, (200, 150))])
+def test_single_view_launches_with_brick_minima(kw, livelist, recordbytes, coopstore, img):
     """The reference's call pattern (examples.cc:117-149): carve ONE view, extract, carve the next ... With
     `defer` 0 every call is a launch of its own; from the second on a wave whose view provably changes nothing
     (bound against the brick minimum the previous launch left, or below the truncation limit) returns without
     reading the state -- or, with the live list, is never started -- and marching cubes skips bricks whose minimum lies above the iso level.  State and mesh
     equal the oracle's after every view, on smooth and adversarial images; writes that bypass the fused kernel
     (vcy_upload, the per-view kernel) switch the minima off until the next fused launch has rebuilt them."""
-    n, nv, w, h = 72, 14, 200, 150
+    n, nv, (w, h) = 72, 14, img
     uo = UpdateOption(**kw)
     opt = synth.sphere_option(n, uo)
     views, masks = synth.sphere_views(n, nv, w, h)
@@ -941,6 +949,10 @@ def test_single_view_launches_with_brick_minima(kw, livelist, recordbytes):
     dev.set_param("defer", 0)
     dev.set_param("livelist", livelist)  # 1: only the workgroups with a live (brick, view) pair are started
     dev.set_param("recordbytes", recordbytes)  # 2000: every launch in chunks of three brick layers (as 2048^3 x 64 is)
+    # write-back of a workgroup's bricks through LDS in whole row segments: -1 = the library's rule (weighted average,
+    # few views, carved grid), 0 never, 1 wherever the layout allows (nx = 72: the last workgroup of a row has one wave
+    # inside the grid, the other three leave before the barrier)
+    dev.set_param("coopstore", coopstore)
     orc = O.OracleGrid(opt)
     base = O.make_sdf(masks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
     for i in range(nv):

@@ -69,6 +69,19 @@ constexpr int tile_f4_per_wave() { return TQ == kTileRaw ? kRawBuffers * 64 : TQ
 constexpr int kTileBig = 512;            // (in float4 units)
 constexpr int kBigPixels = 4 * kTileBig;
 
+// Cooperative write-back (state_flags bit 3, launch_carve_fused): the four waves of a workgroup hand their bricks' state
+// to each other through LDS and every store instruction then writes whole 128-byte (sdf) / 64-byte (update_num) row
+// segments instead of 64 scattered 16-byte pieces -- see the write-back of carve_fused_kernel.  Row pitches padded by
+// 16 bytes so that the 16-byte LDS accesses of both directions spread over the banks.
+constexpr int kCoopSdfPitch = 8 * VCY_WG_WAVES + 4;          // floats per row of the workgroup's 64 rows
+template <typename CountT>
+constexpr int coop_cnt_pitch() { return 8 * VCY_WG_WAVES + 16 / (int)sizeof(CountT); }  // counters per row
+template <typename CountT>
+constexpr size_t coop_lds_bytes() {
+  return 64 * (size_t)kCoopSdfPitch * sizeof(float) + 64 * (size_t)coop_cnt_pitch<CountT>() * sizeof(CountT) +
+         2 * VCY_WG_WAVES * sizeof(unsigned long long);  // (changed-lane masks, then "this wave takes part in the stores")
+}
+
 constexpr int kWmaxPlanes = 2;           // window sizes 4 and 8
 constexpr int kLiveListMaxViews = 8;      // launches of up to this many views over a carved grid list their live workgroups first
 constexpr int64_t kRecordBytesMax = (int64_t)1 << 30;  // footprint records of one carve launch (see launch_carve_fused)
@@ -889,9 +902,12 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   // bricks that lie entirely outside the iso-surface with it (mc_bits).
   // state_flags: bit 0 = the slab is fresh (known sdf = lowest(), update_num = 0, never written);
   //              bit 1 = update_num == 0 implies sdf == lowest() (no vcy_upload since the fill)
+  //              bit 3 = cooperative write-back through LDS (below)
   const int fresh = state_flags & 1;
   const bool implied = (state_flags & 2) != 0;
-  // dynamic LDS: [4 waves][TQ] quads, then [4 waves][nviews] TileInfo (sized by the launch)
+  const bool coop = kWgWaves == 4 && (state_flags & 8) != 0;
+  // dynamic LDS: [4 waves][TQ] quads, then [4 waves][nviews] TileInfo (sized by the launch), then the staging of the
+  // cooperative write-back
   extern __shared__ float4 fused_lds[];
   constexpr bool kRaw = TQ == kTileRaw;                  // raw-pixel tiles, loaded straight into LDS
   constexpr int kTileF4 = tile_f4_per_wave<TQ>();
@@ -913,6 +929,23 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   VCY_PT_DECL;
   float4* tile = fused_lds + wave * kTileF4;
   TileInfo* tinfo = (TileInfo*)(fused_lds + kWgWaves * kTileF4) + wave * nviews;
+  // (sizeof(TileInfo) * kWgWaves is a multiple of 16: the staging area is 16-byte aligned)
+  static_assert((sizeof(TileInfo) * kWgWaves) % 16 == 0, "alignment of the cooperative write-back's staging");
+  typedef CountT CountVec8 __attribute__((ext_vector_type(WX)));
+  typedef CountVec8 __attribute__((address_space(3))) lds_countvec;
+  typedef unsigned long long __attribute__((address_space(3))) lds_u64;
+  float* coop_s = (float*)((TileInfo*)(fused_lds + kWgWaves * kTileF4) + kWgWaves * nviews);
+  CountT* coop_n = (CountT*)(coop_s + 64 * kCoopSdfPitch);
+  lds_u64* coop_mask = (lds_u64*)(unsigned long long*)(coop_n + 64 * coop_cnt_pitch<CountT>());
+  // A wave that leaves early tells the others that none of its rows is to be stored and that it will not be there to
+  // store rows of theirs (s_barrier only waits for the waves of the workgroup that have not ended; the LDS writes have
+  // completed before the wave ends).
+  auto coop_leave = [&]() {
+    if (coop) {
+      if (lane == 0) coop_mask[wave] = 0ull, coop_mask[kWgWaves + wave] = 0ull;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+  };
   int cur = 0;  // raw tiles: which of the wave's buffers holds the view being carved
   auto raw_buf = [&](int b) -> float* { return (float*)tile + 256 * b; };
   const int ly = lane & (BY - 1), lz = lane >> 3;
@@ -963,7 +996,10 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   const int bz = b / nby;
   // (the wave index is uniform, which the compiler cannot see: readfirstlane keeps the x tables in scalar loads)
   const int x_first = __builtin_amdgcn_readfirstlane(bx * BX + wave * WX);  // wave brick origin
-  if (x_first >= g.nx) return;              // (no workgroup barriers: a wave may leave alone)
+  if (x_first >= g.nx) {                    // (a wave may leave alone: see coop_leave)
+    coop_leave();
+    return;
+  }
   const int zl0 = bz * BZ;
   const int y_raw = by * BY + ly, zl_raw = zl0 + lz;
   const bool lane_valid = y_raw < g.ny && zl_raw < g.nz_local;
@@ -1024,7 +1060,10 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
         const float smin0 = ((cfloat_ptr)brick_min)[brick_lin];  // (uniform: a scalar load)
         drop0 = drop0 || ub_lane <= smin0;  // (a brick with an untouched voxel holds lowest(): never true)
       }
-      if ((__ballot(!drop0) & view_mask) == 0ull) return;
+      if ((__ballot(!drop0) & view_mask) == 0ull) {
+        coop_leave();
+        return;
+      }
     }
   }
 #endif
@@ -1455,7 +1494,54 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     if (lane == 0) brick_min[brick_lin] = smin;
   }
 #endif
-  if (lane_valid) {
+  if (coop) {
+    // Cooperative write-back.  A wave's own stores are 64 pieces of 16 bytes in 64 different rows; the 128-byte line of
+    // a row is completed by the other three waves of the workgroup at other times, and in a launch that also READS the
+    // state (a view over a carved grid) the L2 writes such lines back before they are complete: 10.4 GB written for
+    // 6.4 GB of state at 1024^3 in weighted-average mode, and four write requests where one would do
+    // (profiles/r04/per_view_tsdf_pmc.txt).  Here every wave leaves its runs in LDS (row = lane, columns of its brick),
+    // and after one barrier the waves share out the 64 rows of the workgroup's 32 x 8 x 8 block: 8 lanes = one
+    // 128-byte row segment of sdf, 4 lanes = one row segment of update_num.  A row is stored when the lane that owned
+    // it changed (coop_mask: a wave that left early, or a lane outside the grid, owns none).
+    const bool changed = lane_valid && (fresh != 0 || ((changed_lanes >> lane) & 1ull) != 0ull);
+    const unsigned long long my_mask = __ballot(changed);
+    {
+      lds_float4* rs = (lds_float4*)(float4*)(coop_s + lane * kCoopSdfPitch + wave * WX);
+      rs[0] = f4{s[0], s[1], s[2], s[3]};
+      rs[1] = f4{s[4], s[5], s[6], s[7]};
+      CountVec8 cv;
+#pragma unroll
+      for (int k = 0; k < WX; ++k) cv[k] = (CountT)n[k];
+      *(lds_countvec*)(CountVec8*)(coop_n + lane * coop_cnt_pitch<CountT>() + wave * WX) = cv;
+      if (lane == 0) coop_mask[wave] = my_mask, coop_mask[kWgWaves + wave] = 1ull;
+    }
+    __syncthreads();
+    // the row groups are dealt to the waves that are still here (a wave whose every view was dropped has left)
+    int n_here = 0, my_rank = 0;
+#pragma unroll
+    for (int w = 0; w < kWgWaves; ++w) {
+      const int here = __builtin_amdgcn_readfirstlane((int)coop_mask[kWgWaves + w]);
+      n_here += here;
+      my_rank += (w < wave) ? here : 0;
+    }
+    const int xb = bx * BX;
+    for (int gi = my_rank; gi < 8; gi += n_here) {  // sdf: 8 rows x 8 chunks of 16 bytes per instruction
+      const int r = gi * 8 + (lane >> 3), ch = lane & 7;
+      if ((coop_mask[ch >> 1] >> r) & 1ull) {
+        const f4 v = *(lds_float4*)(float4*)(coop_s + r * kCoopSdfPitch + ch * 4);
+        const int64_t rowg = ((int64_t)(zl0 + (r >> 3)) * g.ny + (by * BY + (r & 7))) * g.nx;
+        *(float4*)(g.sdf + rowg + xb + ch * 4) = make_float4(v.x, v.y, v.z, v.w);
+      }
+    }
+    for (int gi = my_rank; gi < 4; gi += n_here) {  // update_num: 16 rows x 4 chunks of 8 counters per instruction
+      const int r = gi * 16 + (lane >> 2), ch = lane & 3;
+      if ((coop_mask[ch] >> r) & 1ull) {
+        const CountVec8 cv = *(lds_countvec*)(CountVec8*)(coop_n + r * coop_cnt_pitch<CountT>() + ch * WX);
+        const int64_t rowg = ((int64_t)(zl0 + (r >> 3)) * g.ny + (by * BY + (r & 7))) * g.nx;
+        *(CountVec8*)(cnt + rowg + xb + ch * WX) = cv;
+      }
+    }
+  } else if (lane_valid) {
     if (vec_io) {
       bool changed = fresh != 0;  // (a fresh slab has never been written: every voxel is stored)
 #ifdef VCY_FLOOR_NO_STORES  // development build (issue floor): results stay live, nothing is stored
@@ -1510,7 +1596,8 @@ void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const Gri
   const bool gen = m.ortho != 0 || m.interp == VCY_INTERP_NN;
 #define VCY_FUSED(CM, TQ_, GEN_, DIV_)                                                                           \
   hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, CM, TQ_, GEN_, DIV_>), grid, dim3(64 * kWgWaves),  \
-                     (size_t)kWgWaves * tile_f4_per_wave<TQ_>() * sizeof(float4) + (size_t)kWgWaves * nv * sizeof(TileInfo), s, \
+                     (size_t)kWgWaves * tile_f4_per_wave<TQ_>() * sizeof(float4) + (size_t)kWgWaves * nv * sizeof(TileInfo) + \
+                         ((fresh & 8) ? coop_lds_bytes<CountT>() : 0), s,                                         \
                      g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt)
 #define VCY_FUSED_G(CM, TQ_)                                                                                     \
   do {                                                                                                           \
@@ -1880,7 +1967,14 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
                        c->stream, c->d_brick_min, nb);
     VCY_HIP_CHECK(hipGetLastError());
   }
-  const int state_flags = (c->fresh ? 1 : 0) | (c->cnt_implied ? 2 : 0) | (c->brick_min_valid && !c->fresh ? 4 : 0);
+  // Cooperative write-back (carve_fused_kernel): pays where a launch reads AND rewrites most of the state for little
+  // arithmetic -- few views over a carved grid in a weighted-average mode ("coopstore": -1 that rule, 0 never, 1 always
+  // when the layout allows it: rows of whole bricks, four waves per workgroup, raw tiles, not a fresh slab).
+  const bool coop_ok = kWgWaves == 4 && (c->nx & (WX - 1)) == 0 && !c->fresh && !big;
+  const bool coop = coop_ok && (c->coop_store > 0 || (c->coop_store < 0 && u.voxel_update == VCY_UPDATE_WEIGHTED_AVERAGE &&
+                                                      n_views <= kLiveListMaxViews));
+  const int state_flags = (c->fresh ? 1 : 0) | (c->cnt_implied ? 2 : 0) | (c->brick_min_valid && !c->fresh ? 4 : 0) |
+                          (coop ? 8 : 0);
   // Raw tiles: the footprint records of every (wave brick, view) pair come from a pre-pass (footprint_records_kernel),
   // 8 bytes per pair.  The slab is carved in chunks of whole brick layers so that the records of a chunk stay
   // below kRecordBytesMax (1024^3 x 32 views: 0.5 GiB, one chunk; 2048^3 x 64: nine).
