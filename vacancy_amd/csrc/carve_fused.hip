@@ -102,6 +102,13 @@ constexpr int64_t kRecordBytesMax = (int64_t)1 << 30;  // footprint records of o
 #ifndef VCY_WAVES_CHECKED
 #define VCY_WAVES_CHECKED 5
 #endif
+// The unit-weight weighted average keeps update_num as floats next to sdf and carries the brick-wide weights: at 7 waves
+// its PROLOGUE spills 24 bytes per lane, which every wave executes -- 3 GB of scratch written back per single-view
+// launch at 1024^3 (the L2 turns over every 8 us there), a third of what the launch has to write at all
+// (profiles/r04/per_view_tsdf_pmc.txt).
+#ifndef VCY_WAVES_WA
+#define VCY_WAVES_WA 6
+#endif
 
 
 // Development build only (-DVCY_PHASE_TIMING, profiles/tools/phase_timing.py): s_memtime ticks of every wave,
@@ -357,6 +364,9 @@ __device__ __forceinline__ void raw_prefetch(const ViewParams& v, const TileInfo
 #ifdef VCY_FLOOR_NO_TILE_LOADS  // development build (issue floor, profiles/tools/issue_floor.sh): the taps read whatever LDS holds
   return;
 #endif
+  // (opaque: lane >> 4 and lane & 15 are formed here, every time -- hoisted out of the view loop they were two more
+  // registers live through every view, and the weighted-average kernels spilled exactly those to scratch)
+  asm volatile("" : "+v"(lane));
   const int nq = __builtin_amdgcn_readfirstlane(ti.nq);
   if (nq == 0) return;
   const int th = __builtin_amdgcn_readfirstlane(ti.th);
@@ -885,7 +895,8 @@ __global__ __launch_bounds__(256) void live_workgroups_kernel(const FootprintRec
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX, int TQ, bool GEN, int DIV>
 __global__ __launch_bounds__(64 * kWgWaves)
 __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDATE != VCY_UPDATE_WEIGHTED_AVERAGE)
-                                       ? VCY_WAVES : VCY_WAVES_CHECKED))) void carve_fused_kernel(GridParams g,
+                                       ? (UPDATE == kUpdateWaUnitWeight ? VCY_WAVES_WA : VCY_WAVES)
+                                       : VCY_WAVES_CHECKED))) void carve_fused_kernel(GridParams g,
                                                           const FusedView* __restrict__ views,
                                                           const float* __restrict__ c0_all,
                                                           int nviews, ModeParams mode, int nbx,
@@ -905,7 +916,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   //              bit 3 = cooperative write-back through LDS (below)
   const int fresh = state_flags & 1;
   const bool implied = (state_flags & 2) != 0;
-  const bool coop = kWgWaves == 4 && (state_flags & 8) != 0;
+  const bool coop = (kWgWaves == 4 || kWgWaves == 8) && (state_flags & 8) != 0;
   // dynamic LDS: [4 waves][TQ] quads, then [4 waves][nviews] TileInfo (sized by the launch), then the staging of the
   // cooperative write-back
   extern __shared__ float4 fused_lds[];
@@ -1083,6 +1094,31 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   float s[WX];
   NT n[WX];
   const int64_t row0 = ((int64_t)zl * g.ny + y) * g.nx;  // this lane's row; voxel k is at row0 + min(x_first + k, nx - 1)
+  // The first view this brick will process is usually known BEFORE its state is: it is the first view the bounds do not
+  // drop, and what the bounds are compared with -- the truncation limit, the brick minimum the previous launch left --
+  // is already here.  Its tile is then requested right behind the state instead of after the state has arrived and been
+  // looked at: one memory round trip less in a wave's chain, which is most of what a launch of ONE view consists of.
+  // (kMax without valid minima: not known, vi_pre stays -1.  live_views() below decides as before; the request is
+  // repeated there if it names another view -- it never does -- and loads complete in order, so the later one wins.)
+  int vi_pre = -1;
+  auto prefetch_first_tile = [&]() {
+    if constexpr (kRaw) {
+      const bool have_min = UPDATE == VCY_UPDATE_MAX && !fresh && (state_flags & 4) != 0 && brick_min != nullptr;
+      if (!(fresh || UPDATE != VCY_UPDATE_MAX || !want_bound || have_min)) return;
+      bool drop = false;
+      if (want_bound) {
+        if (TRUNC) drop = ub_lane < -1.0f;
+        if (have_min) {
+          const float smin0 = ((cfloat_ptr)brick_min)[brick_lin];
+          // (lowest(): a voxel of the brick is untouched -- all_touched will be false and nothing is dropped by this rule)
+          if (smin0 != kInvalidSdf) drop = drop || ub_lane <= smin0;
+        }
+      }
+      const unsigned long long lp = __ballot(!drop) & view_mask;
+      vi_pre = lp ? (__ffsll((long long)lp) - 1) : nviews;
+      if (vi_pre < nviews) raw_prefetch(views[vi_pre].v, tinfo[vi_pre], lane, raw_buf(0));
+    }
+  };
   // rows are whole bricks when nx % 8 == 0: the run is one 32-byte (sdf) and one 8/16-byte (update_num) vector
   const bool vec_io = (g.nx & (WX - 1)) == 0;
   typedef CountT CountVec __attribute__((ext_vector_type(WX)));
@@ -1095,6 +1131,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   } else if (vec_io) {
     const float4 a = *(const float4*)(g.sdf + row0 + x_first), b4 = *(const float4*)(g.sdf + row0 + x_first + 4);
     const CountVec cv = *(const CountVec*)(cnt + row0 + x_first);
+    prefetch_first_tile();  // (behind the state's requests, in front of their first use)
     s[0] = a.x, s[1] = a.y, s[2] = a.z, s[3] = a.w, s[4] = b4.x, s[5] = b4.y, s[6] = b4.z, s[7] = b4.w;
 #pragma unroll
     for (int k = 0; k < WX; ++k) n[k] = (NT)cv[k];
@@ -1179,7 +1216,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   unsigned long long changed_lanes = 0ull;
   unsigned long long live = live_views();
   int vi = live ? (__ffsll((long long)live) - 1) : nviews;
-  if (kRaw && vi < nviews) raw_prefetch(views[vi].v, tinfo[vi], lane, raw_buf(0));
+  if (kRaw && vi < nviews && vi != vi_pre) raw_prefetch(views[vi].v, tinfo[vi], lane, raw_buf(0));
   VCY_PT(0);
   VCY_PT_COUNT(10);
 
@@ -1482,6 +1519,15 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
 
   // ---- write back what changed (update_num grows with every change) ----------------------------
   leave_uniform();
+  // Where this lane's run lies is worked out again from the thread id (opaque to the compiler): kept from the prologue
+  // it occupies three registers through every view, and the weighted-average kernels are short of exactly those --
+  // their loop pre-header spilled to scratch, which every wave executes.
+  int tid_w = (int)threadIdx.x;
+  asm volatile("" : "+v"(tid_w));
+  const int lane_w = tid_w & 63;
+  const int y_w = by * BY + (lane_w & (BY - 1)), zl_w = zl0 + (lane_w >> 3);
+  const bool lane_valid_w = y_w < g.ny && zl_w < g.nz_local;
+  const int64_t row0_w = ((int64_t)min(zl_w, g.nz_local - 1) * g.ny + min(y_w, g.ny - 1)) * g.nx;
   // ("paircount" 1: (brick, view) pairs processed, per brick layer of the launch -- what the slab planner's
   // estimate is checked against, and what bench.py reports as the fraction of pairs the scene leaves)
   if (pair_count != nullptr && lane == 0) atomicAdd(&pair_count[bz], (unsigned long long)n_processed);
@@ -1503,16 +1549,16 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     // and after one barrier the waves share out the 64 rows of the workgroup's 32 x 8 x 8 block: 8 lanes = one
     // 128-byte row segment of sdf, 4 lanes = one row segment of update_num.  A row is stored when the lane that owned
     // it changed (coop_mask: a wave that left early, or a lane outside the grid, owns none).
-    const bool changed = lane_valid && (fresh != 0 || ((changed_lanes >> lane) & 1ull) != 0ull);
+    const bool changed = lane_valid_w && (fresh != 0 || ((changed_lanes >> lane_w) & 1ull) != 0ull);
     const unsigned long long my_mask = __ballot(changed);
     {
-      lds_float4* rs = (lds_float4*)(float4*)(coop_s + lane * kCoopSdfPitch + wave * WX);
+      lds_float4* rs = (lds_float4*)(float4*)(coop_s + lane_w * kCoopSdfPitch + wave * WX);
       rs[0] = f4{s[0], s[1], s[2], s[3]};
       rs[1] = f4{s[4], s[5], s[6], s[7]};
       CountVec8 cv;
 #pragma unroll
       for (int k = 0; k < WX; ++k) cv[k] = (CountT)n[k];
-      *(lds_countvec*)(CountVec8*)(coop_n + lane * coop_cnt_pitch<CountT>() + wave * WX) = cv;
+      *(lds_countvec*)(CountVec8*)(coop_n + lane_w * coop_cnt_pitch<CountT>() + wave * WX) = cv;
       if (lane == 0) coop_mask[wave] = my_mask, coop_mask[kWgWaves + wave] = 1ull;
     }
     __syncthreads();
@@ -1525,23 +1571,35 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
       my_rank += (w < wave) ? here : 0;
     }
     const int xb = bx * BX;
-    for (int gi = my_rank; gi < 8; gi += n_here) {  // sdf: 8 rows x 8 chunks of 16 bytes per instruction
-      const int r = gi * 8 + (lane >> 3), ch = lane & 7;
+    // sdf: a row of the block is 2 kWgWaves chunks of 16 bytes, an instruction covers 64 / (2 kWgWaves) rows
+    constexpr int kSdfChunks = 2 * kWgWaves, kSdfRows = 64 / kSdfChunks;
+    for (int gi = my_rank; gi < 64 / kSdfRows; gi += n_here) {
+      const int r = gi * kSdfRows + lane / kSdfChunks, ch = lane % kSdfChunks;
       if ((coop_mask[ch >> 1] >> r) & 1ull) {
         const f4 v = *(lds_float4*)(float4*)(coop_s + r * kCoopSdfPitch + ch * 4);
         const int64_t rowg = ((int64_t)(zl0 + (r >> 3)) * g.ny + (by * BY + (r & 7))) * g.nx;
+#ifndef VCY_DEV_SKIP_SDF_STORE  // (development builds: which of the two arrays the written bytes belong to)
         *(float4*)(g.sdf + rowg + xb + ch * 4) = make_float4(v.x, v.y, v.z, v.w);
+#else
+        if (v.x == 1.2345e-30f) g.sdf[0] = v.y;
+#endif
       }
     }
-    for (int gi = my_rank; gi < 4; gi += n_here) {  // update_num: 16 rows x 4 chunks of 8 counters per instruction
-      const int r = gi * 16 + (lane >> 2), ch = lane & 3;
+    // update_num: kWgWaves chunks of 8 counters per row, 64 / kWgWaves rows per instruction
+    constexpr int kCntRows = 64 / kWgWaves;
+    for (int gi = my_rank; gi < 64 / kCntRows; gi += n_here) {
+      const int r = gi * kCntRows + lane / kWgWaves, ch = lane % kWgWaves;
       if ((coop_mask[ch] >> r) & 1ull) {
         const CountVec8 cv = *(lds_countvec*)(CountVec8*)(coop_n + r * coop_cnt_pitch<CountT>() + ch * WX);
         const int64_t rowg = ((int64_t)(zl0 + (r >> 3)) * g.ny + (by * BY + (r & 7))) * g.nx;
+#ifndef VCY_DEV_SKIP_CNT_STORE
         *(CountVec8*)(cnt + rowg + xb + ch * WX) = cv;
+#else
+        if (cv[0] == (CountT)12345) cnt[0] = cv[1];
+#endif
       }
     }
-  } else if (lane_valid) {
+  } else if (lane_valid_w) {
     if (vec_io) {
       bool changed = fresh != 0;  // (a fresh slab has never been written: every voxel is stored)
 #ifdef VCY_FLOOR_NO_STORES  // development build (issue floor): results stay live, nothing is stored
@@ -1552,23 +1610,23 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
         changed = ssum == 1.2345e-30f && nsum == 777.25f;
       }
 #else
-      changed = changed || ((changed_lanes >> lane) & 1ull) != 0ull;
+      changed = changed || ((changed_lanes >> lane_w) & 1ull) != 0ull;
 #endif
       if (changed) {
 #ifdef VCY_FLOOR_DUMMY_STORES  // development build: the same store instructions, all into 64 rows of ONE brick row (never reach HBM)
         const int64_t row0_ = ((int64_t)(lane >> 3) * g.ny + (lane & 7)) * g.nx;
         const int x_first_ = (x_first & 1023);
-#define row0 row0_
+#define row0_w row0_
 #define x_first x_first_
 #endif
-        *(float4*)(g.sdf + row0 + x_first) = make_float4(s[0], s[1], s[2], s[3]);
-        *(float4*)(g.sdf + row0 + x_first + 4) = make_float4(s[4], s[5], s[6], s[7]);
+        *(float4*)(g.sdf + row0_w + x_first) = make_float4(s[0], s[1], s[2], s[3]);
+        *(float4*)(g.sdf + row0_w + x_first + 4) = make_float4(s[4], s[5], s[6], s[7]);
         CountVec cv;
 #pragma unroll
         for (int k = 0; k < WX; ++k) cv[k] = (CountT)n[k];
-        *(CountVec*)(cnt + row0 + x_first) = cv;
+        *(CountVec*)(cnt + row0_w + x_first) = cv;
 #ifdef VCY_FLOOR_DUMMY_STORES
-#undef row0
+#undef row0_w
 #undef x_first
 #endif
       }
@@ -1576,8 +1634,8 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
 #pragma unroll
       for (int k = 0; k < WX; ++k) {
         if (x_first + k < g.nx) {
-          const int64_t idx = row0 + x_first + k;
-          if (fresh || ((changed_lanes >> lane) & 1ull) != 0ull) {  // (unchanged voxels of a changed lane store what they hold)
+          const int64_t idx = row0_w + x_first + k;
+          if (fresh || ((changed_lanes >> lane_w) & 1ull) != 0ull) {  // (unchanged voxels of a changed lane store what they hold)
             g.sdf[idx] = s[k];
             cnt[idx] = (CountT)n[k];
           }
@@ -1967,12 +2025,12 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
                        c->stream, c->d_brick_min, nb);
     VCY_HIP_CHECK(hipGetLastError());
   }
-  // Cooperative write-back (carve_fused_kernel): pays where a launch reads AND rewrites most of the state for little
-  // arithmetic -- few views over a carved grid in a weighted-average mode ("coopstore": -1 that rule, 0 never, 1 always
-  // when the layout allows it: rows of whole bricks, four waves per workgroup, raw tiles, not a fresh slab).
-  const bool coop_ok = kWgWaves == 4 && (c->nx & (WX - 1)) == 0 && !c->fresh && !big;
-  const bool coop = coop_ok && (c->coop_store > 0 || (c->coop_store < 0 && u.voxel_update == VCY_UPDATE_WEIGHTED_AVERAGE &&
-                                                      n_views <= kLiveListMaxViews));
+  // Cooperative write-back (carve_fused_kernel): pays where a launch reads and rewrites the state for little arithmetic
+  // -- few views over a carved grid (1024^3, one view per launch: weighted average 4.39 -> 3.41 ms, kMax 0.89 -> 0.84).
+  // "coopstore": -1 that rule, 0 never, 1 always when the layout allows it: rows of whole bricks, four waves per
+  // workgroup, raw tiles, not a fresh slab.
+  const bool coop_ok = (kWgWaves == 4 || kWgWaves == 8) && (c->nx & (WX - 1)) == 0 && !c->fresh && !big;
+  const bool coop = coop_ok && (c->coop_store > 0 || (c->coop_store < 0 && n_views <= kLiveListMaxViews));
   const int state_flags = (c->fresh ? 1 : 0) | (c->cnt_implied ? 2 : 0) | (c->brick_min_valid && !c->fresh ? 4 : 0) |
                           (coop ? 8 : 0);
   // Raw tiles: the footprint records of every (wave brick, view) pair come from a pre-pass (footprint_records_kernel),
