@@ -74,6 +74,10 @@ def parse(argv=None):
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the extra measurements of the same kernel without view dropping and in TSDF mode")
+    ap.add_argument("--variants", default="all",
+                    help="which of the extra measurements to run, comma separated: modes (cull0, tsdf), scenes (hard_scene, "
+                         "two_batches), per_view (the reference's one-view-per-call loops), streamed (silhouettes from host "
+                         "memory); default all")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--allow-gloo", action="store_true",
                     help="let the halo exchange fall back to gloo (host staging) when RCCL cannot initialise; "
@@ -787,7 +791,10 @@ def main():
     # (warm device, steps queued back to back) so that the headline's dependence on scene and call pattern is in the
     # driver's record.
     variants = None
-    if world == 1 and not args.no_variants and args.batch:
+    want = set() if args.no_variants else set(x.strip() for x in args.variants.split(","))
+    if "all" in want:
+        want = {"modes", "scenes", "per_view", "streamed"}
+    if world == 1 and want and args.batch:
         variants = {}
 
         def rate_record(ms, pre, ker, mode, u, extra=None):
@@ -801,7 +808,7 @@ def main():
             return rec
 
         for name, mode, cull in (("cull0", args.mode, 0), ("tsdf", "tsdf", 1)):
-            if mode == args.mode and cull == args.cull:
+            if (mode == args.mode and cull == args.cull) or "modes" not in want:
                 continue
             try:
                 u2 = update_option(mode)
@@ -832,6 +839,8 @@ def main():
         #     (6.4 GB at 1024^3) instead of starting from a fresh grid.  voxel_carver.cc:442-491 costs the same whatever
         #     the scene; this path does not, and the line says by how much.
         try:
+            if "scenes" not in want:
+                raise StopIteration
             cs = make_carvers(opt, args.cull, my_slabs)
             c0 = cs[0]
             hv, hm = synth.blob_views(n, nv, args.width, args.height)
@@ -852,6 +861,8 @@ def main():
                 "pairs_processed_frac": pairs_of(c0, [lambda c: c.CarveBatchDevice(ba), lambda c: c.CarveBatchDevice(bb)])})
             for c in reversed(cs):
                 c.close()
+        except StopIteration:
+            pass
         except Exception as e:
             variants.setdefault("hard_scene", {"error": "%s: %s" % (type(e).__name__, e)})
             variants.setdefault("two_batches", {"error": "%s: %s" % (type(e).__name__, e)})
@@ -864,7 +875,7 @@ def main():
         # (VoxelUpdate::kWeightedAverage + truncation: every view changes nearly every brick).
         for name, extract, mode in (("per_view_interleaved", True, args.mode), ("per_view_defer0", False, args.mode),
                                     ("per_view_tsdf", False, "tsdf")):
-            if name == "per_view_tsdf" and args.mode == "tsdf":
+            if (name == "per_view_tsdf" and args.mode == "tsdf") or "per_view" not in want:
                 continue
             try:
                 u2 = update_option(mode)
@@ -920,6 +931,8 @@ def main():
         # page-locked staging -> DMA -> SDF build on the device -> fused carve, in chunks of 32 views with chunk i + 1
         # produced while chunk i is carved.  Wall time of the call (PCIe inclusive: never `value`).
         try:
+            if "streamed" not in want:
+                raise StopIteration
             cs = make_carvers(opt, args.cull, my_slabs)
             c0 = cs[0]
             walls = []
@@ -941,6 +954,8 @@ def main():
                         "overlap and overlap = the longer side's share of the wall time"}
             for c in reversed(cs):
                 c.close()
+        except StopIteration:
+            pass
         except Exception as e:
             variants["streamed_silhouettes"] = {"error": "%s: %s" % (type(e).__name__, e)}
 

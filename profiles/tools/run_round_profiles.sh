@@ -57,6 +57,6 @@ echo "2 ranks (rccl on one device, expected to be refused) rc=$?" >> "$O/status.
 mkdir -p profiles && cp "$CTR" profiles/counters.json
 python bench.py > "$O/bench_1024x32_default.json" 2> "$O/bench_default.err"; echo "bench default rc=$?" >> "$O/status.txt"
 python bench.py --config 1 --no-variants > "$O/bench_512x16_tsdf_config1.json" 2> "$O/bench_config1.err"; echo "bench config1 rc=$?" >> "$O/status.txt"
-python bench.py --config 4 --steps 5 --warmup 1 --no-variants --no-cpu-baseline --no-mc > "$O/bench_2048x64_config4.json" 2> "$O/bench_config4.err"; echo "bench config4 rc=$?" >> "$O/status.txt"
+python bench.py --config 4 --steps 5 --warmup 1 --variants streamed --no-cpu-baseline --no-mc > "$O/bench_2048x64_config4.json" 2> "$O/bench_config4.err"; echo "bench config4 rc=$?" >> "$O/status.txt"
 cat "$O/status.txt"
 ls "$O"

@@ -2030,7 +2030,10 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   // "coopstore": -1 that rule, 0 never, 1 always when the layout allows it: rows of whole bricks, four waves per
   // workgroup, raw tiles, not a fresh slab.
   const bool coop_ok = (kWgWaves == 4 || kWgWaves == 8) && (c->nx & (WX - 1)) == 0 && !c->fresh && !big;
-  const bool coop = coop_ok && (c->coop_store > 0 || (c->coop_store < 0 && n_views <= kLiveListMaxViews));
+  // (kMax: only single-view launches -- with 4 or 8 views per launch the waves of a workgroup process different numbers
+  // of views and the barrier costs 3 - 4 %, profiles/r04/coop_store_batches.txt; weighted average: up to 8 views, 0 ... +2 %)
+  const bool coop = coop_ok && (c->coop_store > 0 ||
+                                (c->coop_store < 0 && n_views <= (u.voxel_update == VCY_UPDATE_MAX ? 1 : kLiveListMaxViews)));
   const int state_flags = (c->fresh ? 1 : 0) | (c->cnt_implied ? 2 : 0) | (c->brick_min_valid && !c->fresh ? 4 : 0) |
                           (coop ? 8 : 0);
   // Raw tiles: the footprint records of every (wave brick, view) pair come from a pre-pass (footprint_records_kernel),
