@@ -285,7 +285,9 @@ int vcy_reset(vcy_ctx* ctx);
  * it or copied: a third of the mesh bytes) -- for callers that do not merge z-slabs, i.e. what the reference's
  * MarchingCubes returns.
  * "mcskip" (default 1): vcy_extract_iso does not read bricks whose minimum -- kept per 8 x 8 x 8 brick by the fused
- * carve kernel -- lies above the iso level (they are outside the surface whatever they hold exactly); 0 reads every brick.
+ * carve kernel -- lies above the iso level (they are outside the surface whatever they hold exactly); 0 reads every
+ * brick; 1 skips them where that is the faster pass (voxel rows of 1024 and more: at 512^3 the dense pass wins by 7 - 14 %);
+ * 2 skips them on any size (what the parity tests ask for).
  * "livelist" (default 1): a carve launch of up to 8 views over an already carved grid first lists the workgroups in
  * which some view can still change a voxel (bounds of the views' samples against the kept brick minima / the
  * truncation limit) and starts only those; 0 starts every workgroup and lets each decide for itself.

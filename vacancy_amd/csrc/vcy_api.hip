@@ -485,7 +485,7 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
     return VCY_OK;
   }
   if (std::strcmp(name, "mcskip") == 0) {
-    c->mc_skip = value != 0;
+    c->mc_skip = value <= 0 ? 0 : (value >= 2 ? 2 : 1);
     return VCY_OK;
   }
   if (std::strcmp(name, "meshkeys") == 0) {
@@ -505,7 +505,7 @@ int vcy_get_param(vcy_ctx* c, const char* name, int* value) {
   else if (std::strcmp(name, "shortdiv") == 0) *value = c->use_short_div ? 1 : 0;
   else if (std::strcmp(name, "div_level") == 0) *value = c->last_div_level;
   else if (std::strcmp(name, "mcsweep") == 0) *value = c->mc_sweep ? 1 : 0;
-  else if (std::strcmp(name, "mcskip") == 0) *value = c->mc_skip ? 1 : 0;
+  else if (std::strcmp(name, "mcskip") == 0) *value = c->mc_skip;
   else if (std::strcmp(name, "livelist") == 0) *value = c->use_live_list ? 1 : 0;
   else if (std::strcmp(name, "coopstore") == 0) *value = c->coop_store;
   else if (std::strcmp(name, "brick_min_valid") == 0) *value = c->brick_min_valid && !c->fresh ? 1 : 0;

@@ -67,7 +67,7 @@ struct vcy_ctx {
   float* d_pz = nullptr;
 
   bool mesh_keys = true;              // vcy_extract_iso also returns the edge key of every vertex (vcy_set_param "meshkeys")
-  bool mc_skip = true;                // marching cubes: bricks whose kept minimum is above the iso level are not read (vcy_set_param "mcskip")
+  int mc_skip = 1;                    // marching cubes: bricks whose kept minimum is above the iso level are not read (vcy_set_param "mcskip": 0 never, 1 where it pays -- rows of 1024 voxels and more --, 2 wherever possible)
   bool mc_sweep = false;              // marching cubes: cell search in one sweep with the bit planes in LDS where the row shape allows (vcy_set_param "mcsweep")
   int tile_mode = 0;                  // 0 auto, 1 the 16 x 16 pixel tile, 2 the 2048-pixel tile filled in place (vcy_set_param "tile")
   bool use_cull = true;               // vcy_set_param("cull", 0): never drop provably idle views
