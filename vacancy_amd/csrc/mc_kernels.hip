@@ -238,10 +238,6 @@ __global__ __launch_bounds__(256) void mc_bits_kernel(const float* __restrict__ 
 // predicated by bits it already holds -- whole 64-voxel words of skipped bricks cost no instruction at all.
 // For rows that are whole words (nx == 64 Wr) of an owned slab whose state implies TC == OK.
 constexpr int kBricksMaxNbw = 1024;  // bricks along x (nx <= 8192)
-#ifndef VCY_BRICK_ROWS_IN_FLIGHT
-#define VCY_BRICK_ROWS_IN_FLIGHT 1   // (2 and 4 measured: no difference, the pass is not bound by requests in flight)
-#endif
-
 template <bool ISO_F32>
 __global__ __launch_bounds__(256) void mc_bits_bricks_kernel(const float* __restrict__ sdf, int ny, int nz, int Wr,
                                                              double iso, u64* __restrict__ in, u64* __restrict__ ok,
@@ -278,50 +274,72 @@ __global__ __launch_bounds__(256) void mc_bits_bricks_kernel(const float* __rest
       word_skip |= (byte == 255u ? 1u : 0u) << k;
       lane_skip |= ((byte >> (lane >> 3)) & 1u) << k;
     }
-    // this wave's 16 rows of the brick row, kRowsInFlight at a time: the loads of all of them are requested
-    // before the first ballot (one row alone keeps at most 16 x 256 bytes of a wave in flight, a quarter of that
-    // after the skipped bricks)
-    constexpr int kRowsInFlight = VCY_BRICK_ROWS_IN_FLIGHT;
-    for (int i0 = 0; i0 < 16; i0 += kRowsInFlight) {
-      float s[kRowsInFlight][16];
-      int64_t rows[kRowsInFlight];
-      bool valid[kRowsInFlight];
+    // This wave's 16 rows of the brick row, four at a time, and of each row only the words that hold a brick to be read
+    // (`live`, uniform), four of those at a time: 16 loads in flight per pass.  (Round 3 walked a row's 16 words with
+    // predicated loads, one row per memory round trip: in a carved grid a quarter of the words are live, so a wave had
+    // four loads in flight and sixteen round trips in a row -- the pass moved its 1.4 GB at 3.6 TB/s.)
+    const uint32_t live = ~word_skip & ((nw >= 32 ? 0u : (1u << nw)) - 1u);
+    for (int i0 = 0; i0 < 16; i0 += 4) {
+      int64_t rows[4];
+      bool valid[4];
+      const float* __restrict__ ps[4];
+      u64 m_in[4], m_ok[4];
 #pragma unroll
-      for (int q = 0; q < kRowsInFlight; ++q) {
+      for (int q = 0; q < 4; ++q) {
         const int r = wave * 16 + i0 + q;
         const int yy = by * 8 + (r & 7), zz = bz * 8 + (r >> 3);
         valid[q] = yy < ny && zz < nz;  // (uniform)
         rows[q] = (int64_t)zz * ny + yy;
-        const float* __restrict__ ps = sdf + rows[q] * nx + (int64_t)w0 * 64 + lane;
+        ps[q] = sdf + rows[q] * nx + (int64_t)w0 * 64 + lane;
+        m_in[q] = 0ull;   // a skipped brick: outside ...
+        m_ok[q] = ~0ull;  // ... and valid
+      }
+      uint32_t rest = live;
+      while (rest != 0u) {  // (uniform)
+        int kk[4];
+        int cnt = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          s[q][k] = INFINITY;  // outside and valid
-          if (valid[q] && k < nw && !((word_skip >> k) & 1u)) {      // (uniform)
-            if (!((lane_skip >> k) & 1u)) s[q][k] = __builtin_nontemporal_load(ps + k * 64);
+        for (int j = 0; j < 4; ++j) {
+          kk[j] = 0;
+          if (rest != 0u) {
+            kk[j] = __builtin_ctz(rest);
+            rest &= rest - 1u;
+            cnt = j + 1;
+          }
+        }
+        float sv[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            sv[q][j] = INFINITY;  // outside and valid
+            if (valid[q] && j < cnt) {                                                  // (uniform)
+              if (!((lane_skip >> kk[j]) & 1u)) sv[q][j] = __builtin_nontemporal_load(ps[q] + kk[j] * 64);
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (valid[q] && j < cnt) {                                                  // (uniform)
+              const u64 a = __ballot(ISO_F32 ? sv[q][j] < (float)iso : (double)sv[q][j] < iso);
+              const u64 b = __ballot(sv[q][j] != kInvalidSdf);
+              const bool mine = lane == kk[j];
+              m_in[q] = mine ? a : m_in[q];
+              m_ok[q] = mine ? b : m_ok[q];
+            }
           }
         }
       }
 #pragma unroll
-      for (int q = 0; q < kRowsInFlight; ++q) {
-        if (!valid[q]) continue;
-        u64 m_in = 0, m_ok = ~0ull;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          if (k < nw && !((word_skip >> k) & 1u)) {      // (uniform)
-            const u64 a = __ballot(ISO_F32 ? s[q][k] < (float)iso : (double)s[q][k] < iso);
-            const u64 b = __ballot(s[q][k] != kInvalidSdf);
-            const bool mine = lane == k;
-            m_in = mine ? a : m_in;
-            m_ok = mine ? b : m_ok;
-          }
-        }
-        if (lane < nw) {
+      for (int q = 0; q < 4; ++q) {
+        if (valid[q] && lane < nw) {
           const int64_t o = rows[q] * Wr + w0 + lane;
-          in[o] = m_in;
-          ok[o] = m_ok;
-          if (tc != nullptr) tc[o] = m_ok;
+          in[o] = m_in[q];
+          ok[o] = m_ok[q];
+          if (tc != nullptr) tc[o] = m_ok[q];
         }
-
       }
     }
   }
