@@ -861,10 +861,15 @@ __global__ __launch_bounds__(256) void footprint_records_kernel(GridParams g, co
 // most workgroups would only start, load 8 bytes and leave; 2 M such waves cost more than the bricks that do
 // change.  This pass lists the workgroups with a live pair, list[0] = their number, list[1 ...] = their linear
 // ids (any order); the carve kernel is launched over the full range and workgroups beyond list[0] leave at once.
-__global__ __launch_bounds__(256) void live_workgroups_kernel(const FootprintRecord* __restrict__ recs, int64_t nbricks,
-                                                              int nviews, const float* __restrict__ bmin, int trunc,
-                                                              int nbx, int nby, int nbw, int nwg, int* __restrict__ list) {
-  const int wg = blockIdx.x * 256 + threadIdx.x;
+constexpr int kLiveThreads = 1024;
+__global__ __launch_bounds__(kLiveThreads) void live_workgroups_kernel(const FootprintRecord* __restrict__ recs, int64_t nbricks,
+                                                                       int nviews, const float* __restrict__ bmin, int trunc,
+                                                                       int nbx, int nby, int nbw, int nwg, int* __restrict__ list) {
+  // (one atomic per block of 1024 workgroups: one per WAVE -- 8192 of them on one counter at 1024^3 -- took 78 us of a
+  // 0.8 ms single-view launch, the serialised atomics, not the 25 MB it reads)
+  __shared__ int wave_count[kLiveThreads / 64];
+  __shared__ int block_base;
+  const int wg = blockIdx.x * kLiveThreads + threadIdx.x;
   bool live = false;
   if (wg < nwg) {
     const int bx = wg % nbx, r = wg / nbx;
@@ -882,12 +887,20 @@ __global__ __launch_bounds__(256) void live_workgroups_kernel(const FootprintRec
     }
   }
   const unsigned long long m = __ballot(live);
-  if (m == 0ull) return;
-  const int lane = threadIdx.x & 63;
-  int base = 0;
-  if (lane == 0) base = atomicAdd(&list[0], __popcll(m));
-  base = __shfl(base, 0, 64);
-  if (live) list[1 + base + __popcll(m & ((1ull << lane) - 1ull))] = wg;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_count[wave] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int w = 0; w < kLiveThreads / 64; ++w) {
+      const int c = wave_count[w];
+      wave_count[w] = total;  // exclusive offsets of the waves
+      total += c;
+    }
+    block_base = total ? atomicAdd(&list[0], total) : 0;
+  }
+  __syncthreads();
+  if (live) list[1 + block_base + wave_count[wave] + __popcll(m & ((1ull << lane) - 1ull))] = wg;
 }
 
 // GEN: nearest-neighbour sampling and/or an orthographic camera, selected at run time from `mode`
@@ -1013,7 +1026,6 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   }
   const int zl0 = bz * BZ;
   const int y_raw = by * BY + ly, zl_raw = zl0 + lz;
-  const bool lane_valid = y_raw < g.ny && zl_raw < g.nz_local;
   const int y = min(y_raw, g.ny - 1), zl = min(zl_raw, g.nz_local - 1);  // clones for out-of-grid lanes
   const float py = g.py[y], pz = g.pz[g.z0 + zl];
   // Lane (y, z) walks the WX voxels of its x run: in pc = t + (c0 + (c1 + c2)) (reference association) the
@@ -2118,7 +2130,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
         c->wg_list_bytes = need;
       }
       VCY_HIP_CHECK(hipMemsetAsync(c->d_wg_list, 0, sizeof(int), c->stream));
-      hipLaunchKernelGGL(live_workgroups_kernel, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, c->stream, recs, nbricks,
+      hipLaunchKernelGGL(live_workgroups_kernel, dim3((unsigned)((nwg + kLiveThreads - 1) / kLiveThreads)), dim3(kLiveThreads), 0, c->stream, recs, nbricks,
                          n_views, have_min ? bmin : nullptr, m.trunc, nbx, nby, nbw, nwg, c->d_wg_list);
       VCY_HIP_CHECK(hipGetLastError());
       wgl = c->d_wg_list;
