@@ -30,6 +30,9 @@ profiles/tools/ab_mc_sweep.sh prod 2>&1 | grep mcsweep > "$O/mc_sweep_vs_bit_pla
 # marching cubes with / without the brick minima, the per-view call pattern with / without the live-workgroup list
 python profiles/tools/mc_skip.py 2>&1 | grep mcskip > "$O/marching_cubes_brick_minima.txt"
 for m in default tsdf; do python profiles/tools/per_view.py 1024 $m 2>&1 | grep livelist; done > "$O/per_view_launches.txt"
+# single-view launches: kernel trace (per kernel us per view) and the counters of the weighted-average launch
+for m in default tsdf; do bash profiles/tools/per_view_trace.sh "gpurun_out/$RND/pvt_$m" 1024 $m 16 > "$O/per_view_trace_$m.txt" 2>&1; done
+bash profiles/tools/pmc_per_view.sh "gpurun_out/$RND/pv_tsdf" 1024 tsdf > /dev/null 2>&1; cp "$O/pv_tsdf/summary.txt" "$O/per_view_tsdf_pmc_final.txt"
 # issue floor of the fused kernel: the same instruction stream without tile loads (T), without stores (S), without both
 if [ -f build/variants/floorTS/libvacancy_hip.so ]; then
   profiles/tools/ab_variants.sh "$O/floor" devprod floorT floorS floorTS devprod floorT floorS floorTS > "$O/issue_floor.txt" 2>&1
