@@ -673,8 +673,11 @@ def main():
         # against the shader clock the profiled launch really ran at (GRBM_GUI_ACTIVE counts the busy cycles of each
         # of the 8 XCDs over the launch; 2.4 GHz is the boost clock)
         clk = CLOCK_HZ
-        if ctr.get("GRBM_GUI_ACTIVE") and ctr.get("trace_avg_ns"):
-            clk = ctr["GRBM_GUI_ACTIVE"] / 8.0 / (ctr["trace_avg_ns"] * 1e-9)
+        if ctr.get("shader_clock_hz"):  # busy cycles / duration of the same dispatch, median over the counter pass
+            clk = ctr["shader_clock_hz"]
+            roofline["shader_clock_ghz_profiled"] = round(clk / 1e9, 3)
+        elif ctr.get("GRBM_GUI_ACTIVE") and ctr.get("trace_avg_ns"):
+            clk = min(CLOCK_HZ, ctr["GRBM_GUI_ACTIVE"] / 8.0 / (ctr["trace_avg_ns"] * 1e-9))
             roofline["shader_clock_ghz_profiled"] = round(clk / 1e9, 3)
         # (the counters are of the carve kernel alone: its own duration in the profiled run, not the step's)
         t_kernel = ctr.get("trace_avg_ns", avg_launch_ms * 1e6) * 1e-9

@@ -28,7 +28,7 @@ def main():
         "default_without_stores_only": round(prod[0] / st[0], 4),
         "rates_mvoxel_views_per_s": {k: [round(x) for x in v] for k, v in avg.items()},
         "meaning": "kernel as shipped / same instruction stream without tile loads and stores (1.0 = at its issue floor)",
-        "source": "profiles/r03/issue_floor.txt", "build": library_build(),
+        "source": __import__("os").path.relpath(__import__("os").path.abspath(sys.argv[1]), __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))), "build": library_build(),
     }
     try:
         allc = json.load(open(sys.argv[2]))

@@ -38,6 +38,7 @@ def main():
     full = {}
     for path in sorted(glob.glob(os.path.join(d, "*_counter_collection.csv"))):
         acc = {}
+        dur = {}
         with open(path) as f:
             for row in csv.DictReader(f):
                 k = short(row["Kernel_Name"])
@@ -46,10 +47,18 @@ def main():
                 disp = row["Dispatch_Id"]
                 acc.setdefault(key, {}).setdefault(disp, 0.0)
                 acc[key][disp] += float(row["Counter_Value"])
+                if row["Counter_Name"] == "GRBM_GUI_ACTIVE" and row.get("End_Timestamp"):
+                    dur.setdefault(k, {})[disp] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-9
         for (k, cname), disp in acc.items():
             vals = list(disp.values())
             per.setdefault(k, {})[cname] = sum(vals) / len(vals)
             per[k]["dispatches_" + cname] = len(vals)
+            if cname == "GRBM_GUI_ACTIVE" and k in dur:
+                # shader clock of the launch: busy cycles (summed over the 8 XCDs) / 8 / the SAME dispatch's duration --
+                # the median over the dispatches (the kernel-trace run's durations are another run's: a counter pass is slower)
+                clocks = sorted(disp[d] / 8.0 / dur[k][d] for d in disp if dur[k].get(d, 0) > 0)
+                if clocks:
+                    per[k]["shader_clock_hz"] = clocks[len(clocks) // 2]
     stats = glob.glob(os.path.join(d, "*_kernel_stats.csv"))
     if stats:
         with open(stats[0]) as f:
@@ -103,7 +112,7 @@ def mc_entry(per):
     search: mc_sweep, or mc_active on the bit-plane path).  The run holds extractions of both kinds -- bricks outside
     the surface skipped (mc_bits_bricks, the default) and every brick read (mc_bits, "mcskip" 0): the pass over the
     state is counted once per extraction with the per-launch bytes of the kernel of that kind."""
-    names = [k for k in per if re.match(r"mc_|scan_chunks|add_chunk_offsets", k) and "hbm_bytes_per_launch" in per[k]]
+    names = [k for k in per if re.match(r"mc_|scan_chunks|scan_chained|add_chunk_offsets", k) and "hbm_bytes_per_launch" in per[k]]
     calls = per.get("mc_sweep", per.get("mc_active", {})).get("dispatches_FETCH_SIZE", 0)
     if not calls:
         return None

@@ -1132,3 +1132,41 @@ def test_carve_log_records_queued_steps_without_synchronising():
     assert dev.carve_log() == []
     dev.free_device(d)
     dev.close()
+
+
+@pytest.mark.parametrize("kw,coopstore", [(_TSDF, -1), (_TSDF, 1), (_TRUNC, 1), (dict(), 1),
+                                          (dict(voxel_update=1, voxel_update_weight=0.5), -1)])
+def test_cooperative_write_back_with_groups_of_views(kw, coopstore):
+    """Launches of 1, 2, 3, 5 and 8 views over a carved grid with the cooperative write-back (the four waves of a
+    workgroup exchange their bricks through LDS and store whole row segments): by the library's rule (weighted
+    average, up to 8 views) and forced on in the other modes.  A sphere deep enough inside the grid that whole
+    workgroups -- and single waves of a workgroup -- drop every view and leave before the barrier; the rows those
+    waves would have stored belong to their neighbours' bricks (the first version lost them).  nx = 96: every
+    workgroup has its four waves inside the grid; state against the oracle after every launch, mesh at the end."""
+    n, w, h = 96, 160, 120
+    groups = [1, 2, 3, 5, 8, 1]
+    nv = sum(groups)
+    uo = UpdateOption(**kw)
+    opt = synth.sphere_option(n, uo)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    base = O.make_sdf(masks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
+    rng = np.random.RandomState(11)
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init(), vc.last_error()
+    dev.set_param("defer", 0)
+    dev.set_param("coopstore", coopstore)
+    orc = O.OracleGrid(opt)
+    d_base = dev.upload_sdf(base)
+    noisy = (base + rng.uniform(-0.03, 0.03, base.shape)).astype(np.float32)
+    d_noisy = dev.upload_sdf(noisy)
+    first = 0
+    for gi, g in enumerate(groups):
+        imgs = [(noisy, d_noisy) if (first + j) % 4 == 3 else (base, d_base) for j in range(g)]
+        assert dev.CarveBatchDevice(views[first:first + g], [p for _, p in imgs]), vc.last_error()
+        for j in range(g):
+            orc.carve(views[first + j], imgs[j][0])
+        assert_state_equal(dev, orc, "%s coopstore %d group %d (%d views)" % (kw, coopstore, gi, g))
+        first += g
+    assert_mesh_equal(dev.ExtractIsoSurface(0.0, True), orc.marching_cubes(0.0, True), "%s coopstore %d" % (kw, coopstore))
+    dev.free_device(d_base)
+    dev.free_device(d_noisy)
