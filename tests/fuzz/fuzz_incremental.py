@@ -30,10 +30,14 @@ def same_mesh(a, b):
 
 
 for seed in range(lo, hi):
+    if seed > lo and (seed - lo) % 10 == 0:
+        print("  ... seed %d, %d mismatches so far, %.0f s" % (seed, bad, time.time() - t0), flush=True)
     rng = np.random.RandomState(17000 + seed)
     dims = rng.randint(40, 100, 3)
     if rng.rand() < 0.3:
         dims[0] = int(rng.choice([64, 128]))  # rows of whole 64-voxel words: the brick-row pass of marching cubes
+    if seed >= 2000:  # (round 4) rows of whole bricks, which the vector loads / stores and the cooperative write-back need
+        dims[0] = int(np.random.RandomState(29000 + seed).choice([48, 56, 64, 72, 80, 96, 104, 128]))
     centre = rng.uniform(-30, 30, 3)
     half = dims / 2.0
     bb_min = (centre - half).astype(np.float32)
@@ -82,6 +86,8 @@ for seed in range(lo, hi):
         dev = vc.VoxelCarver(opt, z_range=zr) if zr else vc.VoxelCarver(opt)
         assert dev.Init()
         dev.set_param("mcskip", 2)  # the brick-row pass on these small grids too (the library's rule: rows of 1024 voxels and more)
+        # (round 4) write-back through LDS in whole row segments: the library's rule, never, wherever the layout allows
+        dev.set_param("coopstore", int(np.random.RandomState(23000 + seed).choice([-1, 0, 1, 1])))
         dev.set_param("defer", int(rng.randint(0, 2)))
         dev.set_param("recordbytes", int(rng.choice([0, 0, 3000, 20000])))  # chunks of a few brick layers
         orc = O.OracleGrid(opt)
