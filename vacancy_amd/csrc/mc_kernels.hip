@@ -480,7 +480,7 @@ __device__ __forceinline__ bool neighbour_active(const McParams& p, const u64* _
 }
 
 __device__ __forceinline__ int owned_edges(const McParams& p, const u64* __restrict__ act, int code, int li,
-                                           int cy, int x) {
+                                           int cy, int x, int* nactive_out = nullptr) {
   const int cut = cut_edges(code);
   // the ACT bits of the nine neighbour cells an edge can be shared with, requested together (cells outside
   // the grid read word 0 and count as inactive), then pure bit logic
@@ -506,6 +506,7 @@ __device__ __forceinline__ int owned_edges(const McParams& p, const u64* __restr
   }
   // a ghost cell only contributes vertices on the plane it shares with the slab (e4..e7)
   if (li == 0) owned &= 0xF0;
+  if (nactive_out) *nactive_out = nactive;
   return owned;
 }
 
@@ -939,26 +940,32 @@ __global__ __launch_bounds__(256) void mc_owner_kernel(McParams p, const McTable
                                                        const u64* __restrict__ cell_list,
                                                        const u64* __restrict__ ncells_dev, int64_t capacity,
                                                        uint32_t* __restrict__ info,
+                                                       uint16_t* __restrict__ nbr_active,
                                                        u64* __restrict__ block_counts) {
   __shared__ int sm[4];
   // the number of active cells is read where the scan left it: the host need not know it to launch this
   const int64_t ncells = min((int64_t)*ncells_dev, capacity);
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int nvert = 0, ntri = 0, owned = 0, code = 0;
+  int nvert = 0, ntri = 0, owned = 0, code = 0, nactive = 0;
   if (i < ncells) {
     const int64_t slot = (int64_t)cell_list[i];
     int li, cy, w;
     decode_word(p, slot >> 6, &li, &cy, &w);
     const int x = w * 64 + (int)(slot & 63);
     code = case_at(p, li, cy, x);
-    owned = owned_edges(p, act, code, li, cy, x);
+    owned = owned_edges(p, act, code, li, cy, x, &nactive);
     nvert = __popc(owned);
     if (li > 0) ntri = T->ntri[code];
   }
   int tot_v, tot_t;
   const int off_v = block_exclusive_scan(nvert, &tot_v, sm);
   (void)block_exclusive_scan(ntri, &tot_t, sm);
-  if (i < ncells) info[i] = (uint32_t)owned | ((uint32_t)code << 12) | ((uint32_t)off_v << 20);
+  if (i < ncells) {
+    info[i] = (uint32_t)owned | ((uint32_t)code << 12) | ((uint32_t)off_v << 20);
+    // which of the nine neighbour cells are active: mc_emit finds the owners of this cell's other cut edges from it
+    // without asking again (it used to re-read the nine ACT words -- and three more arrays for all nine)
+    nbr_active[i] = (uint16_t)nactive;
+  }
   if (threadIdx.x == 0) block_counts[blockIdx.x] = ((u64)(unsigned)tot_v << 32) | (u64)(unsigned)tot_t;
 }
 
@@ -1109,14 +1116,20 @@ __device__ __forceinline__ void vertex_interp(double iso, const float pa[3], con
 constexpr int kEmitMaxVerts = 512;  // 6 KB + 8 KB of keys (a smooth surface has about one vertex per active cell)
 constexpr int kEmitMaxTris = 768;   // 9 KB (about two triangles per active cell)
 
-// (123 VGPRs, 4 waves per SIMD: compiled for 5, 6 or 8 it spills and is 5 - 15 % slower)
-__global__ __launch_bounds__(256) void mc_emit_kernel(McParams p, const McTables* __restrict__ T,
+// (round 4: 98 VGPRs once the gather asked for the owners only, 123 before; compiled for 5 waves per SIMD -- a handful of
+// spills -- 160 -> 146 us at 1024^3; for 6: 205 us.  Halving its loads changed nothing by itself: the kernel waits for
+// its chain of dependent gathers, so occupancy is what helps.)
+#ifndef VCY_EMIT_WAVES
+#define VCY_EMIT_WAVES 5
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCY_EMIT_WAVES, VCY_EMIT_WAVES))) void mc_emit_kernel(McParams p, const McTables* __restrict__ T,
                                                       const u64* __restrict__ act,
                                                       const u64* __restrict__ cell_list,
                                                       const u64* __restrict__ ncells_dev, int64_t capacity,
                                                       const uint32_t* __restrict__ word_cell_off,
                                                       const u64* __restrict__ block_cell_offs,
                                                       const uint32_t* __restrict__ info,
+                                                      const uint16_t* __restrict__ nbr_active,
                                                       const u64* __restrict__ block_offs,
                                                       const u64* __restrict__ grand_total_dev, int64_t verts_capacity,
                                                       int64_t faces_capacity, float* __restrict__ verts,
@@ -1165,55 +1178,90 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(McParams p, const McTables
                       (x + kCornerOff[c][0])];
     const float ax2[2] = {p.px[x - 1], p.px[x]}, ay2[2] = {p.py[y - 1], p.py[y]}, az2[2] = {p.pz[z - 1], p.pz[z]};
     // (b) rank tables of this case: prec[code][e] for the 12 edges
-    uint16_t prec[12];
+    uint16_t prec[12];  // (24 bytes, 8-byte aligned: three loads instead of twelve)
+    {
+      const u64* pw = reinterpret_cast<const u64*>(&T->prec[code][0]);
+      const u64 pw0 = pw[0], pw1 = pw[1], pw2 = pw[2];
 #pragma unroll
-    for (int e = 0; e < 12; ++e) prec[e] = T->prec[code][e];
+      for (int e = 0; e < 12; ++e) prec[e] = (uint16_t)((e < 4 ? pw0 : (e < 8 ? pw1 : pw2)) >> (16 * (e & 3)));
+    }
     //     ... and its triangle row (16 edge numbers) as one 16-byte load
     const uint4 trow = *reinterpret_cast<const uint4*>(&T->tri[code][0]);
-    // (c) the neighbour cells that own the cut edges this cell does not: which of the nine exist and are
-    //     active, their number in the cell list, their info word and their block's vertex offset.  Loads of
-    //     neighbours that are not needed go to element 0 instead of being branched around, so that the three
-    //     dependent rounds (ACT word -> list offsets -> info) are each issued for all nine at once.
+    // (c) the neighbour cells that OWN the cut edges this cell does not.  Which of the nine neighbours are active is
+    //     known from mc_owner (nbr_active); the owner of a foreign edge is its first active sharer in scan order, so
+    //     the set of owners is bit logic -- typically one to three cells -- and only for those are the three dependent
+    //     rounds (ACT word -> list offsets -> info word and block offset) issued, four owners together.  (Round 3 ran
+    //     the rounds for all nine neighbours: 45 loads per cell, most of them to element 0.)
     const int foreign = cut & ~owned;
-    int need = 0;
+    const int nactive = (int)nbr_active[i];
+    int owner_of[12];    // foreign edge e: neighbour index of the cell that owns it (-1: none), its edge number there
+    int owner_edge[12];
+    int owners = 0;
 #pragma unroll
-    for (int e = 0; e < 12; ++e)
-      if (foreign & (1 << e))
+    for (int e = 0; e < 12; ++e) {
+      owner_of[e] = -1;
+      owner_edge[e] = 0;
+      bool found = false;
 #pragma unroll
-        for (int k = 0; k < kShare[e].n; ++k) need |= 1 << kShareNbr[e][k];
-    int64_t ocw[kNbrCount];
-    int obit[kNbrCount];
-    u64 aw[kNbrCount];
-#pragma unroll
-    for (int q = 0; q < kNbrCount; ++q) {
-      const int nl = li + kNbr[q][2], ncy = cy + kNbr[q][1], ox = x + kNbr[q][0];
-      const bool there = ((need >> q) & 1) && nl >= 0 && ncy >= 0 && ncy < p.Y && ox >= 1 && ox < p.nx;
-      ocw[q] = there ? word_index(p, nl, ncy, ox >> 6) : 0;
-      obit[q] = there ? (ox & 63) : -1;
-      aw[q] = act[ocw[q]];
+      for (int k = 0; k < kShare[e].n; ++k) {
+        const int q = kShareNbr[e][k];
+        const bool hit = !found && ((foreign >> e) & 1) && ((nactive >> q) & 1);
+        owner_of[e] = hit ? q : owner_of[e];
+        owner_edge[e] = hit ? (int)kShare[e].e[k] : owner_edge[e];
+        found = found || hit;
+      }
+      if (found) owners |= 1 << owner_of[e];
     }
-    uint32_t wco[kNbrCount];
-    u64 bco[kNbrCount];
-    int nactive = 0;  // bit q: neighbour q is an active cell
+    // (dx, dy, dl) of neighbour q, from kNbr packed two bits per entry (value + 1)
+    auto nbr_d = [](int q, int axis) -> int {
+      constexpr uint32_t kPack[3] = {
+          (1u << 0) | (1u << 2) | (1u << 4) | (2u << 6) | (1u << 8) | (0u << 10) | (0u << 12) | (0u << 14) | (2u << 16),   // dx
+          (0u << 0) | (1u << 2) | (0u << 4) | (1u << 6) | (2u << 8) | (1u << 10) | (1u << 12) | (0u << 14) | (0u << 16),   // dy
+          (0u << 0) | (0u << 2) | (1u << 4) | (0u << 6) | (0u << 8) | (0u << 10) | (1u << 12) | (1u << 14) | (1u << 16)};  // dl
+      return (int)((kPack[axis] >> (2 * q)) & 3u) - 1;
+    };
+    constexpr int kSlots = 4;
+    int sq[kSlots];        // the owners taken in this pass (-1: none)
+    uint32_t sinf[kSlots];
+    u64 sboff[kSlots];
+    {
+      int left = owners;
+      int64_t ocw[kSlots];
+      int obit[kSlots];
+      u64 aw[kSlots];
 #pragma unroll
-    for (int q = 0; q < kNbrCount; ++q) {
-      const bool on = obit[q] >= 0 && ((aw[q] >> obit[q]) & 1ull);
-      nactive |= on ? (1 << q) : 0;
-      const int64_t w = on ? ocw[q] : 0;
-      wco[q] = word_cell_off[w];
-      bco[q] = block_cell_offs[w >> 8];
-    }
-    uint32_t oinf[kNbrCount];
-    u64 oboff[kNbrCount];
+      for (int t = 0; t < kSlots; ++t) {
+        sq[t] = left ? (__ffs(left) - 1) : -1;
+        left &= left - 1;
+        const int q = max(sq[t], 0);
+        const int nl = li + nbr_d(q, 2), ncy = cy + nbr_d(q, 1), ox = x + nbr_d(q, 0);
+        // (an active neighbour lies inside the grid: mc_owner only counts those)
+        ocw[t] = sq[t] >= 0 ? word_index(p, nl, ncy, ox >> 6) : 0;
+        obit[t] = ox & 63;
+        aw[t] = act[ocw[t]];
+      }
+      uint32_t wco[kSlots];
+      u64 bco[kSlots];
 #pragma unroll
-    for (int q = 0; q < kNbrCount; ++q) {
-      // the owner cell's number in the list, without a slot -> index array
-      const int64_t oi = ((nactive >> q) & 1)
-                             ? (int64_t)bco[q] + wco[q] + __popcll(aw[q] & ((1ull << obit[q]) - 1ull))
-                             : 0;
-      oinf[q] = info[oi];
-      oboff[q] = block_offs[oi >> 8];
+      for (int t = 0; t < kSlots; ++t) {
+        wco[t] = word_cell_off[ocw[t]];
+        bco[t] = block_cell_offs[ocw[t] >> 8];
+      }
+#pragma unroll
+      for (int t = 0; t < kSlots; ++t) {
+        const int64_t oi = sq[t] >= 0 ? (int64_t)bco[t] + wco[t] + __popcll(aw[t] & ((1ull << obit[t]) - 1ull)) : 0;
+        sinf[t] = info[oi];
+        sboff[t] = block_offs[oi >> 8];
+      }
     }
+    // a fifth and further owner (rare: a cell most of whose cut edges belong to different earlier cells), one at a time
+    auto fetch_owner = [&](int q, uint32_t* oinf, u64* oboff) {
+      const int nl = li + nbr_d(q, 2), ncy = cy + nbr_d(q, 1), ox = x + nbr_d(q, 0);
+      const int64_t cw = word_index(p, nl, ncy, ox >> 6);
+      const int64_t oi = list_index_of(act, word_cell_off, block_cell_offs, cw, ox & 63);
+      *oinf = info[oi];
+      *oboff = block_offs[oi >> 8];
+    };
 
     // ---- vertices of the edges this cell owns ----------------------------------------------------
 #pragma unroll
@@ -1256,18 +1304,20 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(McParams p, const McTables
       if (cut & (1 << e)) {
         if (owned & (1 << e)) {
           vid = (int)(vb + vin + __popc(owned & prec[e]));
-        } else {
-          bool found = false;
+        } else if (owner_of[e] >= 0) {
+          uint32_t oi_inf = 0;
+          u64 oi_boff = 0;
+          bool have = false;
 #pragma unroll
-          for (int k = 0; k < kShare[e].n; ++k) {
-            const int q = kShareNbr[e][k];
-            if (!found && ((nactive >> q) & 1)) {
-              found = true;
-              const uint32_t oi_inf = oinf[q];
-              const int o_owned = oi_inf & 0xFFF, o_code = (oi_inf >> 12) & 0xFF, o_in_block = oi_inf >> 20;
-              vid = (int)((int64_t)(oboff[q] >> 32) + o_in_block + __popc(o_owned & T->prec[o_code][kShare[e].e[k]]));
-            }
+          for (int t = 0; t < kSlots; ++t) {
+            const bool m = sq[t] == owner_of[e];
+            oi_inf = m ? sinf[t] : oi_inf;
+            oi_boff = m ? sboff[t] : oi_boff;
+            have = have || m;
           }
+          if (!have) fetch_owner(owner_of[e], &oi_inf, &oi_boff);
+          const int o_owned = oi_inf & 0xFFF, o_code = (oi_inf >> 12) & 0xFF, o_in_block = oi_inf >> 20;
+          vid = (int)((int64_t)(oi_boff >> 32) + o_in_block + __popc(o_owned & T->prec[o_code][owner_edge[e]]));
         }
       }
       evid[e] = vid;
@@ -1560,15 +1610,16 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   // without the host reading anything back; the counts are fetched once at the end, and if a guess was too
   // small the chain runs again with the exact sizes -- which is also the path of the first extraction.
   struct CellBuffers {
-    u64* list; uint32_t* info; u64* counts; u64* scan; u64* total; unsigned blocks;
+    u64* list; uint32_t* info; uint16_t* nact; u64* counts; u64* scan; u64* total; unsigned blocks;
   };
   auto cell_buffers = [&](int64_t cap_cells, CellBuffers* b) -> int {
     b->blocks = (unsigned)((cap_cells + 255) / 256);
     const size_t sz_list = align(sizeof(u64) * (size_t)cap_cells);
     const size_t sz_info = align(sizeof(uint32_t) * (size_t)cap_cells);
+    const size_t sz_nact = align(sizeof(uint16_t) * (size_t)cap_cells);
     const size_t sz_cc = align(sizeof(u64) * ((size_t)b->blocks + 1));
     const size_t sz_cs = align(sizeof(u64) * ((size_t)b->blocks / 1024 + 64) * 2);
-    const size_t need2 = sz_list + sz_info + sz_cc + sz_cs + 256;
+    const size_t need2 = sz_list + sz_info + sz_nact + sz_cc + sz_cs + 256;
     if (c->mc_cells_bytes < need2) {
       MC_TRY(hipStreamSynchronize(s));
       if (c->d_mc_cells) MC_TRY(hipFree(c->d_mc_cells));
@@ -1580,6 +1631,7 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
     char* b2 = (char*)c->d_mc_cells;
     b->list = (u64*)b2;                   b2 += sz_list;
     b->info = (uint32_t*)b2;              b2 += sz_info;
+    b->nact = (uint16_t*)b2;              b2 += sz_nact;
     b->counts = (u64*)b2;                 b2 += sz_cc;
     b->scan = (u64*)b2;                   b2 += sz_cs;
     b->total = (u64*)b2;
@@ -1590,7 +1642,7 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
     hipLaunchKernelGGL(mc_compact_kernel, dim3((nblocks + kCompactBlocks - 1) / kCompactBlocks), dim3(256), 0, s, p, d_act,
                        d_woff, d_wcounts, d_total, (int64_t)nblocks, b.list, cap_cells);
     hipLaunchKernelGGL(mc_owner_kernel, dim3(b.blocks), dim3(256), 0, s, p, T, d_act, b.list, d_total, cap_cells, b.info,
-                       b.counts);
+                       b.nact, b.counts);
     MC_TRY(hipGetLastError());
     return exclusive_scan_u64(b.counts, b.blocks, b.total, b.scan, s, d_flags + kChainedScanMaxChunks, ++c->mc_scan_epoch);
   };
@@ -1611,7 +1663,7 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
     d_keys = c->mesh_keys ? (long long*)((char*)c->d_mc_out + sz_v) : nullptr;
     d_faces = (int*)((char*)c->d_mc_out + sz_v + sz_k);
     hipLaunchKernelGGL(mc_emit_kernel, dim3(b.blocks), dim3(256), 0, s, p, T, d_act, b.list, d_total, cap_cells, d_woff,
-                       d_wcounts, b.info, b.counts, b.total, cap_v, cap_f, d_verts, d_keys, d_faces);
+                       d_wcounts, b.info, b.nact, b.counts, b.total, cap_v, cap_f, d_verts, d_keys, d_faces);
     MC_TRY(hipGetLastError());
     return VCY_OK;
   };
