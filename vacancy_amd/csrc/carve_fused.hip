@@ -2107,6 +2107,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
       VCY_HIP_CHECK(hipGetLastError());
     }
     const dim3 grid((unsigned)((int64_t)nbx * nby * layers));
+    dim3 launch_grid = grid;
     // few views over a carved grid: only the workgroups with a live (brick, view) pair (live_workgroups_kernel)
     const int* wgl = nullptr;
     const bool have_min = u.voxel_update == VCY_UPDATE_MAX && (state_flags & 4) != 0 && bmin != nullptr;
@@ -2141,14 +2142,26 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
       if (c->h_live_hint) {
         c->h_live_hint[1] = nwg;
         (void)hipMemcpyAsync(&c->h_live_hint[0], c->d_wg_list, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        // The carve kernel is launched over the listed workgroups only: the host waits for the count (the list pass is
+        // 60 us of device time behind it) instead of starting every workgroup of the slab to have all but the listed
+        // ones read list[0] and leave -- 512 K workgroups that do nothing else are 0.115 ms at 1024^3
+        // (profiles/tools/per_view_floor.py), a sixth of a single-view launch.  ("livesync" 0: the full grid, no wait.)
+        if (c->live_sync && hipStreamSynchronize(c->stream) == hipSuccess) {
+          const int live = c->h_live_hint[0];
+          if (live >= 0 && live <= nwg) launch_grid = dim3((unsigned)live);
+        } else {
+          (void)hipGetLastError();
+        }
       }
     }
     if (stamp >= 0) VCY_HIP_CHECK(hipEventRecord(c->carve_log[stamp].ev[1], c->stream));
-    if (c->cnt_bytes == 1)
-      launch_fused_1<uint8_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, gc, d_views,
+    if (launch_grid.x == 0) {
+      // (no workgroup is live: nothing to launch)
+    } else if (c->cnt_bytes == 1)
+      launch_fused_1<uint8_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, launch_grid, c->stream, gc, d_views,
                               d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin, wgl, pcnt);
     else
-      launch_fused_1<uint16_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, grid, c->stream, gc, d_views,
+      launch_fused_1<uint16_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, launch_grid, c->stream, gc, d_views,
                                d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin, wgl, pcnt);
     VCY_HIP_CHECK(hipGetLastError());
     if (stamp >= 0) VCY_HIP_CHECK(hipEventRecord(c->carve_log[stamp].ev[2], c->stream));

@@ -480,6 +480,10 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
     c->use_live_list = value != 0;
     return VCY_OK;
   }
+  if (std::strcmp(name, "livesync") == 0) {
+    c->live_sync = value != 0;
+    return VCY_OK;
+  }
   if (std::strcmp(name, "coopstore") == 0) {
     c->coop_store = value < 0 ? -1 : (value != 0 ? 1 : 0);
     return VCY_OK;
@@ -508,6 +512,7 @@ int vcy_get_param(vcy_ctx* c, const char* name, int* value) {
   else if (std::strcmp(name, "mcskip") == 0) *value = c->mc_skip;
   else if (std::strcmp(name, "livelist") == 0) *value = c->use_live_list ? 1 : 0;
   else if (std::strcmp(name, "coopstore") == 0) *value = c->coop_store;
+  else if (std::strcmp(name, "livesync") == 0) *value = c->live_sync ? 1 : 0;
   else if (std::strcmp(name, "brick_min_valid") == 0) *value = c->brick_min_valid && !c->fresh ? 1 : 0;
   else if (std::strcmp(name, "meshkeys") == 0) *value = c->mesh_keys ? 1 : 0;
   else {

@@ -114,6 +114,7 @@ struct vcy_ctx {
   int* h_live_hint = nullptr;         // page-locked {live workgroups, workgroups} of the last listed launch (a hint, see launch_carve_fused)
   int64_t live_list_age = 0;
   bool use_live_list = true;          // vcy_set_param("livelist", 0): every workgroup is launched and decides for itself
+  bool live_sync = true;              // vcy_set_param("livesync", 0): the carve kernel of a listed launch starts every workgroup instead of waiting for the list's length
   int coop_store = -1;                // vcy_set_param("coopstore"): write-back of a workgroup's bricks through LDS in whole row segments; -1 = where it pays (launch_carve_fused), 0 / 1 = never / whenever possible
   bool count_pairs = false;           // vcy_set_param("paircount", 1): the fused kernel counts the (brick, view) pairs it processes
   unsigned long long* d_pair_count = nullptr;  // ... per brick layer of the slab, of the last fused launch (vcy_last_carve_pairs)
