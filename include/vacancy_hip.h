@@ -294,10 +294,10 @@ int vcy_reset(vcy_ctx* ctx);
  * "livesync" (default 1): with the live list, the host waits for the list's length and launches the carve kernel over the
  * listed workgroups only (a single-view launch at 1024^3: 0.115 ms less than starting all 512 K workgroups to have the
  * others leave); 0 starts every workgroup and never waits.
- * "coopstore" (default -1): how a fused launch over an already carved grid writes the state back.  1: the four waves
- * of a workgroup exchange their bricks through LDS and store whole 128-byte row segments; 0: every wave stores its own
- * 16-byte pieces; -1: the first for single-view launches (weighted-average modes: up to 8 views), the second
- * otherwise.  Results are identical.
+ * "coopstore" (default -1): how a fused launch writes the state back.  1: the four waves of a workgroup exchange their
+ * bricks through LDS and store whole 128-byte row segments; 0: every wave stores its own 16-byte pieces; -1: the first
+ * for single-view launches (over a carved grid in the weighted-average modes: up to 8 views), the second otherwise.
+ * Results are identical.
  * "recordbytes" (default 0 = 1 GiB): bytes of footprint records one carve launch may take; a larger launch is cut into
  * chunks of whole brick layers (2048^3 x 64 views: nine).  Small values let tests run the chunking on small grids.
  * "carvetimer" (default 0): 1 records HIP events around what runs before the carve kernel (window maxima, pre-pass)

@@ -2037,15 +2037,18 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
                        c->stream, c->d_brick_min, nb);
     VCY_HIP_CHECK(hipGetLastError());
   }
-  // Cooperative write-back (carve_fused_kernel): pays where a launch reads and rewrites the state for little arithmetic
-  // -- few views over a carved grid (1024^3, one view per launch: weighted average 4.39 -> 3.41 ms, kMax 0.89 -> 0.84).
-  // "coopstore": -1 that rule, 0 never, 1 always when the layout allows it: rows of whole bricks, four waves per
-  // workgroup, raw tiles, not a fresh slab.
-  const bool coop_ok = (kWgWaves == 4 || kWgWaves == 8) && (c->nx & (WX - 1)) == 0 && !c->fresh && !big;
+  // Cooperative write-back (carve_fused_kernel): pays where a launch moves the state for little arithmetic -- few views
+  // over a carved grid (1024^3, one view per launch: weighted average 4.39 -> 3.41 ms, kMax 0.89 -> 0.84), and the first
+  // single-view launch on a fresh grid, which stores every voxel once (2.48 -> 1.95 ms: 6.4 GB at 3.3 instead of
+  // 2.6 TB/s).  "coopstore": -1 that rule, 0 never, 1 always when the layout allows it: rows of whole bricks, four
+  // waves per workgroup, raw tiles.
   // (kMax: only single-view launches -- with 4 or 8 views per launch the waves of a workgroup process different numbers
-  // of views and the barrier costs 3 - 4 %, profiles/r04/coop_store_batches.txt; weighted average: up to 8 views, 0 ... +2 %)
-  const bool coop = coop_ok && (c->coop_store > 0 ||
-                                (c->coop_store < 0 && n_views <= (u.voxel_update == VCY_UPDATE_MAX ? 1 : kLiveListMaxViews)));
+  // of views and the barrier costs 3 - 4 %, profiles/r04/coop_store_batches.txt; weighted average: up to 8 views, 0 ... +2 %;
+  // a fresh grid: single-view launches in either mode -- the fused 32-view launch gained nothing from whole-segment
+  // stores in round 3)
+  const bool coop_ok = (kWgWaves == 4 || kWgWaves == 8) && (c->nx & (WX - 1)) == 0 && !big;
+  const int coop_views = c->fresh ? 1 : (u.voxel_update == VCY_UPDATE_MAX ? 1 : kLiveListMaxViews);
+  const bool coop = coop_ok && (c->coop_store > 0 || (c->coop_store < 0 && n_views <= coop_views));
   const int state_flags = (c->fresh ? 1 : 0) | (c->cnt_implied ? 2 : 0) | (c->brick_min_valid && !c->fresh ? 4 : 0) |
                           (coop ? 8 : 0);
   // Raw tiles: the footprint records of every (wave brick, view) pair come from a pre-pass (footprint_records_kernel),
