@@ -22,8 +22,10 @@ class Camera {
   const Eigen::Affine3d& w2c() const { return w2c_; }
   void set_c2w(const Eigen::Affine3d& c2w) { c2w_ = c2w; w2c_ = c2w_.inverse(); }
   // camera space -> image plane
+  // (the only virtual the carve path of the reference calls, voxel_carver.cc:460.  The device evaluates the two
+  // projections the reference ships -- PinholeCamera and OrthoCamera, recognised by dynamic_cast -- itself; Carve() with
+  // any other subclass fails loudly: `false` + LOGE, never a silently wrong projection)
   virtual void Project(const Eigen::Vector3f& camera_p, Eigen::Vector2f* image_p) const = 0;
-  virtual bool is_orthographic() const = 0;
 
  protected:
   int width_, height_;
@@ -59,7 +61,6 @@ class PinholeCamera : public Camera {
     (*q)[0] = focal_length_[0] / p[2] * p[0] + principal_point_[0];
     (*q)[1] = focal_length_[1] / p[2] * p[1] + principal_point_[1];
   }
-  bool is_orthographic() const override { return false; }
 
  private:
   void init_fov(float fov_y_deg) {
@@ -76,7 +77,6 @@ class OrthoCamera : public Camera {
   OrthoCamera(int width, int height) : Camera(width, height) {}
   OrthoCamera(int width, int height, const Eigen::Affine3d& c2w) : Camera(width, height, c2w) {}
   void Project(const Eigen::Vector3f& p, Eigen::Vector2f* q) const override { (*q)[0] = p[0]; (*q)[1] = p[1]; }
-  bool is_orthographic() const override { return true; }
 };
 
 }  // namespace vacancy

@@ -113,7 +113,9 @@ void vcy_destroy(vcy_ctx* ctx);
 int vcy_grid_dims(const vcy_ctx* ctx, int32_t dims[3]);
 /* The z-range this context owns. */
 int vcy_slab_range(const vcy_ctx* ctx, int32_t z_range[2]);
-/* Grid dims without creating a context (host arithmetic of VoxelGrid::Init). */
+/* Grid dims without creating a context (host arithmetic of VoxelGrid::Init, voxel_carver.cc:278-301).  A box thinner
+ * than one voxel along an axis gives dims[axis] = 0 and VCY_OK -- the reference builds an empty grid there --; only
+ * vcy_create refuses it (there is nothing to put in HBM). */
 int vcy_compute_dims(const float bb_min[3], const float bb_max[3],
                      float resolution, int32_t dims[3]);
 
@@ -302,11 +304,15 @@ int vcy_reset(vcy_ctx* ctx);
  * chunks of whole brick layers (2048^3 x 64 views: nine).  Small values let tests run the chunking on small grids.
  * "carvetimer" (default 0): 1 records HIP events around what runs before the carve kernel (window maxima, pre-pass)
  * and around the carve kernel of every fused launch (vcy_last_carve_ms, vcy_carve_log); setting it clears the log.
+ * "lazycount" (default 1): update_num is stored in one byte until more than 255 views have been applied since the fill
+ * (a voxel's count cannot exceed that number), then widened in one pass to what voxel_max_update_num needs; 0 allocates
+ * the final width at once.  Results are identical; "count_bytes" / "count_bytes_final" read the widths back.
  * "paircount" (default 0): 1 makes every fused launch count the (brick, view) pairs it processes (vcy_last_carve_pairs).
  * "inject_carve_failure" (test hook, default 0): the next `value` applications of views fail with
  * VCY_ERR_INTERNAL before anything is launched -- how the tests exercise the error contract of vcy_carve. */
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
-/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep", "mcskip", "livelist", "livesync", "coopstore", "meshkeys"), "div_level": the
+/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep", "mcskip", "livelist", "livesync", "coopstore", "meshkeys",
+ * "lazycount", "carvetimer"), "count_bytes" / "count_bytes_final" / "carvelog_dropped" (see above), "div_level": the
  * division sequence the last fused launch was instantiated with (2: 4 instructions, 1: 6, 0: full IEEE expansion), or
  * "brick_min_valid": 1 while the brick minima describe the state (every write since the fill went through the fused kernel). */
 int vcy_get_param(vcy_ctx* ctx, const char* name, int* value);
@@ -325,7 +331,9 @@ int vcy_timer_end(vcy_ctx* ctx, float* elapsed_ms);
 int vcy_last_carve_ms(vcy_ctx* ctx, float* prepass_ms, float* kernel_ms);
 /* The whole log "carvetimer" 1 keeps since it was set (or since the last call with clear != 0): one record per chunk
  * of every fused launch (first_chunk[i] != 0 starts a launch; a launch has one chunk unless its footprint records
- * exceed "recordbytes"), up to 8192 records -- later launches are not recorded.  begin_ms[i] = start of record i
+ * exceed "recordbytes"), up to 8192 records -- later launches are not recorded, and counted:
+ * vcy_get_param "carvelog_dropped" (a reader that divides by a step count must check it; vcy_last_carve_ms fails
+ * rather than report an older launch).  begin_ms[i] = start of record i
  * (before its window maxima and pre-pass) since the start of record 0; prepass_ms[i] / kernel_ms[i] as for
  * vcy_last_carve_ms.  Any of the arrays may be NULL.  Nothing synchronises while the launches are issued: a sequence
  * of carve steps can be queued back to back and read here afterwards (this call waits for the recorded launches).

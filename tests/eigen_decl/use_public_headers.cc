@@ -11,6 +11,15 @@
 #error "the Eigen branch of include/vacancy/common.h was not taken"
 #endif
 
+// a user's Camera subclass that overrides Project() only -- all the reference's carve path calls (camera.h:39-40)
+class UserCamera : public vacancy::Camera {
+ public:
+  void Project(const Eigen::Vector3f& camera_p, Eigen::Vector2f* image_p) const override {
+    (*image_p)[0] = camera_p[0];
+    (*image_p)[1] = camera_p[1];
+  }
+};
+
 void use(const Eigen::Vector3d& p, const Eigen::Vector3d& t, const Eigen::Vector3d& up) {
   Eigen::Affine3d pose = vacancy::c2w(p, t, up);
   Eigen::Matrix<double, 3, 3> R;
@@ -23,5 +32,7 @@ void use(const Eigen::Vector3d& p, const Eigen::Vector3d& t, const Eigen::Vector
   vacancy::VoxelCarverOption opt;
   opt.bb_max = Eigen::Vector3f(1.f, 1.f, 1.f);
   vacancy::VoxelCarver carver(opt);
-  (void)carver;
+  UserCamera user;
+  vacancy::Image1f sdf(4, 4);
+  (void)carver.Carve(user, sdf);  // compiles; returns false at run time (unsupported subclass)
 }

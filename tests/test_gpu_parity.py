@@ -491,6 +491,23 @@ def test_cpp_bunny_example(tmp_path):
     assert open(os.path.join(str(tmp_path), "surface_00005.ply")).read() == expected
 
 
+def test_cpp_facade_refuses_camera_subclasses_it_cannot_project():
+    """Camera::Project is virtual in the reference (camera.h:39-40, called per voxel at voxel_carver.cc:460); the
+    device evaluates PinholeCamera and OrthoCamera.  A third subclass compiles against the facade (no extra pure
+    virtual) and Carve() returns false for it -- single view and batch -- without touching the grid."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "vacancy_amd", "host"), "-s"], check=True)
+    r = subprocess.run([os.path.join(root, "vacancy_amd", "host", "host_selftest"), B.BUNNY, "gpu"],
+                       check=True, capture_output=True, text=True)
+    row = [l.split() for l in r.stdout.splitlines() if l.startswith("CUSTOMCAM")][0]
+    assert row[1:6] == ["1", "1", "0", "0", "1"], row
+    assert int(row[6]) > 0  # the pinhole and orthographic views were applied
+    assert "unsupported Camera subclass" in (r.stdout + r.stderr)
+    assert (r.stdout + r.stderr).count("VoxelCarver::Carve main loop") >= 1  # the applied queue is logged as the reference's loop
+
+
 @pytest.mark.parametrize("world,n", [(2, 44), (3, 44), (2, 64), (3, 64)])
 def test_z_slab_sharding_on_one_gpu(world, n):
     """The multi-GPU path with every 'rank' as its own context on cuda:0: slab carve (no
@@ -1170,3 +1187,120 @@ def test_cooperative_write_back_with_groups_of_views(kw, coopstore):
     assert_mesh_equal(dev.ExtractIsoSurface(0.0, True), orc.marching_cubes(0.0, True), "%s coopstore %d" % (kw, coopstore))
     dev.free_device(d_base)
     dev.free_device(d_noisy)
+
+
+@pytest.mark.parametrize("mode", ["wa_max_update_300", "default", "max_update_70000", "tsdf"])
+def test_counters_widen_lazily_across_the_256th_view(mode):
+    """update_num of a voxel cannot exceed the number of views applied since the fill, so the counter array is u8 (5
+    B/voxel with the sdf) until the 256th view and is widened in one pass then -- also between two chunks of one batch
+    call -- to whatever voxel_max_update_num needs in the end (u16 for the default 255, u32 for 70000, where the fused
+    kernel now serves the first 65535 views).  State and meshes equal the oracle's before and after; a reset goes back
+    to one byte, an upload of counts above 255 widens at once, "lazycount" 0 is round 4's layout."""
+    n, nv, w, h = 40, 300, 128, 96
+    kw = dict(SYN_MODES[mode])
+    if mode in ("default", "tsdf"):
+        kw["voxel_max_update_num"] = 255  # (the reference's default: counts up to 256 -> u16 in the end)
+    uo = UpdateOption(**kw)
+    final = 4 if mode == "max_update_70000" else 2
+    opt = synth.sphere_option(n, uo)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    sdfs = [vc.make_sdf(m, use_truncation=bool(uo.use_truncation), band=uo.truncation_band) for m in masks[:8]]
+    orc = O.OracleGrid(opt)
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init(), vc.last_error()
+    assert (dev.get_param("count_bytes"), dev.get_param("count_bytes_final")) == (1, final)
+    devs = [dev.upload_sdf(s_) for s_ in sdfs]
+    img = lambda i: i % len(sdfs)
+    state_at = {}
+    for i in range(nv):
+        orc.carve(views[i], sdfs[img(i)])
+        if i + 1 in (190, 260):
+            state_at[i + 1] = orc.download()
+    assert dev.CarveBatchDevice(views[:190], [devs[img(i)] for i in range(190)]), vc.last_error()
+    assert dev.get_param("count_bytes") == 1
+    ds, du = dev.download()
+    assert np.array_equal(du, state_at[190][1]) and np.array_equal(ds.view(np.uint32), state_at[190][0].view(np.uint32))
+    m190 = dev.ExtractIsoSurface(0.0, True)
+    # 190 + 64 = 254 views still fit one byte; the last chunk of this call (46 views) does not
+    assert dev.CarveBatchDevice(views[190:], [devs[img(i)] for i in range(190, nv)]), vc.last_error()
+    assert dev.get_param("count_bytes") == 2
+    assert_state_equal(dev, orc, mode + " after 300 views")
+    assert_mesh_equal(dev.ExtractIsoSurface(0.0, True), orc.marching_cubes(0.0, True), mode)
+    if mode == "wa_max_update_300":
+        assert int(dev.download()[1].max()) == nv
+    # the per-view kernel and single-view fused launches cross the boundary view by view
+    for fused in (0, 1):
+        one = vc.VoxelCarver(opt)
+        assert one.Init()
+        one.set_param("fused", fused)
+        one.set_param("defer", 0)
+        one.upload(*state_at[190])
+        assert one.get_param("count_bytes") == 1
+        d1 = [one.upload_sdf(s_) for s_ in sdfs]
+        # (the upload leaves views_carved at the largest count it saw, not at 190: carve until the width must change)
+        for i in range(190, 260):
+            assert one.CarveDevice(views[i], d1[img(i)]), vc.last_error()
+        s1, u1 = one.download()
+        assert np.array_equal(u1, state_at[260][1]), (mode, fused)
+        assert np.array_equal(s1.view(np.uint32), state_at[260][0].view(np.uint32)), (mode, fused)
+    # reset: one byte again, and the same 190 views give the same mesh
+    dev.reset()
+    assert dev.get_param("count_bytes") == 1
+    assert dev.CarveBatchDevice(views[:190], [devs[img(i)] for i in range(190)]), vc.last_error()
+    assert_mesh_equal(dev.ExtractIsoSurface(0.0, True), m190, "after reset")
+    # an upload of counts beyond 255 widens first
+    os_, ou = orc.download()
+    if int(ou.max()) > 255:
+        dev.reset()
+        dev.upload(os_, ou)
+        assert dev.get_param("count_bytes") == 2
+        assert_state_equal(dev, orc, "upload of wide counts")
+    # "lazycount" 0: the final width from the start
+    old = vc.VoxelCarver(opt)
+    assert old.Init()
+    old.set_param("lazycount", 0)
+    assert old.get_param("count_bytes") == final
+    if final <= 2:
+        d2 = [old.upload_sdf(s_) for s_ in sdfs]
+        assert old.CarveBatchDevice(views, [d2[img(i)] for i in range(nv)]), vc.last_error()
+        assert_state_equal(old, orc, "lazycount 0")
+
+
+def test_halo_exchange_between_slabs_of_different_counter_width():
+    """Halo packs carry update_num at its final width whatever the sending slab currently stores (vcy_halo_bytes does
+    not change when a slab is widened), and the receiver converts to its own width: a u16 slab below a u8 slab and the
+    other way round, through the host packs, vcy_halo_copy_from and the native all-gather -- merged mesh == oracle."""
+    from vacancy_amd import dist as vdist
+    n, nv, w, h = 44, 6, 128, 96
+    opt = synth.sphere_option(n, UpdateOption(voxel_update=1, use_truncation=True, truncation_band=0.2))
+    views, masks = synth.sphere_views(n, nv, w, h)
+    sdfs = [vc.make_sdf(m, use_truncation=True, band=0.2) for m in masks]
+    orc = O.OracleGrid(opt)
+    for i in range(nv):
+        orc.carve(views[i], sdfs[i])
+    want = orc.marching_cubes(0.0, True)
+    lib = vc.capi.load()
+    for wide_rank, how in ((0, "host"), (1, "host"), (0, "copy"), (1, "copy"), (1, "rccl")):
+        ranks = []
+        for r in range(2):
+            c = vc.VoxelCarver(opt, z_range=vdist.slab_range(n, r, 2))
+            assert c.Init(), vc.last_error()
+            if r == wide_rank:
+                c.set_param("lazycount", 0)
+            for i in range(nv):
+                assert c.Carve(views[i], sdfs[i])
+            ranks.append(c)
+        assert [c.get_param("count_bytes") for c in ranks] == ([2, 1] if wide_rank == 0 else [1, 2])
+        assert int(lib.vcy_halo_bytes(ranks[0].ctx)) == int(lib.vcy_halo_bytes(ranks[1].ctx)) == 2 * n * n * 6
+        if how == "host":
+            gathered = np.concatenate([c.halo_pack_host() for c in ranks])
+            for r, c in enumerate(ranks):
+                c.halo_unpack_host(gathered, r, 2)
+        elif how == "copy":
+            assert lib.vcy_halo_copy_from(ranks[0].ctx, None) == 0
+            assert lib.vcy_halo_copy_from(ranks[1].ctx, ranks[0].ctx) == 0, vc.last_error()
+            assert ranks[0].get_param("count_bytes") == ranks[1].get_param("count_bytes") == 2
+        else:
+            vc.halo_allgather(ranks)
+        merged = vdist.merge_meshes([c.ExtractIsoSurface(0.0, True) for c in ranks])
+        assert_mesh_equal(merged, want, "wide rank %d via %s" % (wide_rank, how))

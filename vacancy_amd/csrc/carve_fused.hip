@@ -1777,7 +1777,7 @@ bool sane(float f) { return f >= 0x1p-40f && f <= 0x1p40f; }
 // True when the fused kernel can take these views (otherwise the per-view kernel does).
 bool fused_eligible(const vcy_ctx* c, int n_views, const vcy_view* views) {
   const vcy_update_option& u = c->opt.update_option;
-  if (c->cnt_bytes > 2) return false;
+  if (count_width_for(c, c->views_carved + n_views) > 2) return false;  // (32-bit counters: the per-view kernel)
   if (u.voxel_update == VCY_UPDATE_WEIGHTED_AVERAGE && !sane(u.voxel_update_weight)) return false;
   for (int i = 0; i < n_views; ++i) {
     const vcy_view& v = views[i];
@@ -1969,6 +1969,14 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   // having synchronised in between by vcy_carve_log; vcy_last_carve_ms sums the last launch's chunks)
   const bool timed = c->time_carve;
   int stamp = -1;
+  // (a launch that fails between opening a record and its last event leaves no half-recorded triplet behind:
+  // vcy_carve_log would fail on it, or report the times of whatever used those events before)
+  struct LogGuard {
+    vcy_ctx* c;
+    int n0, last0;
+    bool done;
+    ~LogGuard() { if (!done) c->carve_log_n = n0, c->carve_log_last = last0; }
+  } log_guard{c, c->carve_log_n, c->carve_log_last, false};
   if (timed) {
     stamp = carve_log_open(c, true);
     if (stamp >= 0) VCY_HIP_CHECK(hipEventRecord(c->carve_log[stamp].ev[0], c->stream));
@@ -2169,6 +2177,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     VCY_HIP_CHECK(hipGetLastError());
     if (stamp >= 0) VCY_HIP_CHECK(hipEventRecord(c->carve_log[stamp].ev[2], c->stream));
   }
+  log_guard.done = true;
   c->fresh = false;  // the launches store every voxel of a fresh slab
   // (every wave that ran to its end wrote its entry; the others' entries were valid on entry or hold lowest(), see above)
   c->brick_min_valid = c->d_brick_min != nullptr && c->cnt_implied;

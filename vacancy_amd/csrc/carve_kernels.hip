@@ -194,7 +194,7 @@ int launch_carve(vcy_ctx* c, int n_views, const vcy_view* views, const float* co
   const vcy_update_option& u = c->opt.update_option;
   GridParams g;
   g.sdf = c->owned_slab_sdf();
-  g.cnt = c->owned_slab_cnt();
+  g.cnt = nullptr;  // set per launch below: the counter array may be widened between two chunks (ensure_count_width)
   g.px = c->d_px;
   g.py = c->d_py;
   g.pz = c->d_pz;
@@ -225,7 +225,10 @@ int launch_carve(vcy_ctx* c, int n_views, const vcy_view* views, const float* co
     const int chunk = fused_max_views();
     for (int i = 0; i < n_views; i += chunk) {
       const int m = std::min(chunk, n_views - i);
-      int rc = launch_carve_fused(c, g, m, &vp[i]);
+      int rc = ensure_count_width(c, c->views_carved + m);  // (update_num <= views applied: u8 up to the 255th view)
+      if (rc != VCY_OK) return rc;
+      g.cnt = c->owned_slab_cnt();
+      rc = launch_carve_fused(c, g, m, &vp[i]);
       if (rc != VCY_OK) return rc;
       c->views_carved += m;
     }
@@ -234,6 +237,8 @@ int launch_carve(vcy_ctx* c, int n_views, const vcy_view* views, const float* co
     for (int i = 0; i < n_views; ++i) {
       ModeParams m{u.voxel_update, u.sdf_interp, u.update_outside, u.use_truncation ? 1 : 0,
                    views[i].is_ortho ? 1 : 0, 0};
+      { const int rcw = ensure_count_width(c, c->views_carved + 1); if (rcw != VCY_OK) return rcw; }
+      g.cnt = c->owned_slab_cnt();
       if (c->cnt_bytes == 1) launch_view<uint8_t>(c, g, vp[i], m);
       else if (c->cnt_bytes == 2) launch_view<uint16_t>(c, g, vp[i], m);
       else launch_view<uint32_t>(c, g, vp[i], m);
@@ -248,8 +253,11 @@ int launch_carve(vcy_ctx* c, int n_views, const vcy_view* views, const float* co
 // The contiguous partition of L brick layers into n_slabs parts (every part at least one layer) that minimises the
 // largest part's cost and, among those, the sum of the squares: dynamic programming over (parts, layers), O(n_slabs L^2)
 // -- L is nz / 8, a few hundred.  z_bounds[0 .. n_slabs] in slices (layer * 8; the last one nz).  Host arithmetic only
-// (vcy_partition_layers exposes it: the CPU tests check it against brute force).
+// (vcy_partition_layers exposes it: the CPU tests check it against brute force).  Every slab must hold at least two
+// slices (the halo exchange sends a slab's last two): when the last layer is a single slice (nz % 8 == 1) the last part
+// takes at least two layers -- the caller guarantees n_slabs <= L - 1 then.
 void partition_layers(const double* cost, int L, int n_slabs, int nz, int32_t* z_bounds) {
+  const bool tail_single = nz - (L - 1) * 8 == 1 && L > 1;
   std::vector<double> pre((size_t)L + 1, 0.0);
   for (int l = 0; l < L; ++l) pre[(size_t)l + 1] = pre[(size_t)l] + cost[l];
   // f[s][i]: best (largest part, sum of squares) for the first i layers in s parts
@@ -263,6 +271,7 @@ void partition_layers(const double* cost, int L, int n_slabs, int nz, int32_t* z
     for (int i = sidx; i <= L - (n_slabs - sidx); ++i)
       for (int j = sidx - 1; j < i; ++j) {
         if (f[(size_t)sidx - 1][(size_t)j].mx >= 1e299) continue;
+        if (tail_single && i == L && j == L - 1) continue;  // (a last part of one slice)
         const double part = pre[(size_t)i] - pre[(size_t)j];
         const Val v{std::max(f[(size_t)sidx - 1][(size_t)j].mx, part), f[(size_t)sidx - 1][(size_t)j].sq + part * part};
         if (better(v, f[(size_t)sidx][(size_t)i])) {
@@ -290,8 +299,10 @@ constexpr float kPlanBrickCost = 2.55f;
 int plan_z_slabs(vcy_ctx* c, int n_views, const vcy_view* views, const float* const* sdf_dev, int n_slabs, int stride,
                  float brick_cost, int32_t* z_bounds, double* layer_cost, int max_layers, int* n_layers) {
   const int L = (c->nz + 7) / 8;
-  if (n_slabs < 1 || n_slabs > L) {
-    set_error("cannot cut %d brick layers into %d slabs", L, n_slabs);
+  const int usable = (c->nz - (L - 1) * 8 == 1 && L > 1) ? L - 1 : L;  // (a one-slice last layer cannot be a slab)
+  if (n_slabs < 1 || n_slabs > usable || (n_slabs > 1 && c->nz < 2 * n_slabs)) {
+    set_error("cannot cut %d brick layers (%d slices) into %d slabs of whole layers and at least 2 slices", L, c->nz,
+              n_slabs);
     return VCY_ERR_INVALID_ARG;
   }
   std::vector<double> cost((size_t)L, 1.0);

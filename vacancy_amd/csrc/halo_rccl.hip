@@ -188,7 +188,7 @@ int vcy_halo_allgather(vcy_ctx* const* slabs, int n_slabs) {
     if (!c) return VCY_ERR_INVALID_ARG;
     if (i > 0) {
       const vcy_ctx* p = slabs[i - 1];
-      if (p->z1 != c->z0 || p->nx != c->nx || p->ny != c->ny || p->cnt_bytes != c->cnt_bytes) {
+      if (p->z1 != c->z0 || p->nx != c->nx || p->ny != c->ny || p->cnt_bytes_wire != c->cnt_bytes_wire) {
         set_error("vcy_halo_allgather: slab %d does not continue slab %d", i, i - 1);
         return VCY_ERR_INVALID_ARG;
       }

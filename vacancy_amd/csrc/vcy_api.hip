@@ -91,6 +91,91 @@ __global__ void fill_f32_kernel(float* __restrict__ p, float v, int64_t n) {
   for (; i < n; i += stride) p[i] = v;
 }
 
+// update_num from one counter width to another (lazy widening of vcy_ctx::d_cnt; halo packs travel in the final
+// width).  Narrowing saturates: it only happens to the two halo slices a slab receives, whose counters are read as
+// `update_num >= 1` and nothing else (marching_cubes.cc:88-90, extract_voxel.cc:283-286).
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void convert_counts_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n) {
+  int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  constexpr unsigned cap = sizeof(D) == 1 ? 255u : (sizeof(D) == 2 ? 65535u : 0xffffffffu);
+  for (; i < n; i += stride) {
+    if (i + 4 <= n) {
+      S v[4];
+      __builtin_memcpy(v, src + i, sizeof(v));  // (both arrays are 16-byte aligned and i is a multiple of 4)
+      D o[4];
+      for (int k = 0; k < 4; ++k) o[k] = (D)min((unsigned)v[k], cap);
+      __builtin_memcpy(dst + i, o, sizeof(o));
+    } else {
+      for (int64_t k = i; k < n; ++k) dst[k] = (D)min((unsigned)src[k], cap);
+    }
+  }
+}
+
+int convert_counts(hipStream_t stream, const void* src, int sb, void* dst, int db, int64_t n) {
+  if (n <= 0) return VCY_OK;
+  if (sb == db) {
+    VCY_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)n * sb, hipMemcpyDeviceToDevice, stream));
+    return VCY_OK;
+  }
+  const dim3 grid((unsigned)std::min<int64_t>((n + 1023) / 1024, 256 * 32));
+#define VCY_CONV(S, D) hipLaunchKernelGGL((convert_counts_kernel<S, D>), grid, dim3(256), 0, stream, (const S*)src, (D*)dst, n)
+  if (sb == 1 && db == 2) VCY_CONV(uint8_t, uint16_t);
+  else if (sb == 1 && db == 4) VCY_CONV(uint8_t, uint32_t);
+  else if (sb == 2 && db == 4) VCY_CONV(uint16_t, uint32_t);
+  else if (sb == 2 && db == 1) VCY_CONV(uint16_t, uint8_t);
+  else if (sb == 4 && db == 1) VCY_CONV(uint32_t, uint8_t);
+  else if (sb == 4 && db == 2) VCY_CONV(uint32_t, uint16_t);
+  else {
+    set_error("convert_counts: unsupported widths %d -> %d", sb, db);
+    return VCY_ERR_INTERNAL;
+  }
+#undef VCY_CONV
+  VCY_HIP_CHECK(hipGetLastError());
+  return VCY_OK;
+}
+
+// Bytes a counter needs to hold values up to max_count (never more than the final width of the options).
+int count_width_for(const vcy_ctx* c, int64_t max_count) {
+  if (!c->lazy_count) return c->cnt_bytes_wire;
+  const int64_t cap = (int64_t)c->opt.update_option.voxel_max_update_num + 1;  // voxel_carver.cc:447-450
+  const int64_t m = std::min(max_count, cap);
+  const int w = m <= 255 ? 1 : (m <= 65535 ? 2 : 4);
+  return std::min(w, c->cnt_bytes_wire);
+}
+
+// Re-allocates d_cnt at `bytes` per counter, converting what it holds (nothing on a fresh slab).
+static int set_count_width(vcy_ctx* c, int bytes) {
+  if (bytes == c->cnt_bytes) return VCY_OK;
+  const int64_t nvox = c->slice * (int64_t)(c->halo_lo + c->nz_local());
+  void* d_new = nullptr;
+  VCY_HIP_CHECK(hipMalloc(&d_new, (size_t)nvox * bytes));
+  int rc = VCY_OK;
+  if (!c->fresh) {
+    rc = convert_counts(c->stream, c->d_cnt, c->cnt_bytes, d_new, bytes, nvox);
+  } else if (c->halo_lo && c->halo_valid) {
+    rc = convert_counts(c->stream, c->d_cnt, c->cnt_bytes, d_new, bytes, c->slice * (int64_t)c->halo_lo);
+  }
+  if (rc == VCY_OK && hipStreamSynchronize(c->stream) != hipSuccess) {
+    set_error("counter widening failed");
+    rc = VCY_ERR_HIP;
+  }
+  if (rc != VCY_OK) {
+    (void)hipFree(d_new);
+    return rc;
+  }
+  (void)hipFree(c->d_cnt);
+  c->d_cnt = d_new;
+  c->cnt_bytes = bytes;
+  return VCY_OK;
+}
+
+int ensure_count_width(vcy_ctx* c, int64_t max_count) {
+  const int w = count_width_for(c, max_count);
+  if (w <= c->cnt_bytes) return VCY_OK;
+  return set_count_width(c, w);
+}
+
 static void discard_pending(vcy_ctx* c) {
   for (auto& t : c->pending) c->sdf_pool.emplace_back(t.d_sdf, t.bytes);
   c->pending.clear();
@@ -106,6 +191,11 @@ int fill_state(vcy_ctx* c) {
   c->views_carved = 0;
   c->halo_valid = false;
   c->cnt_implied = true;
+  // counters start over at one byte (fresh: nothing to convert; the wide array goes back to the allocator)
+  if (c->d_cnt && c->cnt_bytes != count_width_for(c, 0)) {
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    return set_count_width(c, count_width_for(c, 0));
+  }
   return VCY_OK;
 }
 
@@ -130,7 +220,12 @@ int materialize(vcy_ctx* c) {
 // event cannot be created.
 constexpr int kCarveLogMax = 8192;
 int carve_log_open(vcy_ctx* c, bool first_chunk) {
-  if (c->carve_log_n >= kCarveLogMax) return -1;
+  if (first_chunk) c->carve_log_last_dropped = false;
+  if (c->carve_log_n >= kCarveLogMax) {
+    ++c->carve_log_dropped;
+    c->carve_log_last_dropped = true;
+    return -1;
+  }
   if ((size_t)c->carve_log_n == c->carve_log.size()) {
     vcy_ctx::CarveStamp st{{nullptr, nullptr, nullptr}, false};
     for (int k = 0; k < 3; ++k)
@@ -157,7 +252,8 @@ static void axis_positions(float bb_min, float bb_max, float resolution, int n, 
   for (int i = 0; i < n; ++i) out[i] = diff * (static_cast<float>(i) / static_cast<float>(n)) + bb_min + offset;
 }
 
-static int dims_from_option(const float bb_min[3], const float bb_max[3], float res, int32_t n[3]) {
+static int dims_from_option(const float bb_min[3], const float bb_max[3], float res, int32_t n[3],
+                            bool allow_empty = false) {
   // VoxelGrid::Init, reference voxel_carver.cc:278-301
   if (res < std::numeric_limits<float>::min()) {
     set_error("resolution must be positive %f", res);
@@ -172,6 +268,10 @@ static int dims_from_option(const float bb_min[3], const float bb_max[3], float 
     n[i] = static_cast<int>(diff / res);
   }
   if (n[0] <= 0 || n[1] <= 0 || n[2] <= 0) {
+    // The reference accepts a box thinner than one voxel and builds an EMPTY grid (voxel_carver.cc:292-345: the
+    // loops do not run, Init returns true); the host container does the same (vcy_compute_dims, VoxelGrid::Init).
+    // A device context over no voxels is refused (vcy_create).
+    if (allow_empty) return VCY_OK;
     set_error("grid has an empty axis (%d,%d,%d)", n[0], n[1], n[2]);
     return VCY_ERR_INVALID_ARG;
   }
@@ -220,7 +320,7 @@ int vcy_device_count(int* count) {
 
 int vcy_compute_dims(const float bb_min[3], const float bb_max[3], float resolution,
                      int32_t dims[3]) {
-  return dims_from_option(bb_min, bb_max, resolution, dims);
+  return dims_from_option(bb_min, bb_max, resolution, dims, true);
 }
 
 int vcy_axis_positions(const float bb_min[3], const float bb_max[3], float resolution, int axis, float* out) {
@@ -296,7 +396,8 @@ int vcy_create(const vcy_carver_option* o, int device_id, int z_begin, int z_end
   }
   // update_num never exceeds voxel_max_update_num + 1 (voxel_carver.cc:447-450)
   const int64_t max_cnt = (int64_t)u.voxel_max_update_num + 1;
-  c->cnt_bytes = max_cnt <= 255 ? 1 : (max_cnt <= 65535 ? 2 : 4);
+  c->cnt_bytes_wire = max_cnt <= 255 ? 1 : (max_cnt <= 65535 ? 2 : 4);
+  c->cnt_bytes = 1;  // widened when the views applied (or uploaded counts) need it, ensure_count_width
 
   auto fail = [&](int code) {
     vcy_destroy(c);
@@ -465,7 +566,8 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
   }
   if (std::strcmp(name, "carvetimer") == 0) {
     c->time_carve = value != 0;
-    c->carve_log_n = c->carve_log_last = 0;  // (the log starts over)
+    c->carve_log_n = c->carve_log_last = c->carve_log_dropped = 0;  // (the log starts over)
+    c->carve_log_last_dropped = false;
     return VCY_OK;
   }
   if (std::strcmp(name, "paircount") == 0) {
@@ -496,6 +598,12 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
     c->mesh_keys = value != 0;
     return VCY_OK;
   }
+  if (std::strcmp(name, "lazycount") == 0) {  // 0: counters at their final width from now on (round 4's layout)
+    VCY_HIP_CHECK(hipSetDevice(c->device));
+    c->lazy_count = value != 0;
+    if (!c->lazy_count) return set_count_width(c, c->cnt_bytes_wire);
+    return VCY_OK;
+  }
   set_error("unknown parameter %s", name);
   return VCY_ERR_INVALID_ARG;
 }
@@ -515,6 +623,11 @@ int vcy_get_param(vcy_ctx* c, const char* name, int* value) {
   else if (std::strcmp(name, "livesync") == 0) *value = c->live_sync ? 1 : 0;
   else if (std::strcmp(name, "brick_min_valid") == 0) *value = c->brick_min_valid && !c->fresh ? 1 : 0;
   else if (std::strcmp(name, "meshkeys") == 0) *value = c->mesh_keys ? 1 : 0;
+  else if (std::strcmp(name, "lazycount") == 0) *value = c->lazy_count ? 1 : 0;
+  else if (std::strcmp(name, "carvetimer") == 0) *value = c->time_carve ? 1 : 0;
+  else if (std::strcmp(name, "carvelog_dropped") == 0) *value = c->carve_log_dropped;
+  else if (std::strcmp(name, "count_bytes") == 0) *value = c->cnt_bytes;
+  else if (std::strcmp(name, "count_bytes_final") == 0) *value = c->cnt_bytes_wire;
   else {
     set_error("unknown parameter %s", name);
     return VCY_ERR_INVALID_ARG;
@@ -555,6 +668,10 @@ int vcy_last_carve_ms(vcy_ctx* c, float* prepass_ms, float* kernel_ms) {
   if (!c || !prepass_ms || !kernel_ms) return VCY_ERR_INVALID_ARG;
   VCY_HIP_CHECK(hipSetDevice(c->device));
   *prepass_ms = *kernel_ms = 0.0f;
+  if (c->carve_log_last_dropped) {  // (never an older launch's times in its place)
+    set_error("vcy_last_carve_ms: the event log is full (%d records); read it with vcy_carve_log(clear = 1)", kCarveLogMax);
+    return VCY_ERR_INVALID_ARG;
+  }
   for (int i = c->carve_log_last; i < c->carve_log_n; ++i) {  // the chunks of the last launch
     const vcy_ctx::CarveStamp& st = c->carve_log[(size_t)i];
     float a = 0.0f, b = 0.0f;
@@ -585,7 +702,10 @@ int vcy_carve_log(vcy_ctx* c, int max_records, float* begin_ms, float* prepass_m
     if (first_chunk) first_chunk[i] = st.first_chunk ? 1 : 0;
   }
   *n_records = n;
-  if (clear) c->carve_log_n = c->carve_log_last = 0;
+  if (clear) {
+    c->carve_log_n = c->carve_log_last = c->carve_log_dropped = 0;
+    c->carve_log_last_dropped = false;
+  }
   return VCY_OK;
 }
 
@@ -615,6 +735,10 @@ int vcy_partition_layers(const double* layer_cost, int n_layers, int n_slabs, in
   if (!layer_cost || !z_bounds || n_layers < 1 || n_slabs < 1 || n_slabs > n_layers || nz <= (n_layers - 1) * 8 ||
       nz > n_layers * 8) {
     set_error("vcy_partition_layers: invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  if (n_slabs > 1 && n_layers > 1 && nz - (n_layers - 1) * 8 == 1 && n_slabs > n_layers - 1) {
+    set_error("vcy_partition_layers: the last layer is a single slice and cannot be a slab of its own");
     return VCY_ERR_INVALID_ARG;
   }
   for (int l = 0; l < n_layers; ++l)
@@ -759,7 +883,6 @@ int vcy_upload(vcy_ctx* c, const float* sdf, const int32_t* update_num) {
   if (update_num) {
     const int64_t cap = (int64_t)c->opt.update_option.voxel_max_update_num + 1;
     int64_t mx = 0;
-    std::vector<uint8_t> raw((size_t)n * c->cnt_bytes);
     for (int64_t i = 0; i < n; ++i) {
       const int32_t v = update_num[i];
       if (v < 0 || v > cap) {
@@ -767,6 +890,11 @@ int vcy_upload(vcy_ctx* c, const float* sdf, const int32_t* update_num) {
         return VCY_ERR_INVALID_ARG;
       }
       mx = v > mx ? v : mx;
+    }
+    { const int rcw = ensure_count_width(c, std::max<int64_t>(mx, c->views_carved)); if (rcw != VCY_OK) return rcw; }
+    std::vector<uint8_t> raw((size_t)n * c->cnt_bytes);
+    for (int64_t i = 0; i < n; ++i) {
+      const int32_t v = update_num[i];
       if (c->cnt_bytes == 1) raw[i] = (uint8_t)v;
       else if (c->cnt_bytes == 2) ((uint16_t*)raw.data())[i] = (uint16_t)v;
       else ((int32_t*)raw.data())[i] = v;
@@ -807,7 +935,8 @@ int vcy_download_positions(vcy_ctx* c, float* pos) {
 
 int64_t vcy_halo_bytes(const vcy_ctx* c) {
   if (!c) return 0;
-  return 2 * c->slice * (int64_t)(sizeof(float) + c->cnt_bytes);
+  // (counters travel at their final width: a pack's size and layout do not depend on how many views a slab has seen)
+  return 2 * c->slice * (int64_t)(sizeof(float) + c->cnt_bytes_wire);
 }
 
 int vcy_halo_pack(vcy_ctx* c, void* send) {
@@ -822,9 +951,7 @@ int vcy_halo_pack(vcy_ctx* c, void* send) {
   const float* sdf_src = c->owned_slab_sdf() + (int64_t)(c->nz_local() - 2) * s;
   const char* cnt_src = (const char*)c->owned_slab_cnt() + (int64_t)(c->nz_local() - 2) * s * c->cnt_bytes;
   VCY_HIP_CHECK(hipMemcpyAsync(send, sdf_src, 2 * s * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-  VCY_HIP_CHECK(hipMemcpyAsync((char*)send + 2 * s * sizeof(float), cnt_src, 2 * s * c->cnt_bytes,
-                               hipMemcpyDeviceToDevice, c->stream));
-  return VCY_OK;
+  return convert_counts(c->stream, cnt_src, c->cnt_bytes, (char*)send + 2 * s * sizeof(float), c->cnt_bytes_wire, 2 * s);
 }
 
 int vcy_halo_install(vcy_ctx* c, const void* prev_pack) {
@@ -838,8 +965,8 @@ int vcy_halo_install(vcy_ctx* c, const void* prev_pack) {
   const int64_t s = c->slice;
   const char* src = (const char*)prev_pack;
   VCY_HIP_CHECK(hipMemcpyAsync(c->d_sdf, src, 2 * s * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-  VCY_HIP_CHECK(hipMemcpyAsync(c->d_cnt, src + 2 * s * sizeof(float), 2 * s * c->cnt_bytes,
-                               hipMemcpyDeviceToDevice, c->stream));
+  { const int rcc = convert_counts(c->stream, src + 2 * s * sizeof(float), c->cnt_bytes_wire, c->d_cnt, c->cnt_bytes, 2 * s);
+    if (rcc != VCY_OK) return rcc; }
   c->halo_valid = true;
   return VCY_OK;
 }
@@ -851,12 +978,23 @@ int vcy_halo_copy_from(vcy_ctx* c, vcy_ctx* below) {
     return VCY_OK;
   }
   if (!below || below->z1 != c->z0 || below->nx != c->nx || below->ny != c->ny ||
-      below->cnt_bytes != c->cnt_bytes || below->nz_local() < 2) {
+      below->cnt_bytes_wire != c->cnt_bytes_wire || below->nz_local() < 2) {
     set_error("vcy_halo_copy_from: `below` is not the slab that ends at z_begin (with >= 2 slices)");
     return VCY_ERR_INVALID_ARG;
   }
   VCY_HIP_CHECK(hipSetDevice(below->device));
   { int rcm = materialize(below); if (rcm != VCY_OK) return rcm; }
+  if (below->cnt_bytes != c->cnt_bytes) {  // (slabs that have not seen the same number of views: the wider width for both)
+    const int wide = std::max(below->cnt_bytes, c->cnt_bytes);
+    int rcw = set_count_width(below, wide);
+    if (rcw == VCY_OK) {
+      VCY_HIP_CHECK(hipSetDevice(c->device));
+      { int rcm = flush_pending(c); if (rcm != VCY_OK) return rcm; }
+      rcw = set_count_width(c, wide);
+    }
+    if (rcw != VCY_OK) return rcw;
+    VCY_HIP_CHECK(hipSetDevice(below->device));
+  }
   VCY_HIP_CHECK(hipStreamSynchronize(below->stream));  // its carve must have finished
   VCY_HIP_CHECK(hipSetDevice(c->device));
   const int64_t s = c->slice;
@@ -882,8 +1020,8 @@ int vcy_halo_unpack(vcy_ctx* c, const void* gathered, int rank, int world) {
   const int64_t s = c->slice;
   const char* src = (const char*)gathered + (int64_t)(rank - 1) * vcy_halo_bytes(c);
   VCY_HIP_CHECK(hipMemcpyAsync(c->d_sdf, src, 2 * s * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-  VCY_HIP_CHECK(hipMemcpyAsync(c->d_cnt, src + 2 * s * sizeof(float), 2 * s * c->cnt_bytes,
-                               hipMemcpyDeviceToDevice, c->stream));
+  { const int rcc = convert_counts(c->stream, src + 2 * s * sizeof(float), c->cnt_bytes_wire, c->d_cnt, c->cnt_bytes, 2 * s);
+    if (rcc != VCY_OK) return rcc; }
   c->halo_valid = true;
   return VCY_OK;
 }

@@ -58,7 +58,16 @@ struct vcy_ctx {
   // (no state read, no fill pass); everything else calls materialize() first.
   bool fresh = false;
   int64_t slice = 0;           // nx*ny
+  // Counter width, lazily widened (round 5): update_num of a voxel cannot exceed the number of views applied since the
+  // fill, so the array is u8 while at most 255 views have been applied (or uploaded counts are <= 255), u16 up to 65535,
+  // u32 beyond -- whatever voxel_max_update_num would allow in the end (cnt_bytes_wire, also the width of the halo
+  // packs, whose layout therefore does not depend on how far a slab has got).  The default options (max 255 -> counts up
+  // to 256) used to mean 6 B/voxel from the start; now 5 B/voxel until the 256th view.  ensure_count_width() widens
+  // (one conversion pass, skipped on a fresh slab); vcy_reset goes back to u8.  vcy_set_param "lazycount" 0 keeps the
+  // final width from the start.
   int cnt_bytes = 1;
+  int cnt_bytes_wire = 1;
+  bool lazy_count = true;
 
   float* d_sdf = nullptr;      // includes halo slices
   void* d_cnt = nullptr;
@@ -111,6 +120,8 @@ struct vcy_ctx {
   std::vector<CarveStamp> carve_log;  // event triplets, created on demand (vcy_carve_log, vcy_last_carve_ms)
   int carve_log_n = 0;                // triplets recorded since the log was last cleared
   int carve_log_last = 0;             // index of the first chunk of the last launch
+  int carve_log_dropped = 0;          // chunks that found the log full since it was cleared (vcy_get_param "carvelog_dropped")
+  bool carve_log_last_dropped = false;  // ... the last launch among them: vcy_last_carve_ms has nothing to report
   int* h_live_hint = nullptr;         // page-locked {live workgroups, workgroups} of the last listed launch (a hint, see launch_carve_fused)
   int64_t live_list_age = 0;
   bool use_live_list = true;          // vcy_set_param("livelist", 0): every workgroup is launched and decides for itself
@@ -200,6 +211,9 @@ int device_make_sdf_batch(hipStream_t stream, int n, const uint8_t* const* masks
 void* mesh_host_alloc(size_t bytes);
 void mesh_host_free(void* p);
 // utility kernels (vcy_api.hip)
+int ensure_count_width(vcy_ctx* ctx, int64_t max_count);  // d_cnt wide enough for counts up to max_count (vcy_api.hip)
+int count_width_for(const vcy_ctx* ctx, int64_t max_count);
+int convert_counts(hipStream_t stream, const void* src, int src_bytes, void* dst, int dst_bytes, int64_t n);  // saturating
 int fill_state(vcy_ctx* ctx);   // marks the slab fresh (lazy)
 int materialize(vcy_ctx* ctx);  // writes the fresh state to HBM if it is still pending
 

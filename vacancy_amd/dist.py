@@ -43,11 +43,13 @@ def plan_bounds(option, device_id, views, sdf_host_images, count, stride=0, bric
     `device_id` with a small planning context that is destroyed again.  Deterministic: every rank of a job that calls
     this with the same inputs gets the same cuts.  Returns (bounds, layer_cost, info)."""
     import time
+    import warnings
     from . import carver as vc
     t0 = time.perf_counter()
     p = vc.VoxelCarver(option, device_id=device_id, z_range=(0, 8))
     if not p.Init():
         raise RuntimeError("vcy_create failed (planning context): " + vc.last_error())
+    nz = p.dims[2]
     try:
         uniq, ptrs = {}, []
         for img in sdf_host_images:  # (the same array object for several views is uploaded once)
@@ -55,17 +57,30 @@ def plan_bounds(option, device_id, views, sdf_host_images, count, stride=0, bric
                 uniq[id(img)] = p.upload_sdf(img)
             ptrs.append(uniq[id(img)])
         t1 = time.perf_counter()
-        bounds, cost = p.plan_z_slabs(views, ptrs, count, stride=stride, brick_cost=brick_cost)
+        why = None
+        try:
+            bounds, cost = p.plan_z_slabs(views, ptrs, count, stride=stride, brick_cost=brick_cost)
+            if any(b1 - b0 < 2 for b0, b1 in zip(bounds[:-1], bounds[1:])):
+                why = "planned cuts %s leave a slab of fewer than 2 slices" % (bounds,)
+        except RuntimeError as e:  # (the planner cuts at whole brick layers: nz = 32 cannot give 8 planned slabs)
+            why = str(e)
         t2 = time.perf_counter()
         for d in uniq.values():
             p.free_device(d)
     finally:
         p.close()
+    if why is not None:
+        # slabs of equal thickness always exist when nz >= 2 * count; say so instead of failing the whole job
+        warnings.warn("slab planner: %s -- falling back to slabs of equal thickness" % why)
+        return equal_bounds(nz, count), None, {"plan_ms": round((t2 - t1) * 1e3, 3), "fallback": "equal thickness",
+                                               "reason": why[:200], "in_timed_region": False}
     parts = [float(cost[bounds[s] // 8:(bounds[s + 1] + 7) // 8].sum()) for s in range(count)]
     mean = sum(parts) / max(1, count)
     info = {"plan_ms": round((t2 - t1) * 1e3, 3), "setup_ms": round((t1 - t0) * 1e3, 3),
             "predicted_cost_share": [round(x / (mean * count), 4) for x in parts],
-            "predicted_spread": round((max(parts) - min(parts)) / mean, 4) if mean > 0 else 0.0}
+            "predicted_spread": round((max(parts) - min(parts)) / mean, 4) if mean > 0 else 0.0,
+            # once per view set, before the timed steps (a camera rig that stays put is planned once)
+            "in_timed_region": False}
     return bounds, cost, info
 
 

@@ -1,14 +1,59 @@
 // CPU-only check of the facade's host utilities (no GPU calls): PNG decode of the bunny masks,
 // TUM pose -> w2c arithmetic.  Prints values that tests/test_host.py compares with fixtures.
+#include <cmath>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "vacancy/camera.h"
 #include "vacancy/image.h"
 #include "vacancy/voxel_carver.h"
 
+namespace {
+// A user's Camera: only Project() overridden -- all the reference's carve path calls (camera.h:39-40,
+// voxel_carver.cc:460).  It must compile against the facade, and Carve() must refuse it loudly (the device
+// evaluates PinholeCamera and OrthoCamera only).
+class FisheyeCamera : public vacancy::Camera {
+ public:
+  FisheyeCamera(int w, int h) : vacancy::Camera(w, h) {}
+  void Project(const Eigen::Vector3f& p, Eigen::Vector2f* q) const override {
+    const float r = std::sqrt(p[0] * p[0] + p[1] * p[1]), th = std::atan2(r, p[2]);
+    (*q)[0] = 100.0f * th * (r > 0 ? p[0] / r : 0.0f) + 0.5f * width_;
+    (*q)[1] = 100.0f * th * (r > 0 ? p[1] / r : 0.0f) + 0.5f * height_;
+  }
+};
+}  // namespace
+
 int main(int argc, char* argv[]) {
   const std::string dir = argc > 1 ? argv[1] : ".";
+  if (argc > 2 && std::string(argv[2]) == "gpu") {
+    // needs a device: a carver that works for the two known cameras and says no to a third
+    vacancy::VoxelCarverOption opt;
+    opt.bb_min = Eigen::Vector3f(-16.f, -16.f, -16.f);
+    opt.bb_max = Eigen::Vector3f(16.f, 16.f, 16.f);
+    opt.resolution = 1.0f;
+    vacancy::VoxelCarver carver(opt);
+    if (!carver.Init()) return 3;
+    vacancy::Image1f sdf(64, 48);
+    for (float& v : *sdf.data_ptr()) v = 0.25f;
+    Eigen::Translation3d t;
+    t.x() = 0.0; t.y() = 0.0; t.z() = -80.0;
+    Eigen::Quaterniond q;
+    q.x() = 0.0; q.y() = 0.0; q.z() = 0.0; q.w() = 1.0;
+    vacancy::PinholeCamera pin(64, 48, t * q, 60.0f);
+    vacancy::OrthoCamera ortho(64, 48, t * q);
+    FisheyeCamera fish(64, 48);
+    const bool a = carver.Carve(pin, sdf), b = carver.Carve(ortho, sdf), c = carver.Carve(fish, sdf);
+    std::vector<vacancy::Image1b> sil(1, vacancy::Image1b(64, 48));
+    const bool d = carver.Carve(std::vector<const vacancy::Camera*>{&fish}, sil);
+    std::vector<float> s;
+    std::vector<int> n;
+    const bool e = carver.Download(&s, &n);
+    long long touched = 0;
+    for (int k : n) touched += k > 0;
+    std::printf("CUSTOMCAM %d %d %d %d %d %lld\n", a ? 1 : 0, b ? 1 : 0, c ? 1 : 0, d ? 1 : 0, e ? 1 : 0, touched);
+    return 0;
+  }
   for (int i = 0; i < 6; ++i) {
     vacancy::Image1b m;
     if (!m.Load(dir + "/mask_" + vacancy::zfill(i) + ".png")) return 1;
@@ -60,6 +105,10 @@ int main(int argc, char* argv[]) {
     ok = ok && !grid.get(1, 2, 3).on_surface && grid.resolution() == 10.0f;
     vacancy::VoxelGrid bad;
     ok = ok && !bad.Init(bb_min, bb_max, 10.0f) && !bad.Init(bb_max, bb_min, 0.0f);  // inverted box, zero resolution
+    // a box thinner than one voxel: the reference returns true with an empty grid (voxel_carver.cc:292-345)
+    vacancy::VoxelGrid thin;
+    ok = ok && thin.Init(Eigen::Vector3f(100.f, 100.f, 5.f), Eigen::Vector3f(0.f, 0.f, 0.f), 10.0f) &&
+         !thin.initialized() && thin.voxel_num()[2] == 0 && thin.voxel_num()[0] == 10;
     std::printf("GRID %d %d %d %016llx %d\n", n[0], n[1], n[2], h, ok ? 1 : 0);
   }
   // the reference's look-at forms (common.h:51-75) against the Affine one

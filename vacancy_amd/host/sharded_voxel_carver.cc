@@ -13,7 +13,7 @@ namespace vacancy {
 
 namespace {
 
-vcy_view MakeView(const Camera& camera, int width, int height) {
+vcy_view MakeView(const Camera& camera, int width, int height, bool* ok) {
   vcy_view v;
   std::memset(&v, 0, sizeof(v));
   const Eigen::Affine3f w2c = camera.w2c().cast<float>();
@@ -21,13 +21,19 @@ vcy_view MakeView(const Camera& camera, int width, int height) {
     for (int j = 0; j < 3; ++j) v.w2c[4 * i + j] = w2c.linear()(i, j);
     v.w2c[4 * i + 3] = w2c.translation()[i];
   }
+  // Camera::Project is virtual in the reference (camera.h:39-40, called at voxel_carver.cc:460); the device knows the
+  // two projections the reference implements.  Anything else is refused, never projected with fx = fy = 0.
   if (const PinholeCamera* p = dynamic_cast<const PinholeCamera*>(&camera)) {
     v.fx = p->focal_length()[0];
     v.fy = p->focal_length()[1];
     v.cx = p->principal_point()[0];
     v.cy = p->principal_point()[1];
+  } else if (dynamic_cast<const OrthoCamera*>(&camera)) {
+    v.is_ortho = 1;
+  } else {
+    *ok = false;
+    LOGE("VoxelCarver::Carve unsupported Camera subclass: the HIP path projects PinholeCamera and OrthoCamera only\n");
   }
-  v.is_ortho = camera.is_orthographic() ? 1 : 0;
   v.roi_max[0] = width - 1;
   v.roi_max[1] = height - 1;
   v.width = width;
@@ -108,7 +114,8 @@ bool ShardedVoxelCarver::PlanPartition(const std::vector<const Camera*>& cameras
   std::vector<float*> imgs(n, nullptr);
   bool ok = true;
   for (int i = 0; i < n && ok; ++i) {
-    views[i] = MakeView(*cameras[i], silhouettes[i].width(), silhouettes[i].height());
+    views[i] = MakeView(*cameras[i], silhouettes[i].width(), silhouettes[i].height(), &ok);
+    if (!ok) break;
     // MakeSignedDistanceField as Carve() will build it (voxel_carver.cc:405-408), on the device
     ok = vcy_make_sdf_device(planner, silhouettes[i].data().data(), views[i].width, views[i].height, views[i].roi_min,
                              views[i].roi_max, c.sdf_minmax_normalize, c.update_option.use_truncation,
@@ -171,7 +178,9 @@ bool ShardedVoxelCarver::Carve(const std::vector<const Camera*>& cameras, const 
   std::vector<vcy_view> views(n);
   std::vector<const uint8_t*> masks(n);
   for (int i = 0; i < n; ++i) {
-    views[i] = MakeView(*cameras[i], silhouettes[i].width(), silhouettes[i].height());
+    bool known = true;
+    views[i] = MakeView(*cameras[i], silhouettes[i].width(), silhouettes[i].height(), &known);
+    if (!known) return false;
     masks[i] = silhouettes[i].data().data();
   }
   // one host thread per slab: a context is single-threaded, different contexts are independent.

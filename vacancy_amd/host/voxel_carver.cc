@@ -18,7 +18,7 @@ double NowMs() {
 }
 
 vcy_view ToView(const Camera& camera, const Eigen::Vector2i& roi_min, const Eigen::Vector2i& roi_max, int width,
-                int height) {
+                int height, bool* ok) {
   vcy_view v;
   std::memset(&v, 0, sizeof(v));
   const Eigen::Affine3f w2c = camera.w2c().cast<float>();  // reference voxel_carver.cc:438
@@ -26,13 +26,19 @@ vcy_view ToView(const Camera& camera, const Eigen::Vector2i& roi_min, const Eige
     for (int j = 0; j < 3; ++j) v.w2c[4 * i + j] = w2c.linear()(i, j);
     v.w2c[4 * i + 3] = w2c.translation()[i];
   }
+  // Camera::Project is virtual in the reference (camera.h:39-40, called at voxel_carver.cc:460); the device knows the
+  // two projections the reference implements.  Anything else is refused, never projected with fx = fy = 0.
   if (const PinholeCamera* p = dynamic_cast<const PinholeCamera*>(&camera)) {
     v.fx = p->focal_length()[0];
     v.fy = p->focal_length()[1];
     v.cx = p->principal_point()[0];
     v.cy = p->principal_point()[1];
+  } else if (dynamic_cast<const OrthoCamera*>(&camera)) {
+    v.is_ortho = 1;
+  } else {
+    *ok = false;
+    LOGE("VoxelCarver::Carve unsupported Camera subclass: the HIP path projects PinholeCamera and OrthoCamera only\n");
   }
-  v.is_ortho = camera.is_orthographic() ? 1 : 0;
   v.roi_min[0] = roi_min[0];
   v.roi_min[1] = roi_min[1];
   v.roi_max[0] = roi_max[0];
@@ -40,6 +46,27 @@ vcy_view ToView(const Camera& camera, const Eigen::Vector2i& roi_min, const Eige
   v.width = width;
   v.height = height;
   return v;
+}
+
+// Per-view Carve() calls only queue their view; the loop the reference times as "VoxelCarver::Carve main loop"
+// (voxel_carver.cc:435,492-493) runs when the queue is applied -- inside the next call that reads the state.  The
+// library keeps HIP-event times of every fused launch ("carvetimer"); they are logged here, one line per launch, in the
+// reference's words, by the calls that apply the queue.
+void LogAppliedCarves(vcy_ctx* ctx) {
+  constexpr int kMax = 256;
+  float pre[kMax], ker[kMax];
+  int32_t first[kMax];
+  int n = 0;
+  if (vcy_carve_log(ctx, kMax, nullptr, pre, ker, first, &n, 1) != VCY_OK) return;
+  double ms = 0.0;
+  for (int i = 0; i < n; ++i) {
+    if (first[i] && i > 0) {
+      LOGI("VoxelCarver::Carve main loop %02f\n", ms);
+      ms = 0.0;
+    }
+    ms += static_cast<double>(pre[i]) + ker[i];
+  }
+  if (n > 0) LOGI("VoxelCarver::Carve main loop %02f\n", ms);
 }
 }  // namespace
 
@@ -63,8 +90,9 @@ bool VoxelGrid::Init(const Eigen::Vector3f& bb_max, const Eigen::Vector3f& bb_mi
     LOGE("too many voxels\n");
     return false;
   }
+  const bool empty = n[0] <= 0 || n[1] <= 0 || n[2] <= 0;  // (the reference returns true with no voxels, :292-345)
   std::vector<float> axis[3];
-  for (int a = 0; a < 3; ++a) {
+  for (int a = 0; a < 3 && !empty; ++a) {
     axis[a].resize(static_cast<size_t>(n[a]));
     if (vcy_axis_positions(mn, mx, resolution, a, axis[a].data()) != VCY_OK) return false;
   }
@@ -74,6 +102,7 @@ bool VoxelGrid::Init(const Eigen::Vector3f& bb_max, const Eigen::Vector3f& bb_mi
   voxel_num_ = Eigen::Vector3i(n[0], n[1], n[2]);
   xy_slice_num_ = n[0] * n[1];
   voxels_.clear();
+  if (empty) return true;
   voxels_.resize(static_cast<size_t>(n[0]) * n[1] * n[2]);
   size_t id = 0;
   for (int z = 0; z < n[2]; z++)
@@ -140,6 +169,7 @@ bool VoxelCarver::Init() {
   // one context holds the whole grid: no slab merge, so the mesh needs no edge keys (the reference's
   // MarchingCubes returns vertices and faces)
   vcy_set_param(impl_->ctx, "meshkeys", 0);
+  vcy_set_param(impl_->ctx, "carvetimer", 1);  // (three events per fused launch: LogAppliedCarves)
   return true;
 }
 
@@ -150,7 +180,9 @@ bool VoxelCarver::Carve(const Camera& camera, const Image1b& silhouette, const E
     return false;
   }
   sdf->Init(silhouette.width(), silhouette.height(), 0.0f);
-  const vcy_view v = ToView(camera, roi_min, roi_max, silhouette.width(), silhouette.height());
+  bool known = true;
+  const vcy_view v = ToView(camera, roi_min, roi_max, silhouette.width(), silhouette.height(), &known);
+  if (!known) return false;
   const double t0 = NowMs();
   // The view is QUEUED by the library (vcy_set_param "defer"): this call returns after the silhouette has
   // been uploaded and its SDF built and downloaded; queued views are carved together by one fused
@@ -168,7 +200,9 @@ bool VoxelCarver::Carve(const Camera& camera, const Eigen::Vector2i& roi_min, co
     LOGE("VoxelCarver::Carve voxel grid has not been initialized\n");
     return false;
   }
-  const vcy_view v = ToView(camera, roi_min, roi_max, sdf.width(), sdf.height());
+  bool known = true;
+  const vcy_view v = ToView(camera, roi_min, roi_max, sdf.width(), sdf.height(), &known);
+  if (!known) return false;
   const double t0 = NowMs();
   const int rc = vcy_carve(impl_->ctx, &v, sdf.data().data());  // copied and queued, see above
   LOGI("VoxelCarver::Carve enqueue %02f\n", NowMs() - t0);
@@ -209,13 +243,16 @@ bool VoxelCarver::Carve(const std::vector<const Camera*>& cameras, const std::ve
   std::vector<const uint8_t*> masks(n);
   for (int i = 0; i < n; ++i) {
     const Image1b& s = silhouettes[i];
+    bool known = true;
     views[i] = ToView(*cameras[i], Eigen::Vector2i(0, 0), Eigen::Vector2i(s.width() - 1, s.height() - 1), s.width(),
-                      s.height());
+                      s.height(), &known);
+    if (!known) return false;
     masks[i] = s.data().data();
   }
   // masks are streamed to the device, SDFs built there, views fused in chunks of 32
   const bool ok = vcy_carve_batch_silhouettes(impl_->ctx, n, views.data(), masks.data()) == VCY_OK;
   if (!ok) LOGE("%s\n", vcy_last_error());
+  LogAppliedCarves(impl_->ctx);
   return ok;
 }
 
@@ -229,6 +266,7 @@ void VoxelCarver::ExtractIsoSurface(Mesh* mesh, double iso_level, bool linear_in
     vcy_mesh_free(&m);
     return;
   }
+  LogAppliedCarves(impl_->ctx);
   static_assert(sizeof(Eigen::Vector3f) == 3 * sizeof(float), "packed vector layout");
   static_assert(sizeof(Eigen::Vector3i) == 3 * sizeof(int), "packed vector layout");
   std::vector<Eigen::Vector3f>* v = mesh->mutable_vertices();
@@ -251,6 +289,7 @@ void VoxelCarver::ExtractVoxel(Mesh* mesh, bool inside_empty) {
     vcy_mesh_free(&m);
     return;
   }
+  LogAppliedCarves(impl_->ctx);
   std::vector<Eigen::Vector3f>* v = mesh->mutable_vertices();
   std::vector<Eigen::Vector3i>* f = mesh->mutable_vertex_indices();
   v->resize(static_cast<size_t>(m.n_vertices));
@@ -273,7 +312,9 @@ bool VoxelCarver::Download(std::vector<float>* sdf, std::vector<int>* update_num
   const size_t total = static_cast<size_t>(n[0]) * n[1] * n[2];
   if (sdf) sdf->resize(total);
   if (update_num) update_num->resize(total);
-  return vcy_download(impl_->ctx, sdf ? sdf->data() : nullptr, update_num ? update_num->data() : nullptr) == VCY_OK;
+  const bool ok = vcy_download(impl_->ctx, sdf ? sdf->data() : nullptr, update_num ? update_num->data() : nullptr) == VCY_OK;
+  LogAppliedCarves(impl_->ctx);
+  return ok;
 }
 
 bool VoxelCarver::Download(VoxelGrid* grid) const {

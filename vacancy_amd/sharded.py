@@ -138,6 +138,7 @@ class ShardedVoxelCarver:
 
         def body(i, cs):
             logged = all(hasattr(c, "carve_log") for c in cs)
+            before = [c.get_param("carvetimer") if logged and hasattr(c, "get_param") else 0 for c in cs]
             for c in cs:
                 if logged:
                     c.set_param("carvetimer", 1)  # (clears the log)
@@ -156,17 +157,23 @@ class ShardedVoxelCarver:
             barrier.wait()
             if logged:
                 pre = ker = 0.0
-                for c in cs:
+                dropped = 0
+                for c, was in zip(cs, before):
+                    if hasattr(c, "get_param"):
+                        dropped += c.get_param("carvelog_dropped")  # (the log holds 8192 chunks; later ones are counted)
                     log = c.carve_log()
                     pre += sum(r[1] for r in log)
                     ker += sum(r[2] for r in log)
+                    c.set_param("carvetimer", was)  # (later launches of the caller do not keep recording events)
                 n = float(max(1, steps))
                 stats[i] = {"prepass_ms": pre / n, "kernel_ms": ker / n, "period_ms": walls[i] / n,
                             "idle_ms": max(0.0, (walls[i] - pre - ker) / n)}
+                if dropped:  # (per-step means over an incomplete log would be silently too small)
+                    stats[i] = {"period_ms": walls[i] / n, "log_truncated_chunks": dropped}
 
         self._per_device(run)
         self.last_stats = stats
-        self.last_kernel_ms = [(st["kernel_ms"] + st["prepass_ms"]) if st else w / max(1, steps)
+        self.last_kernel_ms = [(st["kernel_ms"] + st["prepass_ms"]) if st and "kernel_ms" in st else w / max(1, steps)
                                for st, w in zip(stats, walls)]
         return max(walls)
 
