@@ -87,6 +87,10 @@ def parse(argv=None):
                          "all-gather through torch.distributed's nccl backend); inprocess = ONE process, a host thread "
                          "per GPU over the C-ABI, the all-gather issued by the library (vcy_halo_allgather); auto = "
                          "torchrun, and inprocess if that cannot start or its nccl backend fails")
+    ap.add_argument("--verify-mesh", action="store_true",
+                    help="N > 1: merge the slabs' meshes by edge key and compare them, array for array, with the mesh a "
+                         "single context holding the whole grid extracts after the same views (on rank 0's GPU; outside "
+                         "the timed region)")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="no GPU work: launch, rendezvous and the halo all-gather of this configuration with "
                          "rank-stamped host buffers (CPU test of the multi-rank launch path)")
@@ -261,6 +265,36 @@ def plumbing_check(args, rank, world, dist, backend):
     return 0 if ok else 1
 
 
+def whole_grid_mesh(opt, device, batch_fn, fused, cull):
+    """The mesh (with edge keys) of ONE context holding the whole grid after the same views: what the merged slab
+    meshes must equal (--verify-mesh)."""
+    from vacancy_amd import carver as vc
+    w = vc.VoxelCarver(opt, device_id=device)
+    if not w.Init():
+        raise RuntimeError("vcy_create failed (whole grid for --verify-mesh): " + vc.last_error())
+    try:
+        w.set_param("fused", fused)
+        w.set_param("cull", cull)
+        w.set_param("meshkeys", 1)
+        if not batch_fn(w):
+            raise RuntimeError(vc.last_error())
+        return w.ExtractIsoSurface(0.0, True)
+    finally:
+        w.close()
+
+
+def compare_meshes(merged, ref):
+    import numpy as np
+    same = (merged["vertices"].shape == ref["vertices"].shape and merged["faces"].shape == ref["faces"].shape
+            and np.array_equal(merged["vertices"].view(np.uint32), ref["vertices"].view(np.uint32))
+            and np.array_equal(merged["faces"], ref["faces"]) and np.array_equal(merged["keys"], ref["keys"]))
+    return {"merged_equals_single_context": bool(same), "vertices": int(len(merged["vertices"])),
+            "faces": int(len(merged["faces"])), "single_context_vertices": int(len(ref["vertices"])),
+            "single_context_faces": int(len(ref["faces"])),
+            "note": "slab meshes merged by edge key (vacancy_amd.dist.merge_meshes) against one context holding the whole "
+                    "grid on rank 0's device: vertex bits, faces and edge keys, array for array"}
+
+
 def run_inprocess(args, why=None):
     """N GPUs from ONE process (vacancy_amd.sharded.ShardedVoxelCarver): a host thread per device over the
     C-ABI, no torch, no rendezvous; the halo exchange is the library's own RCCL all-gather.  Same workload,
@@ -304,7 +338,8 @@ def run_inprocess(args, why=None):
     stats = list(sh.last_stats)
     kernel_ms = [st["kernel_ms"] for st in stats]
     value = float(n) ** 3 * nv * args.steps / (wall_ms * 1e-3) / 1e6
-    bpv = 4.0 if args.mode == "default" else 4.0 + (1 if uo.voxel_max_update_num <= 254 else 2)
+    # (update_num is one byte until more than 255 views have been applied since the fill: vcy_set_param "lazycount")
+    bpv = 4.0 if args.mode == "default" else 4.0 + (1 if min(nv, uo.voxel_max_update_num + 1) <= 255 else 2)
     views_per_launch = min(nv, 64) if args.batch else 1
     launches = ((nv + views_per_launch - 1) // views_per_launch) * k
     slowest = max(range(G), key=lambda g: kernel_ms[g])
@@ -334,6 +369,10 @@ def run_inprocess(args, why=None):
                   "faces": int(sum(len(m["faces"]) for m in meshes)),
                   "roofline_frac": round(cells * 4.0 / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS / G, 4),
                   "mesh_arrays": "vertices, faces, edge keys (slab merge)"}
+            if args.verify_mesh:
+                from vacancy_amd import dist as vdist_
+                ref = whole_grid_mesh(opt, devices[0], lambda w: w.CarveBatchDevice(batches[0]), args.batch, args.cull)
+                mc["mesh_check"] = compare_meshes(vdist_.merge_meshes(meshes), ref)
         except Exception as e:
             mc = {"error": "%s: %s" % (type(e).__name__, e)}
     if collective is None:
@@ -618,7 +657,9 @@ def main():
     # roofline of the dominant kernel (carve), this rank's slab: algorithmic bytes per launch /
     # launch duration from HIP events on the launch stream.
     def bytes_per_vv(mode, u):
-        return 4.0 if mode == "default" else 4.0 + (1 if u.voxel_max_update_num <= 254 else 2)
+        # fp32 sdf, plus update_num in the weighted-average modes -- one byte while at most 255 views have
+        # been applied since the fill (the library widens the counters lazily, vcy_set_param "lazycount"), else two
+        return 4.0 if mode == "default" else 4.0 + (1 if min(nv, u.voxel_max_update_num + 1) <= 255 else 2)
 
     slab_vox = sum(c.slab_voxels for c in devs) / float(len(devs))  # per launch
     FUSED_MAX = 64  # views per fused launch (carve_fused.hip)
@@ -708,6 +749,7 @@ def main():
                 collective["note"] = backend_note
             mc_ms, mc_wall, nvert, nface = 0.0, 0.0, 0, 0
             mc_calls = []
+            my_meshes = []
             single = world == 1 and len(devs) == 1  # no slab merge: the mesh is vertices + faces, as the reference's
             for c in devs:
                 c.set_param("meshkeys", 0 if single else 1)
@@ -722,6 +764,30 @@ def main():
                 mc_wall += runs[1][0]
                 nvert += len(mesh["vertices"]) - mesh["n_foreign"]
                 nface += len(mesh["faces"])
+                my_meshes.append(mesh)
+            mesh_check = None
+            if args.verify_mesh and not single:
+                # one node: the slab meshes travel through shared memory files, rank 0 merges and compares
+                import numpy as np
+                import shutil
+                base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+                tag = os.path.join(base, "vcy_verify_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getuid()))
+                os.makedirs(tag, exist_ok=True)
+                for (sid, _, _), m in zip(my_slabs, my_meshes):
+                    np.savez(os.path.join(tag, "slab_%d.npz" % sid), vertices=m["vertices"], faces=m["faces"],
+                             keys=m["keys"], n_foreign=np.int64(m["n_foreign"]))
+                barrier()
+                if rank == 0:
+                    parts = []
+                    for sid in range(world * k_slabs):
+                        z = np.load(os.path.join(tag, "slab_%d.npz" % sid))
+                        parts.append({"vertices": z["vertices"], "faces": z["faces"], "keys": z["keys"],
+                                      "n_foreign": int(z["n_foreign"])})
+                    ref = whole_grid_mesh(opt, local_rank, lambda w: w.CarveBatchDevice(batch), args.batch, args.cull)
+                    mesh_check = compare_meshes(vdist.merge_meshes(parts), ref)
+                barrier()
+                if rank == 0:
+                    shutil.rmtree(tag, ignore_errors=True)
             if dist is not None:
                 t = torch.tensor([mc_ms, mc_wall, float(nvert), float(nface)], dtype=torch.float64, device=red_dev)
                 tmax = t.clone()
@@ -740,6 +806,8 @@ def main():
                   "mesh_arrays": "vertices, faces" if single else "vertices, faces, edge keys (slab merge)",
                   "vertices": int(nvert), "faces": int(nface),
                   "roofline_frac": round(cells * 4.0 / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            if mesh_check is not None:
+                mc["mesh_check"] = mesh_check
             if single:
                 # the same extraction reading every brick ("mcskip" 0: no use of the brick minima the carve kernel keeps)
                 c = devs[0]

@@ -158,6 +158,25 @@ int vcy_carve_silhouette(vcy_ctx* ctx, const vcy_view* view,
 int vcy_carve_batch_silhouettes(vcy_ctx* ctx, int n_views, const vcy_view* views,
                                 const uint8_t* const* masks_host);
 
+/* The same over the z-slabs of ONE grid held by this process (`slabs`: contexts of the same option set, any order, on
+ * one or several devices -- vacancy::ShardedVoxelCarver::Carve): the devices SHARE the producer.  Device r of R uploads
+ * and transforms the views r, r + R, ... of every chunk of 32; one ncclAllGather per chunk (librccl, the communicators
+ * of vcy_halo_allgather) hands every device all the images of the chunk (width * height * 4 bytes each); every slab
+ * carves the chunk from its device's copy while the next chunk is produced and gathered.  Slabs that share a device
+ * share its images.  Same result as vcy_carve_batch_silhouettes on every slab -- where every GPU would build every
+ * SDF (voxel_carver.cc:516-528 calls MakeSignedDistanceField once per view, :405-408).  One host thread per device
+ * inside the call; vcy_last_stream_ms reports per slab.  VCY_ERR_UNSUPPORTED when several devices are involved and
+ * librccl cannot be loaded (call vcy_carve_batch_silhouettes per slab then). */
+int vcy_carve_batch_silhouettes_sharded(vcy_ctx* const* slabs, int n_slabs, int n_views, const vcy_view* views,
+                                        const uint8_t* const* masks_host);
+
+/* MakeSignedDistanceField (voxel_carver.cc:169-237, as Carve calls it at :405-408 with the context's options) for
+ * n silhouettes in host memory into CALLER-owned device images (sdf_device_out[i]: width * height floats on the
+ * context's device).  Returns when the images are complete.  The producer share of one rank of a one-process-per-GPU
+ * job (vacancy_amd.dist.carve_silhouettes_sharded: build views r, r + G, ..., all-gather, carve). */
+int vcy_make_sdf_batch_device(vcy_ctx* ctx, int n_views, const vcy_view* views, const uint8_t* const* masks_host,
+                              float* const* sdf_device_out);
+
 /* Of the last vcy_carve_batch_silhouettes: milliseconds its producer side took (per chunk of 32 views: the copy of the
  * silhouettes into page-locked staging, their DMA and the SDF build, events on the producer stream), its consumer
  * side (the fused carve launches, events on the context's stream), both summed over the chunks, and the call's wall

@@ -97,7 +97,7 @@ def _worker(rank, world, port, k, ret, bounds=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,k", [(2, 1), (3, 1), (2, 2)])
+@pytest.mark.parametrize("world,k", [(2, 1), (3, 1), (2, 2), (4, 1), (8, 1)])
 def test_slab_sharded_extraction_merges_to_the_serial_mesh(world, k):
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -164,6 +164,16 @@ def test_bench_self_launches_two_ranks_and_records_the_collective():
     assert line["n_gpus"] == 2
     c = line["collective"]
     assert c["ranks"] == 2 and c["backend"] == "gloo" and c["bytes_per_rank"] == 2 * 64 * 64 * 6 * 2
+
+
+def test_bench_self_launches_eight_ranks():
+    """The full width of one node: eight processes under torch.distributed.run, the halo all-gather of eight slabs
+    over gloo with rank-stamped buffers (what the first real 8-GPU run does with RCCL in its place)."""
+    rc, line, err = _run_bench(["--gpus", "8", "--plumbing-check", "--grid", "64"], timeout=600)
+    assert rc == 0, err[-2000:]
+    assert line is not None and line["plumbing_check"] and line["ok"] and line["n_gpus"] == 8
+    c = line["collective"]
+    assert c["ranks"] == 8 and c["backend"] == "gloo" and c["bytes_per_rank"] == 2 * 64 * 64 * 6
 
 
 def test_bench_refuses_a_gloo_halo_exchange_unless_allowed():

@@ -122,6 +122,8 @@ def load():
         "vcy_carve_batch_device": (C.c_int, [vp, C.c_int, P(View), P(vp)]),
         "vcy_carve_silhouette": (C.c_int, [vp, P(View), vp, vp]),
         "vcy_carve_batch_silhouettes": (C.c_int, [vp, C.c_int, P(View), P(vp)]),
+        "vcy_carve_batch_silhouettes_sharded": (C.c_int, [P(vp), C.c_int, C.c_int, P(View), P(vp)]),
+        "vcy_make_sdf_batch_device": (C.c_int, [vp, C.c_int, P(View), P(vp), P(vp)]),
         "vcy_download_voxels": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
         "vcy_distance_transform_l1": (C.c_int, [vp, C.c_int, C.c_int, P(C.c_int32), P(C.c_int32), vp]),
         "vcy_make_sdf": (C.c_int, [vp, C.c_int, C.c_int, P(C.c_int32), P(C.c_int32),

@@ -101,6 +101,15 @@ class VoxelCarver:
         ptrs = (C.c_void_p * n)(*[m.ctypes.data for m in masks])
         return self._lib.vcy_carve_batch_silhouettes(self._ctx, n, arr, ptrs) == 0
 
+    def make_sdf_batch_into(self, views, silhouettes, out_ptrs):
+        """vcy_make_sdf_batch_device: SDF images of `silhouettes` (host) into caller-owned device images."""
+        n = len(views)
+        arr = (View * n)(*views)
+        masks = [np.ascontiguousarray(m, np.uint8) for m in silhouettes]
+        mptr = (C.c_void_p * n)(*[m.ctypes.data for m in masks])
+        optr = (C.c_void_p * n)(*[p.value if isinstance(p, C.c_void_p) else int(p) for p in out_ptrs])
+        return self._lib.vcy_make_sdf_batch_device(self._ctx, n, arr, mptr, optr) == 0
+
     def last_stream_ms(self):
         """(producer ms, carve ms, wall ms) of the last CarveBatchSilhouettes (vcy_last_stream_ms)."""
         a, b, w = C.c_float(), C.c_float(), C.c_float()
@@ -338,6 +347,24 @@ class VoxelCarver:
         ms = C.c_float()
         self._lib.vcy_timer_end(self._ctx, C.byref(ms))
         return ms.value
+
+
+def carve_batch_silhouettes_sharded(carvers, views, silhouettes):
+    """vcy_carve_batch_silhouettes_sharded: the slabs of one grid held by THIS process carve `views` from silhouettes
+    in host memory; the devices share the producer (device r builds the SDFs of views r, r + R, ... of every chunk, one
+    RCCL all-gather per chunk hands every device all of them)."""
+    lib = capi.load()
+    n = len(views)
+    arr = (View * n)(*views)
+    masks = [np.ascontiguousarray(m, np.uint8) for m in silhouettes]
+    ptrs = (C.c_void_p * n)(*[m.ctypes.data for m in masks])
+    ctxs = (C.c_void_p * len(carvers))(*[c.ctx for c in carvers])
+    rc = lib.vcy_carve_batch_silhouettes_sharded(ctxs, len(carvers), n, arr, ptrs)
+    if rc != 0:
+        e = RuntimeError(last_error())
+        e.rc = rc
+        raise e
+    return True
 
 
 def halo_allgather(carvers):

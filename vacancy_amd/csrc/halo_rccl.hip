@@ -15,9 +15,14 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "vcy_internal.h"
@@ -279,8 +284,345 @@ int vcy_halo_allgather(vcy_ctx* const* slabs, int n_slabs) {
   return VCY_OK;
 }
 
+}  // extern "C"
+
+/* ---- sharded silhouette producer ---------------------------------------------------------------------------------
+ * Carve(vector<Camera>, vector<Image1b>) (reference voxel_carver.cc:516-528 around :394-413) over the z-slabs of ONE
+ * grid held by this process.  Round 4 handed every slab context the whole list (vcy_carve_batch_silhouettes per slab):
+ * each GPU uploaded every silhouette and built every SDF, and at 8 GPUs the producer (1.6 ms per 32 views at 1280 x 720)
+ * was longer than a rank's carve (1.0 ms).  Here the devices SHARE the producer: device r of R uploads and transforms the
+ * views r, r + R, ... of every chunk of 32, ONE ncclAllGather per chunk hands every device all the images (W * H * 4
+ * bytes each), and every slab carves the chunk from its device's copy -- while the next chunk is produced and gathered
+ * on the producer streams.  Slabs that share a device share its images (round 4 built them once per slab).
+ * One host thread per producer rank, like ShardedVoxelCarver's thread per slab; results are bit-identical to the
+ * per-slab form (same images, same fused launches).                                                                  */
+namespace vcy {
+namespace {
+
+struct ProducerRank {
+  int device = 0;
+  hipStream_t aux = nullptr;
+  char* pool = nullptr;      // masks [2][per] | scratch [per] | send [per]
+  size_t pool_bytes = 0;
+  char* recv[2] = {nullptr, nullptr};
+  size_t recv_bytes = 0;
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+  hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_uploaded[2] = {nullptr, nullptr}, ev_sent = nullptr;
+  std::vector<hipEvent_t> ev_consumed[2];  // per slab of this rank
+};
+struct ProducerGroup {
+  std::vector<int> devices;  // per rank (distinct unless the test hook splits a device)
+  std::vector<ProducerRank> ranks;
+};
+std::vector<ProducerGroup*> g_producers;
+
+void destroy_producer(ProducerGroup* g) {
+  for (ProducerRank& r : g->ranks) {
+    (void)hipSetDevice(r.device);
+    if (r.aux) {
+      (void)hipStreamSynchronize(r.aux);
+      (void)hipStreamDestroy(r.aux);
+    }
+    (void)hipFree(r.pool);
+    (void)hipFree(r.recv[0]);
+    (void)hipFree(r.recv[1]);
+    if (r.pinned) (void)hipHostFree(r.pinned);
+    for (int k = 0; k < 2; ++k) {
+      if (r.ev_ready[k]) (void)hipEventDestroy(r.ev_ready[k]);
+      if (r.ev_uploaded[k]) (void)hipEventDestroy(r.ev_uploaded[k]);
+      for (hipEvent_t e : r.ev_consumed[k]) (void)hipEventDestroy(e);
+    }
+    if (r.ev_sent) (void)hipEventDestroy(r.ev_sent);
+  }
+  delete g;
+}
+
+int get_producer(const std::vector<int>& devices, ProducerGroup** out) {
+  for (ProducerGroup* g : g_producers)
+    if (g->devices == devices) {
+      *out = g;
+      return VCY_OK;
+    }
+  ProducerGroup* g = new ProducerGroup;
+  g->devices = devices;
+  g->ranks.resize(devices.size());
+  for (size_t r = 0; r < devices.size(); ++r) {
+    ProducerRank& pr = g->ranks[r];
+    pr.device = devices[r];
+    hipError_t e = hipSetDevice(pr.device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&pr.aux, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+      e = hipEventCreateWithFlags(&pr.ev_ready[k], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&pr.ev_uploaded[k], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&pr.ev_sent, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      set_error("sharded producer: device %d: %s", pr.device, hipGetErrorString(e));
+      destroy_producer(g);
+      return VCY_ERR_HIP;
+    }
+  }
+  g_producers.push_back(g);
+  *out = g;
+  return VCY_OK;
+}
+
+// all threads of one call meet here (test hook path and error hand-over)
+struct HostBarrier {
+  std::mutex m;
+  std::condition_variable cv;
+  int n, waiting = 0, phase = 0;
+  explicit HostBarrier(int n_) : n(n_) {}
+  void wait() {
+    std::unique_lock<std::mutex> lk(m);
+    const int ph = phase;
+    if (++waiting == n) {
+      waiting = 0;
+      ++phase;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return phase != ph; });
+    }
+  }
+};
+
+}  // namespace
+}  // namespace vcy
+
+using namespace vcy;
+
+extern "C" {
+
+int vcy_carve_batch_silhouettes_sharded(vcy_ctx* const* slabs, int n_slabs, int n_views, const vcy_view* views,
+                                        const uint8_t* const* masks_host) {
+  if (!slabs || n_slabs <= 0 || n_views <= 0 || !views || !masks_host) {
+    set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  size_t max_px = 0;
+  for (int i = 0; i < n_views; ++i) {
+    if (!masks_host[i]) {
+      set_error("null silhouette");
+      return VCY_ERR_INVALID_ARG;
+    }
+    max_px = std::max(max_px, (size_t)views[i].width * views[i].height);
+  }
+  for (int s = 0; s < n_slabs; ++s) {
+    if (!slabs[s]) {
+      set_error("VoxelCarver::Carve voxel grid has not been initialized");
+      return VCY_ERR_NOT_INITIALIZED;
+    }
+    const int rc = check_carve_views(slabs[s], n_views, views);
+    if (rc != VCY_OK) return rc;
+    const vcy_carver_option &a = slabs[0]->opt, &b = slabs[s]->opt;
+    if (a.sdf_minmax_normalize != b.sdf_minmax_normalize || a.update_option.use_truncation != b.update_option.use_truncation ||
+        a.update_option.truncation_band != b.update_option.truncation_band) {
+      set_error("vcy_carve_batch_silhouettes_sharded: the slabs do not share one option set");
+      return VCY_ERR_INVALID_ARG;
+    }
+  }
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  // producer ranks: one per distinct device, in order of first appearance.  Test hook VCY_TEST_SPLIT_PRODUCERS=1: one
+  // rank per SLAB even on a shared device, the all-gather then being device copies -- the share / slot / gather
+  // layout of an R-device run, exercised on one GPU.
+  const char* split_env = std::getenv("VCY_TEST_SPLIT_PRODUCERS");
+  const bool split = split_env && split_env[0] == '1';
+  std::vector<int> devices, rank_of((size_t)n_slabs);
+  for (int s = 0; s < n_slabs; ++s) {
+    size_t r = 0;
+    if (split) r = devices.size();
+    else while (r < devices.size() && devices[r] != slabs[s]->device) ++r;
+    if (r == devices.size()) devices.push_back(slabs[s]->device);
+    rank_of[(size_t)s] = (int)r;
+  }
+  const int R = (int)devices.size();
+  bool distinct = true;
+  for (int a = 0; a < R; ++a)
+    for (int b = a + 1; b < R; ++b) distinct = distinct && devices[(size_t)a] != devices[(size_t)b];
+  HaloGroup* comm = nullptr;
+  if (R > 1 && distinct) {
+    if (!load_rccl()) return VCY_ERR_UNSUPPORTED;
+    const int rc = get_group(devices, &comm);
+    if (rc != VCY_OK) return rc;
+  }
+  ProducerGroup* pg = nullptr;
+  {
+    const int rc = get_producer(devices, &pg);
+    if (rc != VCY_OK) return rc;
+  }
+  const int chunk = 32;
+  const int n_chunks = (n_views + chunk - 1) / chunk;
+  const int per = (std::min(chunk, n_views) + R - 1) / R;  // images a rank produces per chunk
+  const size_t stride = (max_px * sizeof(float) + 255) / 256 * 256, sz_mask = (max_px + 255) / 256 * 256;
+  const size_t sz_scr = (device_make_sdf_scratch_bytes(1, (int)max_px) + 255) / 256 * 256;
+  const size_t send_bytes = (size_t)per * stride;
+  const vcy_update_option& u = slabs[0]->opt.update_option;
+  const bool normalize = slabs[0]->opt.sdf_minmax_normalize != 0;
+
+  std::atomic<int> failed(VCY_OK);
+  std::mutex err_mutex;
+  std::string err_text;
+  auto fail = [&](int code, const std::string& text) {
+    std::lock_guard<std::mutex> lk(err_mutex);
+    if (failed.load() == VCY_OK) {
+      failed.store(code);
+      err_text = text;
+    }
+  };
+  HostBarrier barrier(R);
+  const auto t_entry = std::chrono::steady_clock::now();
+
+  auto worker = [&](int r) {
+    ProducerRank& pr = pg->ranks[(size_t)r];
+    std::vector<vcy_ctx*> mine;
+    for (int s = 0; s < n_slabs; ++s)
+      if (rank_of[(size_t)s] == r) mine.push_back(slabs[s]);
+    auto hip_ok = [&](hipError_t e, const char* what) {
+      if (e != hipSuccess) fail(VCY_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+      return e == hipSuccess;
+    };
+    hip_ok(hipSetDevice(pr.device), "hipSetDevice");
+    // buffers of this rank, grown on demand
+    const size_t pool_need = 2 * (size_t)per * sz_mask + (size_t)per * sz_scr + (R > 1 ? send_bytes : 0) + 256;
+    const size_t recv_need = send_bytes * (size_t)R;
+    if (failed.load() == VCY_OK && pr.pool_bytes < pool_need) {
+      (void)hipStreamSynchronize(pr.aux);
+      (void)hipFree(pr.pool);
+      pr.pool = nullptr, pr.pool_bytes = 0;
+      if (hip_ok(hipMalloc((void**)&pr.pool, pool_need), "hipMalloc")) pr.pool_bytes = pool_need;
+    }
+    if (failed.load() == VCY_OK && pr.recv_bytes < recv_need) {
+      for (vcy_ctx* c : mine) (void)hipStreamSynchronize(c->stream);
+      for (int k = 0; k < 2; ++k) {
+        (void)hipFree(pr.recv[k]);
+        pr.recv[k] = nullptr;
+      }
+      pr.recv_bytes = 0;
+      if (hip_ok(hipMalloc((void**)&pr.recv[0], recv_need), "hipMalloc") && hip_ok(hipMalloc((void**)&pr.recv[1], recv_need), "hipMalloc"))
+        pr.recv_bytes = recv_need;
+    }
+    if (failed.load() == VCY_OK && pr.pinned_bytes < 2 * (size_t)per * sz_mask) {
+      (void)hipStreamSynchronize(pr.aux);
+      if (pr.pinned) (void)hipHostFree(pr.pinned);
+      pr.pinned = nullptr, pr.pinned_bytes = 0;
+      if (hip_ok(hipHostMalloc(&pr.pinned, 2 * (size_t)per * sz_mask, hipHostMallocDefault), "hipHostMalloc"))
+        pr.pinned_bytes = 2 * (size_t)per * sz_mask;
+    }
+    for (int k = 0; k < 2; ++k)
+      while (failed.load() == VCY_OK && pr.ev_consumed[k].size() < mine.size()) {
+        hipEvent_t ev = nullptr;
+        if (!hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate")) break;
+        pr.ev_consumed[k].push_back(ev);
+      }
+    for (vcy_ctx* c : mine) {  // the timing record of vcy_last_stream_ms, per slab
+      while (failed.load() == VCY_OK && (int)c->stream_events.size() < 4 * n_chunks) {
+        hipEvent_t ev = nullptr;
+        if (!hip_ok(hipEventCreate(&ev), "hipEventCreate")) break;
+        c->stream_events.push_back(ev);
+      }
+      c->stream_timed_chunks = 0;
+    }
+    barrier.wait();  // every rank has its buffers (or the call has failed) before anything is enqueued
+    char* mask_base = pr.pool;
+    char* scratch = pr.pool + 2 * (size_t)per * sz_mask;
+    char* send = scratch + (size_t)per * sz_scr;
+
+    auto produce = [&](int ci) {
+      const int set = ci & 1, first = ci * chunk, m = std::min(chunk, n_views - first);
+      const bool live = failed.load() == VCY_OK;
+      if (live && ci >= 2) {
+        for (size_t s = 0; s < mine.size(); ++s) hip_ok(hipStreamWaitEvent(pr.aux, pr.ev_consumed[set][s], 0), "hipStreamWaitEvent");
+        hip_ok(hipEventSynchronize(pr.ev_uploaded[set]), "hipEventSynchronize");
+      }
+      std::vector<const uint8_t*> mptr;
+      std::vector<float*> optr;
+      std::vector<vcy_view> myviews;
+      if (live) {
+        for (vcy_ctx* c : mine) hip_ok(hipEventRecord(c->stream_events[(size_t)4 * ci + 0], pr.aux), "hipEventRecord");
+        for (int j = r, k = 0; j < m; j += R, ++k) {  // this rank's share of the chunk: views r, r + R, ...
+          const vcy_view& v = views[first + j];
+          const size_t npx = (size_t)v.width * v.height;
+          char* stage = (char*)pr.pinned + ((size_t)set * per + k) * sz_mask;
+          char* dmask = mask_base + ((size_t)set * per + k) * sz_mask;
+          std::memcpy(stage, masks_host[first + j], npx);
+          hip_ok(hipMemcpyAsync(dmask, stage, npx, hipMemcpyHostToDevice, pr.aux), "mask upload");
+          mptr.push_back((const uint8_t*)dmask);
+          optr.push_back((float*)((R > 1 ? send : pr.recv[set]) + (size_t)k * stride));
+          myviews.push_back(v);
+        }
+        hip_ok(hipEventRecord(pr.ev_uploaded[set], pr.aux), "hipEventRecord");
+        if (!mptr.empty() && failed.load() == VCY_OK) {
+          // MakeSignedDistanceField(...) of voxel_carver.cc:405-408 for this rank's share
+          const int rc = device_make_sdf_batch(pr.aux, (int)mptr.size(), mptr.data(), myviews.data(), normalize,
+                                               u.use_truncation != 0, u.truncation_band, scratch, sz_scr, optr.data());
+          if (rc != VCY_OK) fail(rc, vcy_last_error());
+        }
+      }
+      if (R > 1) {
+        if (comm) {  // the exchange: ONE all-gather per chunk, every device receives every rank's images
+          if (failed.load() == VCY_OK) {
+            const ncclResult_t nr = g_rccl.AllGather(send, pr.recv[set], send_bytes, ncclUint8, comm->comms[(size_t)r], pr.aux);
+            if (nr != ncclSuccess) fail(VCY_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(nr));
+          }
+        } else {  // (test hook: several ranks on one device -- the same data movement as device copies)
+          if (failed.load() == VCY_OK) hip_ok(hipEventRecord(pr.ev_sent, pr.aux), "hipEventRecord");
+          barrier.wait();
+          for (int q = 0; q < R && failed.load() == VCY_OK; ++q) {
+            hip_ok(hipStreamWaitEvent(pr.aux, pg->ranks[(size_t)q].ev_sent, 0), "hipStreamWaitEvent");
+            const char* src = pg->ranks[(size_t)q].pool + 2 * (size_t)per * sz_mask + (size_t)per * sz_scr;
+            hip_ok(hipMemcpyAsync(pr.recv[set] + (size_t)q * send_bytes, src, send_bytes, hipMemcpyDeviceToDevice, pr.aux), "gather copy");
+          }
+          (void)hipStreamSynchronize(pr.aux);
+          barrier.wait();  // nobody overwrites its send buffer before every rank has copied it
+        }
+      }
+      if (failed.load() == VCY_OK) {
+        for (vcy_ctx* c : mine) hip_ok(hipEventRecord(c->stream_events[(size_t)4 * ci + 1], pr.aux), "hipEventRecord");
+        hip_ok(hipEventRecord(pr.ev_ready[set], pr.aux), "hipEventRecord");
+      }
+    };
+
+    produce(0);
+    for (int ci = 0; ci < n_chunks; ++ci) {
+      const int set = ci & 1, first = ci * chunk, m = std::min(chunk, n_views - first);
+      if (ci + 1 < n_chunks) produce(ci + 1);  // the next chunk is produced and gathered while this one is carved
+      if (failed.load() != VCY_OK) continue;   // (keep meeting the others at the barriers of produce)
+      std::vector<const float*> ptrs((size_t)m);
+      for (int j = 0; j < m; ++j) ptrs[(size_t)j] = (const float*)(pr.recv[set] + ((size_t)(j % R) * per + (size_t)(j / R)) * stride);
+      for (size_t s = 0; s < mine.size() && failed.load() == VCY_OK; ++s) {
+        vcy_ctx* c = mine[s];
+        hip_ok(hipStreamWaitEvent(c->stream, pr.ev_ready[set], 0), "hipStreamWaitEvent");
+        hip_ok(hipEventRecord(c->stream_events[(size_t)4 * ci + 2], c->stream), "hipEventRecord");
+        const int rc = launch_carve(c, m, views + first, ptrs.data());
+        if (rc != VCY_OK) fail(rc, vcy_last_error());
+        hip_ok(hipEventRecord(c->stream_events[(size_t)4 * ci + 3], c->stream), "hipEventRecord");
+        hip_ok(hipEventRecord(pr.ev_consumed[set][s], c->stream), "hipEventRecord");
+        if (failed.load() == VCY_OK) c->stream_timed_chunks = ci + 1;
+      }
+    }
+    for (vcy_ctx* c : mine) (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(pr.aux);
+  };
+
+  std::vector<std::thread> threads;
+  for (int r = 1; r < R; ++r) threads.emplace_back(worker, r);
+  worker(0);
+  for (std::thread& t : threads) t.join();
+  const float wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
+  for (int s = 0; s < n_slabs; ++s) slabs[s]->stream_wall_ms = wall;
+  (void)hipSetDevice(slabs[0]->device);
+  if (failed.load() != VCY_OK) {
+    set_error("%s", err_text.c_str());
+    return failed.load();
+  }
+  return VCY_OK;
+}
+
 void vcy_halo_shutdown(void) {
   std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  for (ProducerGroup* g : g_producers) destroy_producer(g);
+  g_producers.clear();
   for (HaloGroup* g : g_groups) destroy_group(g);
   g_groups.clear();
 }

@@ -1060,6 +1060,18 @@ static int check_view(const vcy_ctx* c, const vcy_view* v) {
   return check_view_static(v);
 }
 
+}  // extern "C"
+namespace vcy {
+int check_carve_views(vcy_ctx* c, int n_views, const vcy_view* views) {
+  for (int i = 0; i < n_views; ++i) {
+    const int rc = check_view(c, &views[i]);
+    if (rc != VCY_OK) return rc;
+  }
+  return VCY_OK;
+}
+}  // namespace vcy
+extern "C" {
+
 int vcy_carve_batch_device(vcy_ctx* c, int n_views, const vcy_view* views,
                            const float* const* sdf_device) {
   if (n_views <= 0 || !views || !sdf_device) {
@@ -1263,6 +1275,82 @@ int vcy_make_sdf_device(vcy_ctx* c, const uint8_t* mask_host, int w, int h, cons
   }
   *sdf_device_out = sdf;
   return VCY_OK;
+}
+
+// MakeSignedDistanceField for n silhouettes in host memory into CALLER-owned device images (sdf_device_out[i]: w * h
+// floats on the context's device): page-locked staging -> DMA -> device transform, in groups of 32.  Returns when the
+// images are complete.  What a rank of a multi-GPU job calls for ITS share of the views (views r, r + G, ...) before the
+// images are exchanged (vacancy_amd.dist.carve_silhouettes_sharded): every GPU building every SDF would leave the
+// streamed path producer-bound at 8 GPUs.
+int vcy_make_sdf_batch_device(vcy_ctx* c, int n_views, const vcy_view* views, const uint8_t* const* masks_host,
+                              float* const* sdf_device_out) {
+  if (!c) return VCY_ERR_NOT_INITIALIZED;
+  if (n_views < 0 || (n_views > 0 && (!views || !masks_host || !sdf_device_out))) {
+    set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  if (n_views == 0) return VCY_OK;
+  size_t max_px = 0;
+  for (int i = 0; i < n_views; ++i) {
+    const int rc = check_view_static(&views[i]);
+    if (rc != VCY_OK) return rc;
+    if (!masks_host[i] || !sdf_device_out[i]) {
+      set_error("null silhouette or output image");
+      return VCY_ERR_INVALID_ARG;
+    }
+    max_px = std::max(max_px, (size_t)views[i].width * views[i].height);
+  }
+  VCY_HIP_CHECK(hipSetDevice(c->device));
+  const vcy_update_option& u = c->opt.update_option;
+  const int group = std::min(32, n_views);
+  const size_t sz_mask = (max_px + 255) / 256 * 256;
+  const size_t sz_scr = (device_make_sdf_scratch_bytes(1, (int)max_px) + 255) / 256 * 256;
+  // staging of the streamed entry point, grown on demand (page-locking 64 MB per call would cost more than the work)
+  const size_t need_dev = (size_t)group * (sz_mask + sz_scr), need_pin = (size_t)group * sz_mask;
+  if (c->stream_pool_bytes < need_dev) {
+    VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->d_stream_pool) VCY_HIP_CHECK(hipFree(c->d_stream_pool));
+    c->d_stream_pool = nullptr;
+    c->stream_pool_bytes = 0;
+    VCY_HIP_CHECK(hipMalloc(&c->d_stream_pool, need_dev));
+    c->stream_pool_bytes = need_dev;
+  }
+  if (c->pinned_bytes < need_pin) {
+    if (c->aux_stream) VCY_HIP_CHECK(hipStreamSynchronize(c->aux_stream));
+    if (c->h_pinned) VCY_HIP_CHECK(hipHostFree(c->h_pinned));
+    c->h_pinned = nullptr;
+    c->pinned_bytes = 0;
+    VCY_HIP_CHECK(hipHostMalloc(&c->h_pinned, need_pin, hipHostMallocDefault));
+    c->pinned_bytes = need_pin;
+  }
+  char* d_tmp = (char*)c->d_stream_pool;
+  void* h_stage = c->h_pinned;
+  int rc = VCY_OK;
+  hipStream_t st = c->stream;
+  for (int first = 0; first < n_views && rc == VCY_OK; first += group) {
+    const int m = std::min(group, n_views - first);
+    std::vector<const uint8_t*> mptr((size_t)m);
+    std::vector<float*> optr((size_t)m);
+    if (first > 0 && hipStreamSynchronize(st) != hipSuccess) rc = VCY_ERR_HIP;  // staging and scratch are reused
+    for (int j = 0; j < m && rc == VCY_OK; ++j) {
+      const size_t npx = (size_t)views[first + j].width * views[first + j].height;
+      std::memcpy((char*)h_stage + (size_t)j * sz_mask, masks_host[first + j], npx);
+      if (hipMemcpyAsync(d_tmp + (size_t)j * sz_mask, (char*)h_stage + (size_t)j * sz_mask, npx, hipMemcpyHostToDevice, st) != hipSuccess)
+        rc = VCY_ERR_HIP;
+      mptr[(size_t)j] = (const uint8_t*)(d_tmp + (size_t)j * sz_mask);
+      optr[(size_t)j] = sdf_device_out[first + j];
+    }
+    if (rc == VCY_OK)
+      rc = device_make_sdf_batch(st, m, mptr.data(), views + first, c->opt.sdf_minmax_normalize != 0, u.use_truncation != 0,
+                                 u.truncation_band, d_tmp + (size_t)group * sz_mask, sz_scr, optr.data());
+    else
+      set_error("vcy_make_sdf_batch_device: mask upload failed");
+  }
+  if (hipStreamSynchronize(st) != hipSuccess && rc == VCY_OK) {
+    set_error("vcy_make_sdf_batch_device: %s", hipGetErrorString(hipGetLastError()));
+    rc = VCY_ERR_HIP;
+  }
+  return rc;
 }
 
 // Streams n silhouettes through the device: masks are uploaded and turned into SDFs on a second

@@ -192,6 +192,7 @@ int plan_z_slabs(vcy_ctx* ctx, int n_views, const vcy_view* views, const float* 
                  float brick_cost, int32_t* z_bounds, double* layer_cost, int max_layers, int* n_layers);  // carve_kernels.hip
 int selftest_fused(hipStream_t stream);
 int flush_pending(vcy_ctx* ctx, bool from_carve = false);   // applies vcy_ctx::pending (no-op when empty)
+int check_carve_views(vcy_ctx* ctx, int n_views, const vcy_view* views);  // argument checks of the carve entry points (vcy_api.hip)
 int carve_log_open(vcy_ctx* ctx, bool first_chunk);          // next slot of vcy_ctx::carve_log, or -1 (vcy_api.hip)
 // mc_kernels.hip
 int extract_iso(vcy_ctx* ctx, double iso, int linear_interp, vcy_mesh* out);

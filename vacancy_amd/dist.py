@@ -152,6 +152,78 @@ def exchange_halo(carvers, rank, world):
     return result
 
 
+def carve_silhouettes_sharded(carvers, rank, world, views, silhouettes, chunk=32):
+    """Carve(vector<Camera>, vector<Image1b>) (voxel_carver.cc:516-528 around :394-413) in a one-process-per-GPU job:
+    the ranks SHARE the producer.  Per chunk of `chunk` views rank r uploads and transforms the silhouettes r, r + world,
+    ... (vcy_make_sdf_batch_device, its share only), ONE all-gather (RCCL when the backend is nccl) hands every rank all
+    the SDF images of the chunk (W * H * 4 bytes each), and the rank's slabs carve them in one fused launch; the carve
+    of chunk i is queued asynchronously, so chunk i + 1 is produced and gathered while it runs.  Every rank passes the
+    SAME views and silhouettes.  Results are those of CarveBatchSilhouettes on every slab (every rank building every
+    SDF), which is what round 4 did and what left the streamed path producer-bound at 8 GPUs.
+    Returns {"producer_ms", "gather_ms", "carve_enqueue_ms", "wall_ms"} of this rank (host clock)."""
+    import time
+    import torch
+    import torch.distributed as dist
+    from .carver import VoxelCarver
+
+    if not isinstance(carvers, (list, tuple)):
+        carvers = [carvers]
+    c0 = carvers[0]
+    n = len(views)
+    on_gpu = world > 1 and dist.get_backend() == "nccl"
+    dev = torch.device("cuda", c0._device) if torch.cuda.is_available() else None
+    max_px = max(v.width * v.height for v in views)
+    stride = (max_px + 63) // 64 * 64  # floats per image slot
+    per = (min(chunk, n) + world - 1) // world
+    t_all = time.perf_counter()
+    t_prod = t_gather = t_carve = 0.0
+    # two sets of gathered images: chunk i + 1 is gathered while chunk i is still being carved
+    recv = [torch.empty(world * per * stride, dtype=torch.float32, device=dev) for _ in range(2)]
+    send = torch.empty(per * stride, dtype=torch.float32, device=dev)
+    for ci, first in enumerate(range(0, n, chunk)):
+        m = min(chunk, n - first)
+        rv = recv[ci & 1]
+        if ci >= 2:
+            for c in carvers:
+                c.sync()  # the launches of chunk ci - 2 read this set
+        t0 = time.perf_counter()
+        mine = list(range(rank, m, world))
+        if mine:
+            outs = [send.data_ptr() + 4 * k * stride for k in range(len(mine))]
+            ok = c0.make_sdf_batch_into([views[first + j] for j in mine], [silhouettes[first + j] for j in mine], outs)
+            if not ok:
+                from .carver import last_error
+                raise RuntimeError("vcy_make_sdf_batch_device: " + last_error())
+        t1 = time.perf_counter()
+        if world == 1:
+            rv[:per * stride].copy_(send)
+        elif on_gpu:
+            torch.cuda.current_stream().synchronize()
+            dist.all_gather_into_tensor(rv, send)  # the exchange step of the streamed path
+            torch.cuda.synchronize()
+        else:  # gloo (CPU rendezvous / several ranks on one GPU): the same bytes through the host
+            h = send.cpu()
+            parts = [torch.empty_like(h) for _ in range(world)]
+            dist.all_gather(parts, h)
+            rv.copy_(torch.cat(parts).to(rv.device))
+            if dev is not None:
+                torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        ptrs = [C.c_void_p(rv.data_ptr() + 4 * ((j % world) * per + j // world) * stride) for j in range(m)]
+        batch = VoxelCarver.prepare_batch(views[first:first + m], ptrs)
+        for c in carvers:
+            if not c.CarveBatchDevice(batch):
+                from .carver import last_error
+                raise RuntimeError(last_error())
+        t3 = time.perf_counter()
+        t_prod, t_gather, t_carve = t_prod + (t1 - t0), t_gather + (t2 - t1), t_carve + (t3 - t2)
+    for c in carvers:
+        c.sync()
+    return {"producer_ms": t_prod * 1e3, "gather_ms": t_gather * 1e3, "carve_enqueue_ms": t_carve * 1e3,
+            "wall_ms": (time.perf_counter() - t_all) * 1e3, "views_built_by_this_rank": len(range(rank, n, world)) if chunk >= n
+            else sum(len(range(rank, min(chunk, n - f), world)) for f in range(0, n, chunk))}
+
+
 def merge_meshes(meshes):
     """Stitches per-slab meshes (in slab order) into the mesh a single-GPU extraction returns.
 

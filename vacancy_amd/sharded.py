@@ -177,6 +177,28 @@ class ShardedVoxelCarver:
                                for st, w in zip(stats, walls)]
         return max(walls)
 
+    # -- Carve(vector<Camera>, vector<Image1b>) from silhouettes in HOST memory (voxel_carver.cc:516-528 around
+    # :394-413): the devices share the producer -- device r of G uploads and transforms views r, r + G, ... of every
+    # chunk of 32, one RCCL all-gather per chunk hands every device all the images, every slab carves from its device's
+    # copy (vcy_carve_batch_silhouettes_sharded; round 4 had every slab build every SDF).  `sharded_producer=False` is
+    # that older form: one vcy_carve_batch_silhouettes per slab, a host thread per device.
+    def CarveBatchSilhouettes(self, views, silhouettes, sharded_producer=True):
+        lib = getattr(self.slabs[0], "_lib", None)
+        if sharded_producer and lib is not None and hasattr(lib, "vcy_carve_batch_silhouettes_sharded"):
+            from . import capi
+            from . import carver as _vc
+            try:
+                return _vc.carve_batch_silhouettes_sharded(self.slabs, views, silhouettes)
+            except RuntimeError as e:
+                if getattr(e, "rc", 0) != capi.VCY_ERR_UNSUPPORTED:  # (no librccl: every slab for itself)
+                    raise
+        ok = self._per_device(lambda i, cs: all(c.CarveBatchSilhouettes(views, silhouettes) for c in cs))
+        return all(ok)
+
+    def last_stream_ms(self):
+        """[(producer ms, carve ms, wall ms)] per slab of the last CarveBatchSilhouettes."""
+        return [c.last_stream_ms() for c in self.slabs]
+
     # -- the exchange step of MarchingCubes() (marching_cubes.cc:93-101 reads z - 1)
     def exchange_halo(self):
         if len(self.slabs) == 1:
