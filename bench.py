@@ -375,6 +375,40 @@ def run_inprocess(args, why=None):
                 mc["mesh_check"] = compare_meshes(vdist_.merge_meshes(meshes), ref)
         except Exception as e:
             mc = {"error": "%s: %s" % (type(e).__name__, e)}
+    # the streamed entry point with the producer shared by the devices (vcy_carve_batch_silhouettes_sharded) next to
+    # round 4's form (every slab builds every SDF); wall time, PCIe inclusive: never `value`
+    variants = None
+    want = set() if args.no_variants else set(x.strip() for x in args.variants.split(","))
+    if ("all" in want or "streamed" in want) and args.batch and G * k > 1:
+        variants = {}
+        try:
+            sh2 = ShardedVoxelCarver(opt, devices, k, z_bounds=sh.z_bounds)
+            if not sh2.Init():
+                raise RuntimeError(vc.last_error())
+            sh2.set_param("cull", args.cull)
+            rec = {}
+            for name, shx, flag in (("sharded_producer", sh, True), ("replicated_producer", sh2, False)):
+                walls = []
+                for _ in range(3):
+                    shx.reset()
+                    shx.sync()
+                    tw = time.perf_counter()
+                    if not shx.CarveBatchSilhouettes(views, masks, sharded_producer=flag):
+                        raise RuntimeError(vc.last_error())
+                    shx.sync()
+                    walls.append((time.perf_counter() - tw) * 1e3)
+                w = sorted(walls[1:])[len(walls[1:]) // 2]
+                rec[name] = {"wall_ms": round(w, 3), "value_pcie_inclusive": round(float(n) ** 3 * nv / (w * 1e-3) / 1e6, 1),
+                             "per_slab_producer_carve_wall_ms": [[round(x, 3) for x in t] for t in shx.last_stream_ms()]}
+            rec["voxels_differing_between_the_two"] = int(sum(a.state_diff(b) for a, b in zip(sh.slabs, sh2.slabs)))
+            rec["unit"] = "Mvoxel*views/s"
+            rec["note"] = ("silhouettes in pageable host memory; sharded: device r uploads and transforms views r, r + G, ... of "
+                           "every chunk of 32, one ncclAllGather per chunk hands every device all the images "
+                           "(vcy_carve_batch_silhouettes_sharded); replicated: vcy_carve_batch_silhouettes per slab")
+            variants["streamed_silhouettes"] = rec
+            sh2.close()
+        except Exception as e:
+            variants["streamed_silhouettes"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if collective is None:
         collective = {"backend": "none", "ranks": G, "bytes_per_rank": 0}
     collective["launch"] = "in-process: one host thread per GPU over the C-ABI"
@@ -396,6 +430,8 @@ def run_inprocess(args, why=None):
                         "slabs_z": [list(sh.z_ranges[s]) for s in range(g, G * k, G)]} for g in range(G)]}
     if why:
         out["config"]["launch_note"] = why
+    if variants is not None:
+        out["variants"] = variants
     emit(out)
     for g, cs in enumerate(sh.by_device):
         cs[0].free_device(imgs[g])
@@ -1027,6 +1063,59 @@ def main():
                 c.close()
         except StopIteration:
             pass
+        except Exception as e:
+            variants["streamed_silhouettes"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # N > 1: the streamed entry point (silhouettes in host memory -> SDF images -> fused carve, BASELINE configs[4]) with
+    # the producer SHARED by the ranks (rank r builds the SDFs of views r, r + N, ... of every chunk, one all-gather per
+    # chunk: vacancy_amd.dist.carve_silhouettes_sharded) next to round 4's form (every rank builds every SDF), and a
+    # device-side comparison of the two states.  Wall time of the slowest rank, PCIe inclusive: never `value`.
+    if world > 1 and "streamed" in want and args.batch:
+        variants = variants or {}
+        try:
+            ca, cb = make_carvers(opt, args.cull, my_slabs), make_carvers(opt, args.cull, my_slabs)
+
+            def timed(carvers, fn, reps=3):
+                walls, last = [], None
+                for _ in range(reps):
+                    for c in carvers:
+                        c.reset()
+                    sync_all(carvers)
+                    if dist is not None:
+                        dist.barrier()
+                    tw = time.perf_counter()
+                    last = fn(carvers)
+                    sync_all(carvers)
+                    if dist is not None:
+                        dist.barrier()
+                    walls.append((time.perf_counter() - tw) * 1e3)
+                w = sorted(walls[1:] or walls)[len(walls[1:] or walls) // 2]
+                t = torch.tensor([w], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t.item()), last
+
+            def replicated(carvers):
+                for c in carvers:
+                    if not c.CarveBatchSilhouettes(views, masks):
+                        raise RuntimeError(vc.last_error())
+                return None
+
+            w_sh, info = timed(ca, lambda cs_: vdist.carve_silhouettes_sharded(cs_, rank, world, views, masks))
+            w_rep, _ = timed(cb, replicated)
+            diff = torch.tensor([float(sum(x.state_diff(y) for x, y in zip(ca, cb)))], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(diff)
+            variants["streamed_silhouettes"] = {
+                "sharded_producer": {"wall_ms": round(w_sh, 3), "value_pcie_inclusive": round(float(n) ** 3 * nv / (w_sh * 1e-3) / 1e6, 1),
+                                     "rank0": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in (info or {}).items()}},
+                "replicated_producer": {"wall_ms": round(w_rep, 3),
+                                        "value_pcie_inclusive": round(float(n) ** 3 * nv / (w_rep * 1e-3) / 1e6, 1)},
+                "voxels_differing_between_the_two": int(diff.item()), "unit": "Mvoxel*views/s",
+                "note": "silhouettes in pageable host memory; sharded: rank r uploads and transforms views r, r + N, ... of "
+                        "every chunk of 32 (vcy_make_sdf_batch_device), one all-gather per chunk (backend %s) hands every rank "
+                        "all the images, fused carve; replicated: vcy_carve_batch_silhouettes on every rank (every GPU builds "
+                        "every SDF); wall of the slowest rank, median of the repetitions after the first" % backend}
+            for c in reversed(ca + cb):
+                c.close()
         except Exception as e:
             variants["streamed_silhouettes"] = {"error": "%s: %s" % (type(e).__name__, e)}
 

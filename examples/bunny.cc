@@ -154,6 +154,23 @@ int main(int argc, char* argv[]) {
           updates += v.update_num;
         }
     std::printf("GRID touched %lld negative %lld updates %lld\n", touched, negative, updates);
+    // ... and through ShardedVoxelCarver's batch overload: the slabs share ONE producer of SDF images
+    // (vcy_carve_batch_silhouettes_sharded) -- same mesh as the single context
+    if (n_slabs > 0) {
+      vacancy::ShardedVoxelCarver sb(option, {0}, n_slabs);
+      std::vector<const vacancy::Camera*> ptrs;
+      for (const auto& c : cameras) ptrs.push_back(c.get());
+      vacancy::Mesh a, b;
+      if (!sb.Init() || !sb.Carve(ptrs, silhouettes)) return 9;
+      sb.ExtractIsoSurface(&a, 0.0);
+      batch.ExtractIsoSurface(&b, 0.0);
+      bool same = a.vertices().size() == b.vertices().size() && a.vertex_indices().size() == b.vertex_indices().size();
+      for (size_t k = 0; same && k < a.vertices().size(); ++k)
+        for (int q = 0; q < 3; ++q) same = same && a.vertices()[k][q] == b.vertices()[k][q];
+      for (size_t k = 0; same && k < a.vertex_indices().size(); ++k)
+        for (int q = 0; q < 3; ++q) same = same && a.vertex_indices()[k][q] == b.vertex_indices()[k][q];
+      std::printf("SHARDEDBATCH slabs %d verts %zu identical %d\n", sb.slab_count(), a.vertices().size(), same ? 1 : 0);
+    }
   }
   return 0;
 }

@@ -453,6 +453,8 @@ def test_cpp_bunny_example(tmp_path):
     sh = [l.split() for l in out.splitlines() if l.startswith("SHARDED")]
     assert len(sh) == 6 and all(r[4] == "3" and r[6] == "1" for r in sh), sh
     assert [l for l in out.splitlines() if l.startswith("BOUNDS")] == ["BOUNDS 0 14 28 42"]
+    # the batch overload of ShardedVoxelCarver (one shared SDF producer for the three slabs) == single context
+    assert [l for l in out.splitlines() if l.startswith("SHARDEDBATCH")] == ["SHARDEDBATCH slabs 3 verts 8672 identical 1"]
     # ... and with the cuts ShardedVoxelCarver::PlanPartition places for these six views (vcy_plan_z_slabs: whole
     # brick layers, here 42 slices = 6 layers into 3 slabs)
     out2 = subprocess.run([os.path.join(root, "vacancy_amd", "host", "bunny"), B.BUNNY, str(tmp_path), "10", "3", "planned"],
@@ -1304,3 +1306,86 @@ def test_halo_exchange_between_slabs_of_different_counter_width():
             vc.halo_allgather(ranks)
         merged = vdist.merge_meshes([c.ExtractIsoSurface(0.0, True) for c in ranks])
         assert_mesh_equal(merged, want, "wide rank %d via %s" % (wide_rank, how))
+
+
+@pytest.mark.parametrize("split,kw", [(0, dict()), (1, dict()),
+                                      (1, dict(voxel_update=1, use_truncation=True, truncation_band=0.1))])
+def test_sharded_silhouette_producer_equals_per_slab_producer(split, kw, monkeypatch):
+    """vcy_carve_batch_silhouettes_sharded: the slabs of one grid share the producer of SDF images -- rank r of R builds
+    the views r, r + R, ... of every chunk of 32, the images are gathered, every slab carves the chunk from the
+    gathered copy while the next chunk is produced.  On one GPU: split = 0, the three slabs share the device's images
+    (R = 1); split = 1 (test hook VCY_TEST_SPLIT_PRODUCERS), every slab is a producer rank of its own and the gather
+    runs as device copies -- the share / slot / gather layout of a 3-GPU run.  70 views = chunks of 32, 32 and 6 (the
+    last one leaves rank 2's second slot empty), one view with a sub-ROI: every slab's state == the per-slab form's
+    (every slab building every SDF) == the oracle's."""
+    from vacancy_amd import dist as vdist
+    n, nv, w, h = 48, 70, 160, 120
+    uo = UpdateOption(**kw)
+    opt = synth.sphere_option(n, uo)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    rng = np.random.RandomState(5)
+    for i in range(0, nv, 7):  # distinct silhouettes: a wrong slot would show
+        masks[i] = (rng.rand(h, w) < 0.5).astype(np.uint8) * 255
+    views[3].roi_min[0], views[3].roi_min[1], views[3].roi_max[0], views[3].roi_max[1] = 20, 10, 130, 100
+    monkeypatch.setenv("VCY_TEST_SPLIT_PRODUCERS", str(split))
+
+    def slabs():
+        out = []
+        for r in range(3):
+            c = vc.VoxelCarver(opt, z_range=vdist.slab_range(n, r, 3))
+            assert c.Init(), vc.last_error()
+            out.append(c)
+        return out
+
+    a, b = slabs(), slabs()
+    for c in a:
+        assert c.CarveBatchSilhouettes(views, masks), vc.last_error()
+    assert vc.carve_batch_silhouettes_sharded(b, views, masks)
+    for ca, cb in zip(a, b):
+        assert ca.state_diff(cb) == 0
+        prod, carve, wall = cb.last_stream_ms()
+        assert prod > 0 and carve > 0 and wall > 0
+    orc = O.OracleGrid(opt)
+    for i in range(nv):
+        rmin, rmax = tuple(views[i].roi_min), tuple(views[i].roi_max)
+        orc.carve(views[i], O.make_sdf(masks[i], rmin, rmax, use_truncation=bool(uo.use_truncation), band=uo.truncation_band))
+    os_, ou = orc.download()
+    assert np.array_equal(np.concatenate([c.download()[1] for c in b]), ou)
+    assert np.array_equal(np.concatenate([c.download()[0] for c in b]).view(np.uint32), os_.view(np.uint32))
+    # a second call on the same contexts reuses the cached producer buffers; a failing argument check leaves the state alone
+    for c in a + b:
+        c.reset()
+    assert vc.carve_batch_silhouettes_sharded(b, views[:5], masks[:5])
+    for c in a:
+        assert c.CarveBatchSilhouettes(views[:5], masks[:5])
+    assert all(ca.state_diff(cb) == 0 for ca, cb in zip(a, b))
+    with pytest.raises(RuntimeError):
+        bad = vc.make_view(np.eye(3, 4, dtype=np.float32), 10.0, 10.0, 5.0, 5.0, w, h)
+        bad.roi_max[0] = w  # outside the image
+        vc.carve_batch_silhouettes_sharded(b, [bad], masks[:1])
+    vc.capi.load().vcy_halo_shutdown()  # releases the producer groups as well
+
+
+def test_make_sdf_batch_into_caller_owned_images():
+    """vcy_make_sdf_batch_device: a rank's share of the SDF images of a one-process-per-GPU job, built into images the
+    caller owns (one allocation, as the all-gather's send buffer is) -- bit-equal to the oracle's transform."""
+    import ctypes as C
+    opt = synth.sphere_option(16, UpdateOption(use_truncation=True, truncation_band=0.25))
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init()
+    n, w, h = 40, 96, 72
+    views, masks = synth.sphere_views(16, n, w, h)
+    rng = np.random.RandomState(9)
+    for i in range(n):
+        if i % 3:
+            masks[i] = (rng.rand(h, w) < 0.3 + 0.01 * i).astype(np.uint8) * 255
+    lib = vc.capi.load()
+    buf = C.c_void_p()
+    stride = w * h * 4
+    assert lib.vcy_device_alloc(dev.ctx, n * stride, C.byref(buf)) == 0
+    assert dev.make_sdf_batch_into(views, masks, [buf.value + i * stride for i in range(n)]), vc.last_error()
+    for i in range(n):
+        got = dev.download_image(C.c_void_p(buf.value + i * stride), (h, w))
+        want = O.make_sdf(masks[i], use_truncation=True, band=0.25)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), i
+    dev.free_device(buf)

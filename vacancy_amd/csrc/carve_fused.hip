@@ -1679,12 +1679,13 @@ void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const Gri
 #ifdef VCY_DEV_BENCH_KERNELS_ONLY
   // development builds (profiles/tools/build_variant.sh): only the instantiations bench.py launches,
   // a 20x shorter compile; anything else aborts
-  if (big || checkmax || gen || m.div_level != 2 || !SAMEF || sizeof(CountT) != 2 ||
+  // (the benchmark's 32 / 64 views fit one-byte counters: vcy_ctx::cnt_bytes, lazy widening)
+  if (big || checkmax || gen || m.div_level != 2 || !SAMEF || sizeof(CountT) != 1 ||
       UPDATE == VCY_UPDATE_WEIGHTED_AVERAGE) {
     fprintf(stderr, "VCY_DEV_BENCH_KERNELS_ONLY: kernel variant not built\n");
     abort();
   }
-  if constexpr (SAMEF && sizeof(CountT) == 2 && UPDATE != VCY_UPDATE_WEIGHTED_AVERAGE) VCY_FUSED(false, kTileRaw, false, 2);
+  if constexpr (SAMEF && sizeof(CountT) == 1 && UPDATE != VCY_UPDATE_WEIGHTED_AVERAGE) VCY_FUSED(false, kTileRaw, false, 2);
 #else
   if (big) {
     if (checkmax) VCY_FUSED_G(true, kTileBig); else VCY_FUSED_G(false, kTileBig);

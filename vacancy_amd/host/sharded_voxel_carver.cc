@@ -183,6 +183,21 @@ bool ShardedVoxelCarver::Carve(const std::vector<const Camera*>& cameras, const 
     if (!known) return false;
     masks[i] = silhouettes[i].data().data();
   }
+  // Several views: the devices SHARE the producer (vcy_carve_batch_silhouettes_sharded: device r uploads and transforms
+  // the silhouettes r, r + R, ... of every chunk of 32, one RCCL all-gather per chunk hands every device all the SDF
+  // images, every slab carves from its device's copy) -- the reference calls MakeSignedDistanceField once per view
+  // (voxel_carver.cc:405-408), and so does a node of GPUs.  Without librccl (VCY_ERR_UNSUPPORTED) every slab builds
+  // its own, below.
+  if (n > 1) {
+    const int rc = vcy_carve_batch_silhouettes_sharded(impl_->slabs.data(), static_cast<int>(impl_->slabs.size()), n,
+                                                       views.data(), masks.data());
+    if (rc == VCY_OK) return true;
+    if (rc != VCY_ERR_UNSUPPORTED) {
+      LOGE("sharded carve failed: %s\n", vcy_last_error());
+      return false;
+    }
+    LOGW("ShardedVoxelCarver: %s; every slab builds its own SDF images\n", vcy_last_error());
+  }
   // one host thread per slab: a context is single-threaded, different contexts are independent.
   // vcy_last_error() is per thread: the worker hands its message back with the status.
   std::vector<std::future<std::pair<int, std::string>>> jobs;
