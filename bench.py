@@ -62,6 +62,9 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=1, help="1: fused multi-view carve; 0: one launch per view")
     ap.add_argument("--cull", type=int, default=1,
                     help="1: drop (brick, view) pairs that provably cannot change the brick (results identical)")
+    ap.add_argument("--prologue", type=int, default=0, choices=[0, 1, 2],
+                    help="where a fused launch gets its footprints (vcy_set_param \"prologue\"): 0 = pre-pass records while "
+                         "they fit 2 GiB, else in the carve kernel's prologue; 1 = always the prologue; 2 = always records")
     ap.add_argument("--slabs-per-gpu", type=int, default=0,
                     help="z-slabs per GPU, dealt cyclically (0 = 1: one slab per GPU, cut by predicted cost)")
     ap.add_argument("--partition", default="planned", choices=["planned", "equal"],
@@ -568,6 +571,7 @@ def main():
             # (every slab on a stream of its own: a second slab's launch fills the tail of the first one's)
             c.set_param("fused", args.batch)
             c.set_param("cull", cull)
+            c.set_param("prologue", args.prologue)
             c.set_param("carvetimer", 1)  # HIP events around pre-pass and carve kernel of every launch (vcy_carve_log)
             out.append(c)
         return out

@@ -169,7 +169,7 @@ int main(int argc, char* argv[]) {
         for (int q = 0; q < 3; ++q) same = same && a.vertices()[k][q] == b.vertices()[k][q];
       for (size_t k = 0; same && k < a.vertex_indices().size(); ++k)
         for (int q = 0; q < 3; ++q) same = same && a.vertex_indices()[k][q] == b.vertex_indices()[k][q];
-      std::printf("SHARDEDBATCH slabs %d verts %zu identical %d\n", sb.slab_count(), a.vertices().size(), same ? 1 : 0);
+      std::printf("BATCHSHARDED slabs %d verts %zu identical %d\n", sb.slab_count(), a.vertices().size(), same ? 1 : 0);
     }
   }
   return 0;

@@ -231,11 +231,13 @@ def test_select_free_loops_at_benchmark_footprints(kw):
         if i == nv // 2 - 1:
             half = orc.download()
     os_, ou = orc.download()
-    for cull, tile, reupload in ((1, 0, False), (0, 0, False), (1, 2, False), (1, 0, True)):
+    for cull, tile, reupload, prologue in ((1, 0, False, 0), (0, 0, False, 0), (1, 2, False, 0), (1, 0, True, 0),
+                                           (1, 0, False, 1), (0, 0, True, 1)):
         dev = vc.VoxelCarver(opt)
         assert dev.Init()
         dev.set_param("cull", cull)
         dev.set_param("tile", tile)
+        dev.set_param("prologue", prologue)  # 1: footprints in the carve kernel's prologue instead of the pre-pass's records
         devs = [dev.upload_sdf(s_) for s_ in sdfs]
         assert dev.CarveBatchDevice(views[:nv // 2], devs[:nv // 2]), vc.last_error()
         if reupload:
@@ -246,8 +248,8 @@ def test_select_free_loops_at_benchmark_footprints(kw):
         ds, du = dev.download()
         for d in devs:
             dev.free_device(d)
-        assert np.array_equal(du, ou), (kw, cull, tile, reupload, int((du != ou).sum()))
-        assert np.array_equal(ds.view(np.uint32), os_.view(np.uint32)), (kw, cull, tile, reupload)
+        assert np.array_equal(du, ou), (kw, cull, tile, reupload, prologue, int((du != ou).sum()))
+        assert np.array_equal(ds.view(np.uint32), os_.view(np.uint32)), (kw, cull, tile, reupload, prologue)
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(use_truncation=True, truncation_band=0.2),
@@ -283,12 +285,13 @@ def test_view_dropping_is_exact(kw):
     for i in range(nv):
         orc.carve(views[i], sdfs[i])
     os_, ou = orc.download()
-    for fused, cull, tile in ((1, 1, 0), (1, 1, 2), (1, 0, 1), (0, 0, 0)):
+    for fused, cull, tile, prologue in ((1, 1, 0, 0), (1, 1, 2, 0), (1, 0, 1, 0), (0, 0, 0, 0), (1, 1, 1, 1)):
         dev = vc.VoxelCarver(opt)
         assert dev.Init()
         dev.set_param("fused", fused)
         dev.set_param("cull", cull)
         dev.set_param("tile", tile)
+        dev.set_param("prologue", prologue)
         devs = [dev.upload_sdf(s) for s in sdfs]
         assert dev.CarveBatchDevice(views, devs), vc.last_error()
         ds, du = dev.download()
@@ -454,7 +457,7 @@ def test_cpp_bunny_example(tmp_path):
     assert len(sh) == 6 and all(r[4] == "3" and r[6] == "1" for r in sh), sh
     assert [l for l in out.splitlines() if l.startswith("BOUNDS")] == ["BOUNDS 0 14 28 42"]
     # the batch overload of ShardedVoxelCarver (one shared SDF producer for the three slabs) == single context
-    assert [l for l in out.splitlines() if l.startswith("SHARDEDBATCH")] == ["SHARDEDBATCH slabs 3 verts 8672 identical 1"]
+    assert [l for l in out.splitlines() if l.startswith("BATCHSHARDED")] == ["BATCHSHARDED slabs 3 verts 8672 identical 1"]
     # ... and with the cuts ShardedVoxelCarver::PlanPartition places for these six views (vcy_plan_z_slabs: whole
     # brick layers, here 42 slices = 6 layers into 3 slabs)
     out2 = subprocess.run([os.path.join(root, "vacancy_amd", "host", "bunny"), B.BUNNY, str(tmp_path), "10", "3", "planned"],

@@ -84,7 +84,7 @@ constexpr size_t coop_lds_bytes() {
 
 constexpr int kWmaxPlanes = 2;           // window sizes 4 and 8
 constexpr int kLiveListMaxViews = 8;      // launches of up to this many views over a carved grid list their live workgroups first
-constexpr int64_t kRecordBytesMax = (int64_t)1 << 30;  // footprint records of one carve launch (see launch_carve_fused)
+constexpr int64_t kRecordBytesMax = (int64_t)2 << 30;  // footprint records of one carve launch (see launch_carve_fused)
 
 
 // tuning knobs of the select-free view loop (development builds override them, profiles/tools/build_variant.sh)
@@ -1047,7 +1047,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     pt_acc[12] += t_ - pt_last;
   }
 #endif
-  if constexpr (kRaw) {
+  if (kRaw && records != nullptr) {
     // raw tiles: the footprints come from the pre-pass (footprint_records_kernel), 8 bytes per view
     ub_lane = INFINITY;
     if (lane < nviews) {
@@ -1061,6 +1061,8 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
       ub_lane = ti.ub;
     }
   } else {
+    // the big tile -- and raw tiles of a launch whose records would not fit (`records` null: 2048^3 x 64 views would
+    // write and read back 8.6 GB of them in nine chunks; with 64 views every lane of this prologue has a view)
     const int x_lo = min(x_first, g.nx - 1), x_hi = min(x_first + WX - 1, g.nx - 1);
     const int y_hi = min(by * BY + BY - 1, g.ny - 1);
     const int z_hi = min(zl0 + BZ - 1, g.nz_local - 1);
@@ -2065,9 +2067,18 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   // below kRecordBytesMax (1024^3 x 32 views: 0.5 GiB, one chunk; 2048^3 x 64: nine).
   const int64_t layer_bricks = (int64_t)nbw * nby;
   int chunk_layers = nbz;
-  if (!big) {
+  // Footprints from the pre-pass (records) or from the carve kernel's own prologue?  The pre-pass pays for launches of
+  // few views (its threads are all busy where the prologue would use nviews lanes of 64, and the records are what the
+  // live list and the early return read); for a launch whose records would exceed the cap -- 2048^3 x 64 views: 8.6 GB,
+  // written and read back in nine chunks, 9.4 of the step's 81.7 ms -- the prologue computes them in place, one lane
+  // per view, in ONE launch.  "prologue": 0 that rule, 1 always in the kernel, 2 always records (chunked as before).
+  const int64_t rec_cap = c->record_bytes_max > 0 ? c->record_bytes_max : kRecordBytesMax;  // ("recordbytes": tests force several chunks)
+  const bool in_kernel_prologue =
+      !big && (c->prologue_mode == 1 ||
+               (c->prologue_mode == 0 && c->record_bytes_max == 0 && layer_bricks * nbz * n_views * (int64_t)sizeof(FootprintRecord) > rec_cap));
+  if (!big && !in_kernel_prologue) {
     const int64_t per_layer = layer_bricks * n_views * (int64_t)sizeof(FootprintRecord);
-    const int64_t cap = c->record_bytes_max > 0 ? c->record_bytes_max : kRecordBytesMax;  // ("recordbytes": tests force several chunks)
+    const int64_t cap = rec_cap;
     chunk_layers = (int)std::max<int64_t>(1, std::min<int64_t>(nbz, cap / std::max<int64_t>(per_layer, 1)));
     const size_t need = (size_t)(per_layer * chunk_layers);
     if (c->records_bytes < need) {
@@ -2101,14 +2112,14 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     gc.z0 = g.z0 + l0 * BZ;
     gc.nz_local = std::min(layers * BZ, nzl - l0 * BZ);
     const int64_t nbricks = layer_bricks * layers;
-    FootprintRecord* recs = (FootprintRecord*)c->d_records;
+    FootprintRecord* recs = in_kernel_prologue ? nullptr : (FootprintRecord*)c->d_records;
     float* bmin = c->d_brick_min ? c->d_brick_min + (int64_t)l0 * layer_bricks : nullptr;
     unsigned long long* pcnt = c->count_pairs && c->d_pair_count ? c->d_pair_count + l0 : nullptr;  // ("paircount" 1)
     if (timed && l0 > 0) {
       stamp = carve_log_open(c, false);
       if (stamp >= 0) VCY_HIP_CHECK(hipEventRecord(c->carve_log[stamp].ev[0], c->stream));
     }
-    if (!big) {
+    if (!big && !in_kernel_prologue) {
       const dim3 pgrid((unsigned)((nbricks + 255) / 256), (unsigned)n_views);
 #define VCY_PREPASS(SF, GN)                                                                                       \
   hipLaunchKernelGGL((footprint_records_kernel<SF, GN>), pgrid, dim3(256), 0, c->stream, gc, d_views, nbw, nby,   \
@@ -2129,7 +2140,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     const bool list_pays = c->h_live_hint == nullptr || c->h_live_hint[1] <= 0 ||
                            (double)c->h_live_hint[0] < 0.6 * (double)c->h_live_hint[1];
     ++c->live_list_age;
-    if (!big && c->use_live_list && need_bound && !c->fresh && n_views <= kLiveListMaxViews && (m.trunc != 0 || have_min) &&
+    if (!big && recs != nullptr && c->use_live_list && need_bound && !c->fresh && n_views <= kLiveListMaxViews && (m.trunc != 0 || have_min) &&
         (list_pays || c->live_list_age % 16 == 0)) {  // (every 16th launch looks again)
       const int nwg = (int)grid.x;
       const size_t need = sizeof(int) * ((size_t)nwg + 1);  // (the hint below: a race with its copy is benign, it only

@@ -582,6 +582,11 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
     c->use_live_list = value != 0;
     return VCY_OK;
   }
+  if (std::strcmp(name, "prologue") == 0) {
+    if (value < 0 || value > 2) return VCY_ERR_INVALID_ARG;
+    c->prologue_mode = value;
+    return VCY_OK;
+  }
   if (std::strcmp(name, "livesync") == 0) {
     c->live_sync = value != 0;
     return VCY_OK;
@@ -619,6 +624,7 @@ int vcy_get_param(vcy_ctx* c, const char* name, int* value) {
   else if (std::strcmp(name, "mcsweep") == 0) *value = c->mc_sweep ? 1 : 0;
   else if (std::strcmp(name, "mcskip") == 0) *value = c->mc_skip;
   else if (std::strcmp(name, "livelist") == 0) *value = c->use_live_list ? 1 : 0;
+  else if (std::strcmp(name, "prologue") == 0) *value = c->prologue_mode;
   else if (std::strcmp(name, "coopstore") == 0) *value = c->coop_store;
   else if (std::strcmp(name, "livesync") == 0) *value = c->live_sync ? 1 : 0;
   else if (std::strcmp(name, "brick_min_valid") == 0) *value = c->brick_min_valid && !c->fresh ? 1 : 0;
