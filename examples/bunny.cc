@@ -104,6 +104,21 @@ int main(int argc, char* argv[]) {
     carver.ExtractVoxel(&mesh);  // cube per voxel: large and slow to write, like the reference says
     mesh.WritePlyBinary(out_dir + "/voxel_" + num + ".ply");
     const size_t voxel_verts = mesh.vertices().size();
+    if (sharded) {  // ExtractVoxel over the slabs (both predicates) == the single context's, array for array
+      bool same = true;
+      for (int pass = 0; pass < 2 && same; ++pass) {
+        vacancy::Mesh a, b;
+        sharded->ExtractVoxel(&a, pass == 1);
+        carver.ExtractVoxel(&b, pass == 1);
+        same = a.vertices().size() == b.vertices().size() && a.vertex_indices().size() == b.vertex_indices().size() &&
+               (pass == 1 || b.vertices().size() == voxel_verts);
+        for (size_t k = 0; same && k < a.vertices().size(); ++k)
+          for (int q = 0; q < 3; ++q) same = same && a.vertices()[k][q] == b.vertices()[k][q];
+        for (size_t k = 0; same && k < a.vertex_indices().size(); ++k)
+          for (int q = 0; q < 3; ++q) same = same && a.vertex_indices()[k][q] == b.vertex_indices()[k][q];
+      }
+      std::printf("VOXELSHARDED view %zu identical %d\n", i, same ? 1 : 0);
+    }
     carver.ExtractIsoSurface(&mesh, 0.0);
     mesh.WritePly(out_dir + "/surface_" + num + ".ply");
     const size_t nv = mesh.vertices().size(), nf = mesh.vertex_indices().size();

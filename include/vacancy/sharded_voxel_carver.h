@@ -3,7 +3,9 @@
 // The grid is cut into z-slabs (k per device, dealt cyclically; one per device by default).  Where it is cut
 // matters: with view dropping the slabs through the object cost 1.6x the outer ones, so PlanPartition() places
 // the cuts where a carve of the given views is predicted to cost every slab the same (vcy_plan_z_slabs);
-// without it the slabs are of equal thickness.  Carving needs no exchange, extraction needs the two slices below
+// without it the slabs are of equal thickness.  Carving needs no exchange (a batch of views shares ONE producer of SDF
+// images: device r builds views r, r + R, ..., one RCCL all-gather per chunk of 32 hands every device all of them,
+// vcy_carve_batch_silhouettes_sharded), extraction needs the two slices below
 // each slab -- ONE RCCL all-gather of every slab's boundary slices (vcy_halo_allgather: one
 // communicator rank per device, ncclCommInitAll) -- and the per-slab meshes are stitched by edge key
 // into exactly the mesh a single VoxelCarver returns.  (The one-process-per-GPU form of the same
@@ -42,8 +44,13 @@ class ShardedVoxelCarver {
   bool Carve(const Camera& camera, const Image1b& silhouette);
   bool Carve(const std::vector<const Camera*>& cameras, const std::vector<Image1b>& silhouettes);
   void ExtractIsoSurface(Mesh* mesh, double iso_level = 0.0, bool linear_interp = true);
+  // VoxelCarver::ExtractVoxel over the slabs: the keep predicate and the compaction run on every slab's device, the
+  // kept voxels of all slabs are walked in z order by ONE drifting cube on the host -- the reference's arithmetic
+  // (extract_voxel.cc:290-311), so the mesh equals a single VoxelCarver's array for array.
+  void ExtractVoxel(Mesh* mesh, bool inside_empty = false);
 
  private:
+  bool ExchangeHalo();
   struct Impl;
   std::unique_ptr<Impl> impl_;
 };

@@ -212,6 +212,19 @@ int vcy_extract_iso(vcy_ctx* ctx, double iso_level, int linear_interp,
  * host on the downloaded state (the reference's drifting-cube arithmetic is serial by
  * construction); needs the whole grid in one context.  edge_keys is unused. */
 int vcy_extract_voxel(vcy_ctx* ctx, int inside_empty, vcy_mesh* out);
+/* The two halves of ExtractVoxel for a grid cut into z-slabs (vacancy::ShardedVoxelCarver::ExtractVoxel).
+ * vcy_extract_voxel_ids: the parallel half on the device -- the keep predicate of every voxel of this context's slab
+ * (extract_voxel.cc:283-286, or with inside_empty UpdateOnSurface :15-79; a slab above another one reads the slice below
+ * its first from its halo: vcy_halo_allgather / _unpack / _install first) and the compaction -- returns the kept voxels'
+ * GLOBAL ids in scan order (library-owned, vcy_ids_free; *ids_out = NULL when none is kept).
+ * vcy_voxel_cubes: the serial half on the host, no GPU needed -- the reference translates ONE cube mesh to every kept
+ * voxel and back (extract_voxel.cc:290-311), so every corner carries the rounding of all earlier kept voxels: the
+ * slabs' lists, concatenated in z order, are walked with one drifting cube, and the mesh equals the single-context
+ * vcy_extract_voxel array for array. */
+int vcy_extract_voxel_ids(vcy_ctx* ctx, int inside_empty, int64_t** ids_out, int64_t* n_out);
+void vcy_ids_free(int64_t* ids);
+int vcy_voxel_cubes(const vcy_carver_option* option, int64_t n_ids, const int64_t* ids, vcy_mesh* out);
+
 void vcy_mesh_free(vcy_mesh* mesh);
 /* Milliseconds the device kernels of the last vcy_extract_iso took (hipEvents on the
  * context's stream: classify + owner + scan + emit; the mesh download is not included).

@@ -456,6 +456,8 @@ def test_cpp_bunny_example(tmp_path):
     sh = [l.split() for l in out.splitlines() if l.startswith("SHARDED")]
     assert len(sh) == 6 and all(r[4] == "3" and r[6] == "1" for r in sh), sh
     assert [l for l in out.splitlines() if l.startswith("BOUNDS")] == ["BOUNDS 0 14 28 42"]
+    # ShardedVoxelCarver::ExtractVoxel (device predicate per slab, one drifting cube on the host) == single context
+    assert [l for l in out.splitlines() if l.startswith("VOXELSHARDED")] == ["VOXELSHARDED view %d identical 1" % i for i in range(6)]
     # the batch overload of ShardedVoxelCarver (one shared SDF producer for the three slabs) == single context
     assert [l for l in out.splitlines() if l.startswith("BATCHSHARDED")] == ["BATCHSHARDED slabs 3 verts 8672 identical 1"]
     # ... and with the cuts ShardedVoxelCarver::PlanPartition places for these six views (vcy_plan_z_slabs: whole
@@ -1392,3 +1394,47 @@ def test_make_sdf_batch_into_caller_owned_images():
         want = O.make_sdf(masks[i], use_truncation=True, band=0.25)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), i
     dev.free_device(buf)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_extract_voxel_over_z_slabs(world):
+    """ExtractVoxel on a grid cut into z-slabs (row f2 over slabs): the keep predicate and the compaction run per slab on
+    the device (with inside_empty the -z neighbour of a slab's first slice is its halo slice), the kept ids of all slabs
+    are walked in z order by ONE drifting cube (vcy_voxel_cubes, host) -- the reference translates one cube mesh from
+    voxel to voxel, extract_voxel.cc:290-311.  Bunny, all six views, both predicates: == the single context == the oracle,
+    through the Python ShardedVoxelCarver and through the bare C-ABI calls."""
+    from vacancy_amd import dist as vdist
+    from vacancy_amd.sharded import ShardedVoxelCarver
+    opt = B.bunny_option(10.0)
+    views = B.bunny_views(lambda t, q: synth.affine_inverse(synth.pose_from_tum(t, q)))
+    masks = B.load_masks()
+    whole = vc.VoxelCarver(opt)
+    assert whole.Init()
+    sh = ShardedVoxelCarver(opt, [0] * world, 1)
+    assert sh.Init()
+    orc = O.OracleGrid(opt)
+    for i in range(6):
+        sdf = O.make_sdf(masks[i])
+        assert whole.Carve(views[i], sdf)
+        for c in sh.slabs:
+            assert c.Carve(views[i], sdf)
+        orc.carve(views[i], sdf)
+        if i in (0, 3, 5):
+            for inside_empty in (False, True):
+                want = orc.extract_voxel(inside_empty)
+                one = whole.ExtractVoxel(inside_empty)
+                many = sh.ExtractVoxel(inside_empty)
+                for got in (one, many):
+                    assert np.array_equal(got["faces"], want["faces"]), (i, inside_empty)
+                    assert np.array_equal(got["vertices"].view(np.uint32), want["vertices"].view(np.uint32)), (i, inside_empty)
+    assert len(sh.ExtractVoxel(False)["vertices"]) == 683400  # SURVEY Appendix C
+    # a slab above another one cannot decide the on-surface test of its first slice without its halo
+    nz = whole.dims[2]
+    lone = vc.VoxelCarver(opt, z_range=vdist.slab_range(nz, 1, world))
+    assert lone.Init()
+    assert lone.Carve(views[0], O.make_sdf(masks[0]))
+    assert len(lone.extract_voxel_ids(False)) >= 0
+    with pytest.raises(RuntimeError):
+        lone.extract_voxel_ids(True)
+    with pytest.raises(RuntimeError):
+        lone.ExtractVoxel(False)  # (the single-context call still refuses a slab)

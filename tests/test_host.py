@@ -273,3 +273,25 @@ def test_partition_layers_is_optimal_against_brute_force():
     for bad in ((np.ones(4), 5, None), (np.ones(4), 0, None), (np.array([1.0, np.nan]), 1, None), (np.ones(4), 2, 40),
                 (np.ones(4), 2, 24)):
         assert cut(*bad)[0] == capi.VCY_ERR_INVALID_ARG
+
+
+def test_voxel_cubes_without_a_gpu_equals_the_oracle():
+    """vcy_voxel_cubes -- the serial half of ExtractVoxel that ShardedVoxelCarver runs on the concatenated id lists of its
+    slabs (ONE cube mesh drifting from kept voxel to kept voxel, extract_voxel.cc:290-311) -- is host arithmetic: the
+    oracle's carved bunny, its keep predicate evaluated in numpy, cubes from the library == the oracle's ExtractVoxel."""
+    from vacancy_amd import carver
+    opt = B.bunny_option(10.0)
+    views = B.bunny_views(lambda t, q: O.affine_inverse(O.pose_from_tum(t, q)))
+    g = O.OracleGrid(opt)
+    for i, m in enumerate(B.load_masks()):
+        g.carve(views[i], O.make_sdf(m))
+    sdf, cnt = g.download()
+    ids = np.nonzero(~((sdf > 0) | (cnt < 1)))[0].astype(np.int64)   # extract_voxel.cc:283-286
+    got, want = carver.voxel_cubes(opt, ids), g.extract_voxel(False)
+    assert len(want["vertices"]) == 683400 == len(got["vertices"])      # SURVEY Appendix C
+    assert np.array_equal(got["faces"], want["faces"])
+    assert np.array_equal(got["vertices"].view(np.uint32), want["vertices"].view(np.uint32))
+    empty = carver.voxel_cubes(opt, np.zeros(0, np.int64))
+    assert len(empty["vertices"]) == 0 and len(empty["faces"]) == 0
+    with pytest.raises(RuntimeError):
+        carver.voxel_cubes(opt, np.array([g.n], np.int64))  # outside the grid

@@ -132,6 +132,9 @@ def load():
                                           C.c_int, C.c_int, C.c_float, P(vp)]),
         "vcy_extract_iso": (C.c_int, [vp, C.c_double, C.c_int, P(Mesh)]),
         "vcy_extract_voxel": (C.c_int, [vp, C.c_int, P(Mesh)]),
+        "vcy_extract_voxel_ids": (C.c_int, [vp, C.c_int, P(P(C.c_int64)), P(C.c_int64)]),
+        "vcy_ids_free": (None, [P(C.c_int64)]),
+        "vcy_voxel_cubes": (C.c_int, [P(CarverOption), C.c_int64, vp, P(Mesh)]),
         "vcy_mesh_free": (None, [P(Mesh)]),
         "vcy_last_extract_ms": (C.c_int, [vp, P(C.c_float)]),
         "vcy_last_extract_wall_ms": (C.c_int, [vp, P(C.c_float)]),

@@ -212,6 +212,18 @@ class VoxelCarver:
         self._lib.vcy_mesh_free(C.byref(m))
         return out
 
+    def extract_voxel_ids(self, inside_empty=False):
+        """vcy_extract_voxel_ids: GLOBAL ids of the voxels of this slab that ExtractVoxel keeps, in scan order."""
+        p, n = C.POINTER(C.c_int64)(), C.c_int64(0)
+        rc = self._lib.vcy_extract_voxel_ids(self._ctx, int(inside_empty), C.byref(p), C.byref(n))
+        if rc != 0:
+            raise RuntimeError(last_error())
+        if n.value == 0:
+            return np.zeros(0, np.int64)
+        ids = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+        self._lib.vcy_ids_free(p)
+        return ids
+
     # -- state access
     def download(self):
         n = self.slab_voxels
@@ -365,6 +377,22 @@ def carve_batch_silhouettes_sharded(carvers, views, silhouettes):
         e.rc = rc
         raise e
     return True
+
+
+def voxel_cubes(option, ids):
+    """vcy_voxel_cubes: the serial half of ExtractVoxel (extract_voxel.cc:290-311) for kept voxel ids in scan order --
+    host arithmetic, no GPU."""
+    lib = capi.load()
+    ids = np.ascontiguousarray(ids, np.int64)
+    m = Mesh()
+    rc = lib.vcy_voxel_cubes(C.byref(option), len(ids), _p(ids), C.byref(m))
+    if rc != 0:
+        lib.vcy_mesh_free(C.byref(m))
+        raise RuntimeError(last_error())
+    out = {"vertices": _mesh_array(m.vertices, m.n_vertices, 3, np.float32),
+           "faces": _mesh_array(m.faces, m.n_faces, 3, np.int32)}
+    lib.vcy_mesh_free(C.byref(m))
+    return out
 
 
 def halo_allgather(carvers):

@@ -39,7 +39,7 @@ __device__ __forceinline__ bool product_negative(float a, float b) {
 //                  and (sdf * neighbour.sdf < 0 or |sdf| < FLT_MIN)
 template <typename CountT, bool SURFACE>
 __global__ __launch_bounds__(256) void xv_keep_kernel(const float* __restrict__ sdf, const CountT* __restrict__ cnt,
-                                                      int nx, int ny, int64_t n, u64* __restrict__ bits,
+                                                      int nx, int ny, int64_t n, int has_below, u64* __restrict__ bits,
                                                       u64* __restrict__ block_counts) {
   __shared__ int sm[4];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void xv_keep_kernel(const float* __restrict__ 
       const bool tiny = (__float_as_uint(s) & 0x7fffffffu) < 0x00800000u;  // |sdf| < FLT_MIN
       if (x > 0 && cnt[i - 1] >= 1) keep = keep || tiny || product_negative(s, sdf[i - 1]);
       if (y > 0 && cnt[i - nx] >= 1) keep = keep || tiny || product_negative(s, sdf[i - nx]);
-      if (i >= slice && cnt[i - slice] >= 1) keep = keep || tiny || product_negative(s, sdf[i - slice]);
+      // (a z-slab above another one: the slice below its first is the halo slice z0 - 1, stored right below the slab)
+      if ((i >= slice || has_below) && cnt[i - slice] >= 1) keep = keep || tiny || product_negative(s, sdf[i - slice]);
     }
   }
   const u64 word = __ballot(keep);
@@ -90,28 +91,25 @@ int device_exclusive_scan_u64(unsigned long long* d, int64_t n, unsigned long lo
 
 }  // namespace vcy
 
-extern "C" int vcy_extract_voxel(vcy_ctx* c, int inside_empty, vcy_mesh* out) {
+// Kept voxel ids of this context's slab, GLOBAL ids in scan order (device predicate + compaction).
+static int kept_voxel_ids(vcy_ctx* c, int inside_empty, std::vector<int64_t>* out_ids) {
   using namespace vcy;
-  if (!c || !out) {
-    set_error("invalid argument");
-    return VCY_ERR_INVALID_ARG;
-  }
-  std::memset(out, 0, sizeof(*out));
-  if (c->z0 != 0 || c->z1 != c->nz) {
-    set_error("vcy_extract_voxel needs the whole grid in one context");
-    return VCY_ERR_UNSUPPORTED;
-  }
   VCY_HIP_CHECK(hipSetDevice(c->device));
   {
     const int rcf = flush_pending(c);  // queued views are part of the state
     if (rcf != VCY_OK) return rcf;
   }
-  const int nx = c->nx, ny = c->ny, nz = c->nz;
+  // the on-surface test looks at the voxel below: for a slab above another one that is the halo slice z0 - 1
+  if (inside_empty && c->halo_lo > 0 && !c->halo_valid) {
+    set_error("halo slices not installed (call vcy_halo_unpack / vcy_halo_allgather before extracting from a slab)");
+    return VCY_ERR_NOT_INITIALIZED;
+  }
+  const int nx = c->nx, ny = c->ny, nz = c->nz_local();
   const int64_t n = (int64_t)nx * ny * nz;
   hipStream_t s = c->stream;
-
+  std::vector<int64_t>& ids = *out_ids;
+  ids.clear();
   // ---- device: keep bits -> block counts -> scan -> kept voxel ids ---------------------------------
-  std::vector<int64_t> ids;
   if (!c->fresh) {  // a fresh grid is untouched everywhere: nothing is kept under either predicate
     const int64_t nblocks = (n + 255) / 256;
     auto align = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -138,7 +136,7 @@ extern "C" int vcy_extract_voxel(vcy_ctx* c, int inside_empty, vcy_mesh* out) {
     const void* cnt = c->owned_slab_cnt();
 #define XV_KEEP(CT, SURF)                                                                                       \
   hipLaunchKernelGGL((xv_keep_kernel<CT, SURF>), dim3((unsigned)nblocks), dim3(256), 0, s, sdf, (const CT*)cnt, \
-                     nx, ny, n, d_bits, d_counts)
+                     nx, ny, n, c->halo_lo > 0 ? 1 : 0, d_bits, d_counts)
 #define XV_KEEP_S(CT)                                      \
   do {                                                     \
     if (inside_empty) XV_KEEP(CT, true); else XV_KEEP(CT, false); \
@@ -172,23 +170,29 @@ extern "C" int vcy_extract_voxel(vcy_ctx* c, int inside_empty, vcy_mesh* out) {
     (void)hipFree(d_scratch);
     if (rc != VCY_OK) return rc;
   }
-  const size_t kept = ids.size();
+  const int64_t first = (int64_t)c->z0 * c->slice;
+  if (first)
+    for (int64_t& i : ids) i += first;
+  return VCY_OK;
+}
 
-  // ---- host: the drifting cube -----------------------------------------------------------------
-  std::vector<float> py((size_t)ny);
-  VCY_HIP_CHECK(hipMemcpy(py.data(), c->d_py, sizeof(float) * (size_t)ny, hipMemcpyDeviceToHost));
-  const float* px = c->h_px;
-  const float* pz = c->h_pz;
-
+// The serial half of ExtractVoxel (extract_voxel.cc:290-311): ONE cube mesh (MakeCube, mesh.cc:728-798) translated to
+// every kept voxel and back, in scan order.  Host arithmetic only (this file is built with -ffp-contract=off).
+static int cubes_from_ids(const float* px, const float* py, const float* pz, int nx, int ny, float resolution,
+                          const int64_t* ids, size_t kept, vcy_mesh* out) {
+  using namespace vcy;
   // unit cube of MakeCube(resolution): 6 quads x 4 corners, 12 triangles
-  const float h = c->opt.resolution / 2;
+  const float h = resolution / 2;
   static const int8_t sgn[24][3] = {
       {-1, 1, -1}, {1, 1, -1},  {1, 1, 1},   {-1, 1, 1},  {-1, -1, -1}, {1, -1, -1},  {1, -1, 1},  {-1, -1, 1},
       {1, 1, -1},  {1, 1, 1},   {1, -1, 1},  {1, -1, -1}, {-1, 1, -1},  {-1, 1, 1},   {-1, -1, 1}, {-1, -1, -1},
       {-1, 1, -1}, {1, 1, -1},  {1, -1, -1}, {-1, -1, -1}, {-1, 1, 1},  {1, 1, 1},    {1, -1, 1},  {-1, -1, 1}};
   static const int8_t tri[12][3] = {{0, 2, 1},    {0, 3, 2},    {4, 5, 6},    {4, 6, 7},    {8, 9, 10},   {8, 10, 11},
                                     {12, 14, 13}, {12, 15, 14}, {16, 17, 18}, {16, 18, 19}, {20, 22, 21}, {20, 23, 22}};
-
+  if ((unsigned long long)kept * 24 > (unsigned long long)std::numeric_limits<int32_t>::max()) {
+    set_error("voxel mesh too large for 32-bit indices");
+    return VCY_ERR_TOO_MANY_VOXELS;
+  }
   out->n_vertices = (int64_t)kept * 24;
   out->n_faces = (int64_t)kept * 12;
   if (kept == 0) return VCY_OK;  // an empty mesh has no arrays
@@ -230,4 +234,80 @@ extern "C" int vcy_extract_voxel(vcy_ctx* c, int inside_empty, vcy_mesh* out) {
     base += 24;
   }
   return VCY_OK;
+}
+
+extern "C" int vcy_extract_voxel_ids(vcy_ctx* c, int inside_empty, int64_t** ids_out, int64_t* n_out) {
+  using namespace vcy;
+  if (!c || !ids_out || !n_out) {
+    set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  *ids_out = nullptr;
+  *n_out = 0;
+  std::vector<int64_t> ids;
+  const int rc = kept_voxel_ids(c, inside_empty, &ids);
+  if (rc != VCY_OK) return rc;
+  if (ids.empty()) return VCY_OK;
+  int64_t* p = (int64_t*)mesh_host_alloc(sizeof(int64_t) * ids.size());
+  if (!p) {
+    set_error("out of host memory");
+    return VCY_ERR_INTERNAL;
+  }
+  std::memcpy(p, ids.data(), sizeof(int64_t) * ids.size());
+  *ids_out = p;
+  *n_out = (int64_t)ids.size();
+  return VCY_OK;
+}
+
+extern "C" void vcy_ids_free(int64_t* ids) { vcy::mesh_host_free(ids); }
+
+extern "C" int vcy_voxel_cubes(const vcy_carver_option* o, int64_t n_ids, const int64_t* ids, vcy_mesh* out) {
+  using namespace vcy;
+  if (!o || !out || n_ids < 0 || (n_ids > 0 && !ids)) {
+    set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  std::memset(out, 0, sizeof(*out));
+  int32_t dims[3];
+  int rc = vcy_compute_dims(o->bb_min, o->bb_max, o->resolution, dims);
+  if (rc != VCY_OK) return rc;
+  if (dims[0] <= 0 || dims[1] <= 0 || dims[2] <= 0) {
+    if (n_ids == 0) return VCY_OK;
+    set_error("voxel ids for an empty grid");
+    return VCY_ERR_INVALID_ARG;
+  }
+  const int64_t total = (int64_t)dims[0] * dims[1] * dims[2];
+  for (int64_t t = 0; t < n_ids; ++t)
+    if (ids[t] < 0 || ids[t] >= total) {
+      set_error("voxel id %lld outside the grid", (long long)ids[t]);
+      return VCY_ERR_INVALID_ARG;
+    }
+  std::vector<float> axis[3];
+  for (int a = 0; a < 3; ++a) {
+    axis[a].resize((size_t)dims[a]);
+    rc = vcy_axis_positions(o->bb_min, o->bb_max, o->resolution, a, axis[a].data());
+    if (rc != VCY_OK) return rc;
+  }
+  return cubes_from_ids(axis[0].data(), axis[1].data(), axis[2].data(), dims[0], dims[1], o->resolution, ids, (size_t)n_ids, out);
+}
+
+extern "C" int vcy_extract_voxel(vcy_ctx* c, int inside_empty, vcy_mesh* out) {
+  using namespace vcy;
+  if (!c || !out) {
+    set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  std::memset(out, 0, sizeof(*out));
+  if (c->z0 != 0 || c->z1 != c->nz) {
+    // ONE cube drifts through the kept voxels of the whole grid (extract_voxel.cc:290-311): the slabs' id lists
+    // are concatenated in z order and walked by vcy_voxel_cubes (ShardedVoxelCarver::ExtractVoxel)
+    set_error("vcy_extract_voxel needs the whole grid in one context; for z-slabs: vcy_extract_voxel_ids per slab, then vcy_voxel_cubes");
+    return VCY_ERR_UNSUPPORTED;
+  }
+  std::vector<int64_t> ids;
+  const int rc = kept_voxel_ids(c, inside_empty, &ids);
+  if (rc != VCY_OK) return rc;
+  std::vector<float> py((size_t)c->ny);
+  VCY_HIP_CHECK(hipMemcpy(py.data(), c->d_py, sizeof(float) * (size_t)c->ny, hipMemcpyDeviceToHost));
+  return cubes_from_ids(c->h_px, py.data(), c->h_pz, c->nx, c->ny, c->opt.resolution, ids.data(), ids.size(), out);
 }

@@ -219,22 +219,69 @@ bool ShardedVoxelCarver::Carve(const std::vector<const Camera*>& cameras, const 
   return ok;
 }
 
+// the two slices below every slab: ONE RCCL all-gather over the devices that hold slabs
+// (vcy_halo_allgather); peer-to-peer copies only when asked for (set_halo_transport)
+bool ShardedVoxelCarver::ExchangeHalo() {
+  const size_t ns = impl_->slabs.size();
+  if (impl_->peer_copy_halo) {
+    for (size_t s = 0; s < ns; ++s)
+      if (vcy_halo_copy_from(impl_->slabs[s], s ? impl_->slabs[s - 1] : nullptr) != VCY_OK) {
+        LOGE("%s\n", vcy_last_error());
+        return false;
+      }
+  } else if (vcy_halo_allgather(impl_->slabs.data(), static_cast<int>(ns)) != VCY_OK) {
+    LOGE("%s\n", vcy_last_error());
+    return false;
+  }
+  return true;
+}
+
+void ShardedVoxelCarver::ExtractVoxel(Mesh* mesh, bool inside_empty) {
+  mesh->Clear();
+  const size_t ns = impl_->slabs.size();
+  if (ns == 0) return;
+  // UpdateOnSurface (extract_voxel.cc:15-79) compares a voxel with its -z neighbour: the slice below a slab
+  if (inside_empty && !ExchangeHalo()) return;
+  std::vector<int64_t*> ids(ns, nullptr);
+  std::vector<int64_t> counts(ns, 0);
+  std::vector<std::string> errors(ns);
+  std::vector<std::future<int>> jobs;
+  for (size_t s = 0; s < ns; ++s)
+    jobs.push_back(std::async(std::launch::async, [this, s, inside_empty, &ids, &counts, &errors]() {
+      const int rc = vcy_extract_voxel_ids(impl_->slabs[s], inside_empty ? 1 : 0, &ids[s], &counts[s]);
+      if (rc != VCY_OK) errors[s] = vcy_last_error();
+      return rc;
+    }));
+  bool ok = true;
+  for (auto& j : jobs) ok = (j.get() == VCY_OK) && ok;
+  for (const std::string& e : errors)
+    if (!e.empty()) LOGE("sharded ExtractVoxel failed: %s\n", e.c_str());
+  if (ok) {
+    // the kept voxels of the whole grid in scan order = the slabs' lists in z order; ONE cube drifts through them
+    std::vector<int64_t> all;
+    for (size_t s = 0; s < ns; ++s) all.insert(all.end(), ids[s], ids[s] + counts[s]);
+    const vcy_carver_option c = ToC(impl_->option);
+    vcy_mesh m;
+    if (vcy_voxel_cubes(&c, static_cast<int64_t>(all.size()), all.data(), &m) == VCY_OK) {
+      std::vector<Eigen::Vector3f>* V = mesh->mutable_vertices();
+      std::vector<Eigen::Vector3i>* F = mesh->mutable_vertex_indices();
+      V->resize(static_cast<size_t>(m.n_vertices));
+      F->resize(static_cast<size_t>(m.n_faces));
+      if (m.n_vertices) std::memcpy(static_cast<void*>(V->data()), m.vertices, sizeof(float) * 3 * m.n_vertices);
+      if (m.n_faces) std::memcpy(static_cast<void*>(F->data()), m.faces, sizeof(int) * 3 * m.n_faces);
+    } else {
+      LOGE("%s\n", vcy_last_error());
+    }
+    vcy_mesh_free(&m);
+  }
+  for (int64_t* p : ids) vcy_ids_free(p);
+}
+
 void ShardedVoxelCarver::ExtractIsoSurface(Mesh* mesh, double iso_level, bool linear_interp) {
   mesh->Clear();
   const size_t ns = impl_->slabs.size();
   if (ns == 0) return;
-  // the two slices below every slab: ONE RCCL all-gather over the devices that hold slabs
-  // (vcy_halo_allgather); peer-to-peer copies only when asked for (set_halo_transport)
-  if (impl_->peer_copy_halo) {
-    for (size_t s = 1; s < ns; ++s)
-      if (vcy_halo_copy_from(impl_->slabs[s], impl_->slabs[s - 1]) != VCY_OK) {
-        LOGE("%s\n", vcy_last_error());
-        return;
-      }
-  } else if (vcy_halo_allgather(impl_->slabs.data(), static_cast<int>(ns)) != VCY_OK) {
-    LOGE("%s\n", vcy_last_error());
-    return;
-  }
+  if (!ExchangeHalo()) return;
   std::vector<vcy_mesh> parts(ns);
   std::vector<std::string> errors(ns);
   std::vector<std::future<int>> jobs;

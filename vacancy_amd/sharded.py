@@ -236,3 +236,21 @@ class ShardedVoxelCarver:
 
     def ExtractIsoSurface(self, iso_level=0.0, linear_interp=True):
         return vdist.merge_meshes(self.extract_slabs(iso_level, linear_interp))
+
+    # -- ExtractVoxel (voxel_carver.cc:530-538, extract_voxel.cc:258-317): the keep predicate and the compaction run on
+    # every slab's device (the on-surface test reads the slice below a slab from its halo), the kept ids are walked in z
+    # order by ONE drifting cube on the host, exactly the reference's arithmetic (vcy_voxel_cubes)
+    def ExtractVoxel(self, inside_empty=False):
+        if inside_empty:
+            self.exchange_halo()
+        ids = [None] * len(self.slabs)
+        index = {id(c): s for s, c in enumerate(self.slabs)}
+
+        def run(i, cs):
+            for c in cs:
+                ids[index[id(c)]] = c.extract_voxel_ids(inside_empty)
+
+        self._per_device(run)
+        import numpy as np
+        from . import carver as _vc
+        return _vc.voxel_cubes(self.option, np.concatenate(ids) if ids else np.zeros(0, np.int64))
