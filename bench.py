@@ -81,6 +81,10 @@ def parse(argv=None):
                     help="which of the extra measurements to run, comma separated: modes (cull0, tsdf), scenes (hard_scene, "
                          "two_batches), per_view (the reference's one-view-per-call loops), streamed (silhouettes from host "
                          "memory); default all")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="one GPU, headline workload: do not append the `configs` block (BASELINE.json's other single-GPU "
+                         "configurations -- configs[0] bunny sequence, configs[1] 512^3 x 16 TSDF, the configs[4] shape 2048^3 x 64 "
+                         "-- measured after the timed region; also skipped with --no-variants)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--allow-gloo", action="store_true",
                     help="let the halo exchange fall back to gloo (host staging) when RCCL cannot initialise; "
@@ -195,10 +199,10 @@ def cpu_baseline(args, views, sdfs, budget_s):
         "single_thread_value": single,
         "sample": "%soracle (OpenMP over z, %d threads = usable host cores of %d visible) on a %d^3 grid over the "
                   "same scene (the rate per voxel*view is what is reported; the %d^3 AoS grid of the reference "
-                  "needs 43 GB), %d of %d views at %dx%d; times the Carve main loop only (reference "
+                  "needs %.1f GB), %d of %d views at %dx%d; times the Carve main loop only (reference "
                   "voxel_carver.cc:435,492)"
                   % ("EXTRAPOLATED from a smaller grid: " if extrapolated else "", threads, os.cpu_count() or 1,
-                     n_cpu, args.grid, n_done, len(views), args.width, args.height),
+                     n_cpu, args.grid, 40.0 * float(args.grid) ** 3 / 1e9, n_done, len(views), args.width, args.height),
         "mc_mcells_per_s": round(cells / mc_s / 1e6, 2),
         "mc_sample": "oracle MarchingCubes (serial std::map, like the reference) on the carved %d^3 grid" % n_cpu,
     }
@@ -296,6 +300,170 @@ def compare_meshes(merged, ref):
             "single_context_faces": int(len(ref["faces"])),
             "note": "slab meshes merged by edge key (vacancy_amd.dist.merge_meshes) against one context holding the whole "
                     "grid on rank 0's device: vertex bits, faces and edge keys, array for array"}
+
+
+def bytes_per_voxel_view(mode, nv, uo):
+    """fp32 sdf, plus update_num in the weighted-average modes -- one byte while at most 255 views have
+    been applied since the fill (the library widens the counters lazily, vcy_set_param "lazycount"), else two."""
+    return 4.0 if mode == "default" else 4.0 + (1 if min(nv, uo.voxel_max_update_num + 1) <= 255 else 2)
+
+
+def side_config(device, build, label, n, nv, w, h, mode, steps, warmup=1, settle_ms=40.0, mc_runs=3):
+    """One of BASELINE.json's OTHER single-GPU configurations, measured in the same process after the headline's timed
+    region (so that the driver's record holds a number for each): the same step -- reset + fused carve of nv resident SDF
+    images -- `steps` times queued back to back between two device syncs, then marching cubes.  A compact record: value,
+    ms_per_step, roofline {frac (SURVEY 8d's algorithmic bytes / the carve kernel's own duration), traffic and bound
+    from the committed counters of this shape or null}, mc {device_ms, wall_ms}."""
+    from vacancy_amd import carver as vc
+    from vacancy_amd import synth
+    from vacancy_amd.capi import UpdateOption
+    t_begin = time.perf_counter()
+    uo = UpdateOption(voxel_update=1, use_truncation=True, truncation_band=0.1) if mode == "tsdf" else UpdateOption()
+    views, masks = synth.sphere_views(n, nv, w, h)
+    sdf0 = vc.make_sdf(masks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
+    c = vc.VoxelCarver(synth.sphere_option(n, uo), device_id=device)
+    if not c.Init():
+        return {"label": label, "error": "vcy_create failed: " + vc.last_error()}
+    img = None
+    try:
+        c.set_param("carvetimer", 1)
+        c.set_param("meshkeys", 0)
+        img = c.upload_sdf(sdf0)
+        batch = vc.VoxelCarver.prepare_batch(views, [img] * nv)
+
+        def run(count):
+            c.sync()
+            t = time.perf_counter()
+            for _ in range(count):
+                c.reset()
+                if not c.CarveBatchDevice(batch):
+                    raise RuntimeError("carve failed: " + vc.last_error())
+            c.sync()
+            return (time.perf_counter() - t) * 1e3
+
+        busy = run(max(1, warmup))
+        ran = max(1, warmup)
+        if busy < settle_ms:  # clocks (see the module docstring); the device has just run the headline, so less is needed
+            extra = int(math.ceil((settle_ms - busy) / (busy / ran)))
+            busy += run(extra)
+            ran += extra
+        c.set_param("carvetimer", 1)  # clears the event log
+        wall = run(steps)
+        log = c.carve_log()
+        pre = sum(r[1] for r in log) / steps
+        ker = sum(r[2] for r in log) / steps
+        launches = len(log) / float(steps)
+        bpv = bytes_per_voxel_view(mode, nv, uo)
+        vv = float(n) ** 3 * nv
+        achieved = vv * bpv / (ker * 1e-3) / 1e9  # all launches of a step together: the same ratio as per launch
+        ctr, why = load_counters("%s_%d_%d_b1_c1" % (mode, n, nv), build)
+        roof = {"bound": "valu" if ctr and "SQ_INSTS_VALU" in ctr else None, "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": ctr.get("hbm_bytes_per_launch") if ctr else None,
+                "kernel": "carve_fused_kernel", "kernel_ms_per_step": round(ker, 4),
+                "prepass_ms_per_step": round(pre, 4), "kernel_launches_per_step": round(launches, 2),
+                "algorithmic_bytes_per_voxel_view": bpv}
+        if ctr:
+            t_k = ctr.get("trace_avg_ns", 0.0) * 1e-9
+            if roof["traffic"] and t_k > 0:
+                roof["hbm_real_frac"] = round(roof["traffic"] / t_k / 1e9 / HBM_PEAK_GBS, 4)
+                roof["traffic_note"] = "per launch of the profiled run (%s launches per step there)" % ctr.get("trace_calls_per_step", "?")
+            vcyc = valu_issue_cycles(ctr)
+            clk = ctr.get("shader_clock_hz") or CLOCK_HZ
+            if vcyc and t_k > 0:
+                roof["valu_issue_frac_flat2"] = round(vcyc / (N_SIMD * clk * t_k), 4)
+            roof["counters_source"] = ctr.get("source")
+        else:
+            roof["counters_note"] = why
+            roof["bound_note"] = ("no counters of this build at this shape: `bound` is left null; the same kernel at 1024^3 is "
+                                  "bound by VALU issue (the headline's roofline block), frac is the algorithmic figure")
+        rec = {"label": label, "workload": "%d^3 grid x %d views at %dx%d, %s mode, 1 GPU" % (n, nv, w, h, mode),
+               "value": round(vv * steps / (wall * 1e-3) / 1e6, 1), "unit": "Mvoxel*views/s", "steps": steps,
+               "warmup_steps_run": ran, "ms_per_step": round(wall / steps, 3), "roofline": roof}
+        try:
+            c.ExtractIsoSurface(0.0, True)  # allocates
+            runs = sorted((m["wall_ms"], m["device_ms"], len(m["vertices"]), len(m["faces"]))
+                          for m in (c.ExtractIsoSurface(0.0, True) for _ in range(mc_runs)))
+            wl, dv, nvert, nface = runs[len(runs) // 2]
+            cells = float(n - 1) ** 3
+            rec["mc"] = {"device_ms": round(dv, 3), "wall_ms": round(wl, 3),
+                         "mcells_per_s": round(cells / (dv * 1e-3) / 1e6, 1),
+                         "mcells_per_s_wall": round(cells / (wl * 1e-3) / 1e6, 1),
+                         "roofline_frac": round(cells * 4.0 / (dv * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "vertices": int(nvert), "faces": int(nface)}
+        except Exception as e:
+            rec["mc"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        rec["wall_s_spent"] = round(time.perf_counter() - t_begin, 2)
+        return rec
+    except Exception as e:
+        return {"label": label, "error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        if img is not None:
+            c.free_device(img)
+        c.close()
+
+
+def bunny_sequence(device, resolution=2.5, reps=2):
+    """BASELINE configs[0] on the GPU: the reference's examples.cc:117-149 sequence on the data/ bunny fixture
+    (tests/golden/bunny: 6 masks 320x240 + tumpose.txt) -- per view Carve(camera, silhouette) (SDF built on the device),
+    ExtractVoxel, MarchingCubes with and without interpolation -- at `resolution` (examples.cc runs 10.0; 2.5 gives a
+    216 x 212 x 168 grid).  Wall clock of the calls from pageable host inputs to meshes in host memory."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bunny_data as B
+    from vacancy_amd import carver as vc
+    from vacancy_amd import synth
+    t_begin = time.perf_counter()
+    views = B.bunny_views(lambda t, q: synth.affine_inverse(synth.pose_from_tum(t, q)))
+    masks = B.load_masks()
+    c = vc.VoxelCarver(B.bunny_option(resolution), device_id=device)
+    if not c.Init():
+        return {"label": "configs[0]", "error": "vcy_create failed: " + vc.last_error()}
+    try:
+        c.set_param("meshkeys", 0)
+        best = None
+        for rep in range(reps + 1):  # the first pass allocates; the fastest of the others is reported
+            c.reset()
+            c.sync()
+            carve = xv = mc = mc_dev = 0.0
+            t_seq = time.perf_counter()
+            for view, mask in zip(views, masks):
+                t0 = time.perf_counter()
+                if not c.CarveSilhouette(view, mask):
+                    raise RuntimeError(vc.last_error())
+                c.sync()  # (queued views are applied here: the carve is timed by itself)
+                t1 = time.perf_counter()
+                vox = c.ExtractVoxel(False)
+                t2 = time.perf_counter()
+                m1 = c.ExtractIsoSurface(0.0, True)
+                m2 = c.ExtractIsoSurface(0.0, False)
+                t3 = time.perf_counter()
+                carve, xv, mc = carve + (t1 - t0), xv + (t2 - t1), mc + (t3 - t2)
+                mc_dev += m1["device_ms"] + m2["device_ms"]
+            seq = time.perf_counter() - t_seq
+            rec = (seq, carve, xv, mc, mc_dev, len(m1["vertices"]), len(m1["faces"]), len(vox["vertices"]))
+            if rep > 0 and (best is None or rec[0] < best[0]):
+                best = rec
+        seq, carve, xv, mc, mc_dev, nvert, nface, nvox = best
+        nvox_grid = c.dims[0] * c.dims[1] * c.dims[2]
+        cells = float(c.dims[0] - 1) * (c.dims[1] - 1) * (c.dims[2] - 1)
+        return {"label": "configs[0]",
+                "workload": "data/ bunny, 6 masks 320x240, resolution %g (%d x %d x %d voxels), examples.cc sequence per view: "
+                            "Carve(silhouette) + ExtractVoxel + 2 x MarchingCubes" % ((resolution,) + tuple(c.dims)),
+                "value": round(nvox_grid * len(views) / carve / 1e6, 1), "unit": "Mvoxel*views/s",
+                "value_note": "voxels x views / wall time of the 6 Carve(silhouette) calls (mask upload + SDF build + carve, "
+                              "one launch per view, each followed by a sync)",
+                "sequence_wall_ms": round(seq * 1e3, 3), "carve_wall_ms": round(carve * 1e3, 3),
+                "extract_voxel_wall_ms": round(xv * 1e3, 3), "mc_wall_ms": round(mc * 1e3, 3),
+                "mc": {"extractions": 2 * len(views), "wall_ms": round(mc * 1e3 / (2 * len(views)), 3),
+                       "device_ms": round(mc_dev / (2 * len(views)), 3),
+                       "mcells_per_s_wall": round(cells * 2 * len(views) / mc / 1e6, 1)},
+                "final_mesh": {"vertices": int(nvert), "faces": int(nface), "voxel_mesh_vertices": int(nvox)},
+                "roofline": None, "roofline_note": "a 7.7 M voxel grid: every call is launch latency, not bandwidth",
+                "wall_s_spent": round(time.perf_counter() - t_begin, 2)}
+    except Exception as e:
+        return {"label": "configs[0]", "error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        c.close()
 
 
 def run_inprocess(args, why=None):
@@ -697,9 +865,7 @@ def main():
     # roofline of the dominant kernel (carve), this rank's slab: algorithmic bytes per launch /
     # launch duration from HIP events on the launch stream.
     def bytes_per_vv(mode, u):
-        # fp32 sdf, plus update_num in the weighted-average modes -- one byte while at most 255 views have
-        # been applied since the fill (the library widens the counters lazily, vcy_set_param "lazycount"), else two
-        return 4.0 if mode == "default" else 4.0 + (1 if min(nv, u.voxel_max_update_num + 1) <= 255 else 2)
+        return bytes_per_voxel_view(mode, nv, u)
 
     slab_vox = sum(c.slab_voxels for c in devs) / float(len(devs))  # per launch
     FUSED_MAX = 64  # views per fused launch (carve_fused.hip)
@@ -735,6 +901,9 @@ def main():
                         "its tile loads and stores, for the variants whose control flow does not depend on the data)"}
     if ctr is None:
         roofline["counters_note"] = ctr_note
+        roofline["bound_note"] = ("`bound` is the contract's label for the algorithmic figures; no counters of this build were "
+                                  "collected at this shape, so what binds the kernel here is not established (at 1024^3 x 32 it is "
+                                  "VALU issue, not HBM)")
     # the roofs that actually bind the kernel: real HBM traffic and VALU issue slots (counters of the
     # committed PMC passes for this workload, duration measured live above)
     if traffic:
@@ -1149,6 +1318,21 @@ def main():
             out["collective"]["launch"] = "one process per GPU (torch.distributed, backend %s)" % backend
     if variants is not None:
         out["variants"] = variants
+    # BASELINE.json's other single-GPU configurations in the same line (the driver only runs `bench.py --gpus 1`):
+    # configs[0] the bunny sequence of examples.cc, configs[1] 512^3 x 16 TSDF, and the configs[4] shape 2048^3 x 64 on
+    # this one GPU.  After the timed region and the variants, each on contexts of its own; < 60 s together.
+    headline = (n, nv, args.width, args.height, args.mode, args.cull) == (1024, 32, 1280, 720, "default", 1)
+    if rank == 0 and world == 1 and args.batch and headline and not (args.no_configs or args.no_variants):
+        t_cfg = time.perf_counter()
+        out["configs"] = {
+            "note": "BASELINE.json configs other than the headline (configs[2]; configs[3] is the same grid with --gpus N), "
+                    "measured after the timed region on contexts of their own; `value` of this line is the headline's only",
+            "configs[0]": bunny_sequence(local_rank),
+            "configs[1]": side_config(local_rank, build, "configs[1]", 512, 16, 640, 480, "tsdf", steps=20, warmup=3),
+            "configs[4] shape on one GPU": side_config(local_rank, build, "configs[4] on 1 of its 8 GPUs' worth of hardware",
+                                                        2048, 64, 1920, 1080, "default", steps=3, warmup=1, settle_ms=0.0),
+        }
+        out["configs"]["wall_s_spent"] = round(time.perf_counter() - t_cfg, 2)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, views, sdfs, args.cpu_seconds)
     if rank == 0:
