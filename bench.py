@@ -63,8 +63,9 @@ def parse(argv=None):
     ap.add_argument("--cull", type=int, default=1,
                     help="1: drop (brick, view) pairs that provably cannot change the brick (results identical)")
     ap.add_argument("--prologue", type=int, default=0, choices=[0, 1, 2],
-                    help="where a fused launch gets its footprints (vcy_set_param \"prologue\"): 0 = pre-pass records while "
-                         "they fit 2 GiB, else in the carve kernel's prologue; 1 = always the prologue; 2 = always records")
+                    help="where a fused launch gets its footprints (vcy_set_param \"prologue\"): 0 or 2 = pre-pass records "
+                         "(chunks of at most 2 GiB); 1 = in the carve kernel's prologue (measured slower: 92.8 against 81.8 ms "
+                         "at 2048^3 x 64)")
     ap.add_argument("--slabs-per-gpu", type=int, default=0,
                     help="z-slabs per GPU, dealt cyclically (0 = 1: one slab per GPU, cut by predicted cost)")
     ap.add_argument("--partition", default="planned", choices=["planned", "equal"],

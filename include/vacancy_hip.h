@@ -332,12 +332,12 @@ int vcy_reset(vcy_ctx* ctx);
  * bricks through LDS and store whole 128-byte row segments; 0: every wave stores its own 16-byte pieces; -1: the first
  * for single-view launches (over a carved grid in the weighted-average modes: up to 8 views), the second otherwise.
  * Results are identical.
- * "recordbytes" (default 0 = 2 GiB): bytes of footprint records one carve launch may take.  With the default, a launch
- * whose records would be larger computes its footprints in the carve kernel's prologue instead (2048^3 x 64 views: 8.6 GB
- * of records and nine chunks in round 4, one launch now); with an explicit value a larger launch is cut into chunks of
- * whole brick layers -- small values let tests run the chunking on small grids.
- * "prologue" (default 0): where a raw-tile launch gets its footprints: 0 = from the pre-pass's records while they fit
- * "recordbytes", else in the carve kernel's prologue; 1 = always in the prologue; 2 = always records.  Results identical.
+ * "recordbytes" (default 0 = 2 GiB): bytes of footprint records one carve launch may take; a launch whose records would
+ * be larger is cut into chunks of whole brick layers (2048^3 x 64 views: 8.6 GB of records, four chunks) -- small values
+ * let tests run the chunking on small grids.
+ * "prologue" (default 0): where a raw-tile launch gets its footprints: 0 or 2 = from the pre-pass's records; 1 = computed
+ * in the carve kernel's prologue, one lane per view (one launch whatever the size, and slower: 92.8 against 81.8 ms per
+ * step at 2048^3 x 64 views).  Results identical.
  * "carvetimer" (default 0): 1 records HIP events around what runs before the carve kernel (window maxima, pre-pass)
  * and around the carve kernel of every fused launch (vcy_last_carve_ms, vcy_carve_log); setting it clears the log.
  * "lazycount" (default 1): update_num is stored in one byte until more than 255 views have been applied since the fill

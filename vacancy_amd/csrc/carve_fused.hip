@@ -2067,15 +2067,16 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   // below kRecordBytesMax (1024^3 x 32 views: 0.5 GiB, one chunk; 2048^3 x 64: nine).
   const int64_t layer_bricks = (int64_t)nbw * nby;
   int chunk_layers = nbz;
-  // Footprints from the pre-pass (records) or from the carve kernel's own prologue?  The pre-pass pays for launches of
-  // few views (its threads are all busy where the prologue would use nviews lanes of 64, and the records are what the
-  // live list and the early return read); for a launch whose records would exceed the cap -- 2048^3 x 64 views: 8.6 GB,
-  // written and read back in nine chunks, 9.4 of the step's 81.7 ms -- the prologue computes them in place, one lane
-  // per view, in ONE launch.  "prologue": 0 that rule, 1 always in the kernel, 2 always records (chunked as before).
+  // Footprints from the pre-pass (records) or from the carve kernel's own prologue?  The pre-pass: its threads are all
+  // busy where the prologue would use nviews lanes of 64, it runs at full occupancy, and the records are what the live
+  // list and the early return read.  Round 5 tried the prologue for the one launch whose records are large -- 2048^3 x 64
+  // views: 8.6 GB of them, written and read back in chunks, 9.1 of the step's 81.8 ms; every lane of the prologue has a
+  // view there and the step becomes ONE launch -- and measured 92.8 ms: the footprints cost 20 ms in the kernel (two
+  // dependent round trips in front of every wave, at the carve kernel's occupancy) against 9 in the pre-pass
+  // (profiles/r05/bench_2048x64_config4_*.json).  So: "prologue" 0 or 2 records (chunks of at most kRecordBytesMax: four
+  // at that shape), 1 in the kernel.
   const int64_t rec_cap = c->record_bytes_max > 0 ? c->record_bytes_max : kRecordBytesMax;  // ("recordbytes": tests force several chunks)
-  const bool in_kernel_prologue =
-      !big && (c->prologue_mode == 1 ||
-               (c->prologue_mode == 0 && c->record_bytes_max == 0 && layer_bricks * nbz * n_views * (int64_t)sizeof(FootprintRecord) > rec_cap));
+  const bool in_kernel_prologue = !big && c->prologue_mode == 1;
   if (!big && !in_kernel_prologue) {
     const int64_t per_layer = layer_bricks * n_views * (int64_t)sizeof(FootprintRecord);
     const int64_t cap = rec_cap;

@@ -552,13 +552,18 @@ __global__ __launch_bounds__(256) void mc_active_kernel(McParams p, u64* __restr
                                                         uint32_t* __restrict__ word_cell_off,
                                                         u64* __restrict__ block_cells, int64_t nblocks) {
   __shared__ int sm[kActiveBlocks][4];
-  // XCD-aware order (workgroup b runs on XCD b % 8): consecutive word blocks -- which share their
-  // boundary rows and, one layer later, the rows of slice z-1 -- stay on one XCD's L2
+  // Plain order.  (Rounds 2-4 gave every XCD -- workgroup b runs on XCD b % 8 -- a contiguous eighth of the blocks, so
+  // that the plane rows consecutive blocks and, one layer later, consecutive layers share stay in one L2.  Measured
+  // against plain order in round 5: 136 against 131.5 us at 1024^3, 16.7 against 15.5 at 512^3, and mc_compact behind it
+  // 45.8 against 41.3 -- the planes are 1 bit per voxel and every XCD's L2 holds the rows of its neighbours anyway;
+  // profiles/r05/mc_lookback.txt.  VCY_ACTIVE_XCD_EIGHTHS restores the old order.)
   int64_t lg = blockIdx.x;
+#ifdef VCY_ACTIVE_XCD_EIGHTHS
   {
     const int64_t per = gridDim.x >> 3;
     if (lg < per * 8) lg = (lg & 7) * per + (lg >> 3);
   }
+#endif
   CellWord c[kActiveBlocks];
   CellRows r[kActiveBlocks];
   int w[kActiveBlocks];

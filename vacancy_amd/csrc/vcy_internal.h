@@ -131,7 +131,7 @@ struct vcy_ctx {
   unsigned long long* d_pair_count = nullptr;  // ... per brick layer of the slab, of the last fused launch (vcy_last_carve_pairs)
   int pair_count_layers = 0, pair_count_views = 0;
   int64_t record_bytes_max = 0;       // vcy_set_param("recordbytes", n): footprint records per launch chunk (0: 2 GiB)
-  int prologue_mode = 0;              // vcy_set_param("prologue"): 0 records while they fit the cap, else footprints in the carve kernel's prologue; 1 always the prologue; 2 always records
+  int prologue_mode = 0;              // vcy_set_param("prologue"): 0 / 2 footprint records from the pre-pass (chunked); 1 footprints in the carve kernel's prologue (slower at every shape measured)
   void* d_records = nullptr;          // footprint records of one fused launch, 8 bytes per (wave brick, view)
   size_t records_bytes = 0;
   float* d_wmax = nullptr;            // window-maximum planes of the views of one fused launch
