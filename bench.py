@@ -325,12 +325,12 @@ def side_config(device, build, label, n, nv, w, h, mode, steps, warmup=1, settle
     c = vc.VoxelCarver(synth.sphere_option(n, uo), device_id=device)
     if not c.Init():
         return {"label": label, "error": "vcy_create failed: " + vc.last_error()}
-    img = None
+    imgs = []
     try:
         c.set_param("carvetimer", 1)
         c.set_param("meshkeys", 0)
-        img = c.upload_sdf(sdf0)
-        batch = vc.VoxelCarver.prepare_batch(views, [img] * nv)
+        imgs = [c.upload_sdf(sdf0) for _ in range(nv)]  # an image per view, as in the headline step (each gets its window planes)
+        batch = vc.VoxelCarver.prepare_batch(views, imgs)
 
         def run(count):
             c.sync()
@@ -399,7 +399,7 @@ def side_config(device, build, label, n, nv, w, h, mode, steps, warmup=1, settle
     except Exception as e:
         return {"label": label, "error": "%s: %s" % (type(e).__name__, e)}
     finally:
-        if img is not None:
+        for img in imgs:
             c.free_device(img)
         c.close()
 
@@ -408,7 +408,7 @@ def bunny_sequence(device, resolution=2.5, reps=2):
     """BASELINE configs[0] on the GPU: the reference's examples.cc:117-149 sequence on the data/ bunny fixture
     (tests/golden/bunny: 6 masks 320x240 + tumpose.txt) -- per view Carve(camera, silhouette) (SDF built on the device),
     ExtractVoxel, MarchingCubes with and without interpolation -- at `resolution` (examples.cc runs 10.0; 2.5 gives a
-    216 x 212 x 168 grid).  Wall clock of the calls from pageable host inputs to meshes in host memory."""
+    216 x 214 x 170 grid).  Wall clock of the calls from pageable host inputs to meshes in host memory."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import bunny_data as B
     from vacancy_amd import carver as vc
@@ -433,7 +433,7 @@ def bunny_sequence(device, resolution=2.5, reps=2):
                     raise RuntimeError(vc.last_error())
                 c.sync()  # (queued views are applied here: the carve is timed by itself)
                 t1 = time.perf_counter()
-                vox = c.ExtractVoxel(False)
+                vox = c.ExtractVoxel(False, arrays=False)  # (the library call; not numpy's copy of the mesh arrays)
                 t2 = time.perf_counter()
                 m1 = c.ExtractIsoSurface(0.0, True)
                 m2 = c.ExtractIsoSurface(0.0, False)
@@ -441,7 +441,7 @@ def bunny_sequence(device, resolution=2.5, reps=2):
                 carve, xv, mc = carve + (t1 - t0), xv + (t2 - t1), mc + (t3 - t2)
                 mc_dev += m1["device_ms"] + m2["device_ms"]
             seq = time.perf_counter() - t_seq
-            rec = (seq, carve, xv, mc, mc_dev, len(m1["vertices"]), len(m1["faces"]), len(vox["vertices"]))
+            rec = (seq, carve, xv, mc, mc_dev, len(m1["vertices"]), len(m1["faces"]), vox["n_vertices"])
             if rep > 0 and (best is None or rec[0] < best[0]):
                 best = rec
         seq, carve, xv, mc, mc_dev, nvert, nface, nvox = best

@@ -295,3 +295,32 @@ def test_voxel_cubes_without_a_gpu_equals_the_oracle():
     assert len(empty["vertices"]) == 0 and len(empty["faces"]) == 0
     with pytest.raises(RuntimeError):
         carver.voxel_cubes(opt, np.array([g.n], np.int64))  # outside the grid
+    # a list long enough for the threaded fill (>= 65536 kept voxels: the chain is walked serially, the 24 vertices and 12
+    # triangles of every voxel are written by host threads), ascending as a scan leaves it and in an order no scan
+    # produces (the row of a voxel is then found by division): every voxel of the resolution-5 grid kept
+    opt5 = B.bunny_option(5.0)
+    g5 = O.OracleGrid(opt5)
+    rng = np.random.RandomState(7)
+    g5.upload(-rng.rand(g5.n).astype(np.float32), np.ones(g5.n, np.int32))
+    want5 = g5.extract_voxel(False)
+    got5 = carver.voxel_cubes(opt5, np.arange(g5.n, dtype=np.int64))
+    assert g5.n >= 65536 and len(got5["vertices"]) == 24 * g5.n
+    assert np.array_equal(got5["faces"], want5["faces"])
+    assert np.array_equal(got5["vertices"].view(np.uint32), want5["vertices"].view(np.uint32))
+    perm = rng.permutation(g5.n)[:70000].astype(np.int64)
+    one_by_one = carver.voxel_cubes(opt5, perm)
+    # (the same chain on one thread: a list below the threading threshold cannot be compared, so compare with numpy's
+    # restatement of the six running values)
+    h = np.float32(5.0) / np.float32(2)
+    pos = g5.positions()[perm]
+    lo, hi = np.full(3, -h, np.float32), np.full(3, h, np.float32)
+    for t in (0, 1, 69999):
+        lo_t, hi_t = lo.copy(), hi.copy()
+        if t:
+            lo_t, hi_t = np.full(3, -h, np.float32), np.full(3, h, np.float32)
+            for q in range(t):
+                lo_t = (lo_t + pos[q]) + -pos[q]
+                hi_t = (hi_t + pos[q]) + -pos[q]
+        v = one_by_one["vertices"][24 * t:24 * t + 24]
+        assert np.array_equal(np.unique(v[:, 0]), np.unique(np.array([lo_t[0] + pos[t][0], hi_t[0] + pos[t][0]], np.float32)))
+        assert np.array_equal(np.unique(v[:, 2]), np.unique(np.array([lo_t[2] + pos[t][2], hi_t[2] + pos[t][2]], np.float32)))

@@ -198,13 +198,17 @@ class VoxelCarver:
         return out
 
     # -- ExtractVoxel(mesh, inside_empty)  (voxel_carver.cc:530-538)
-    def ExtractVoxel(self, inside_empty=False):
+    def ExtractVoxel(self, inside_empty=False, arrays=True):
+        """arrays=False: only the sizes (bench.py times the library call, not numpy's copy of an 800 MB mesh)."""
         m = Mesh()
         rc = self._lib.vcy_extract_voxel(self._ctx, int(inside_empty), C.byref(m))
         if rc != 0:
             self._lib.vcy_mesh_free(C.byref(m))
             raise RuntimeError(last_error())
         nv, nf = m.n_vertices, m.n_faces
+        if not arrays:
+            self._lib.vcy_mesh_free(C.byref(m))
+            return {"n_vertices": int(nv), "n_faces": int(nf)}
         out = {
             "vertices": _mesh_array(m.vertices, nv, 3, np.float32),
             "faces": _mesh_array(m.faces, nf, 3, np.int32),
