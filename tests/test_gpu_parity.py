@@ -2,6 +2,7 @@
 against the CPU oracle on the same inputs.  Bit-exact: sdf bits, update_num, marching-cubes
 vertex array, face array and edge keys (including their ORDER, which equals the reference's
 serial scan)."""
+import time
 import numpy as np
 import pytest
 
@@ -1438,3 +1439,21 @@ def test_extract_voxel_over_z_slabs(world):
         lone.extract_voxel_ids(True)
     with pytest.raises(RuntimeError):
         lone.ExtractVoxel(False)  # (the single-context call still refuses a slab)
+
+
+@pytest.mark.gpu
+def test_clock_probe_runs_beside_other_work():
+    """vcy_clock_probe_*: one wave samples the shader clock counter against the 100 MHz reference while other kernels run
+    (bench.py prices the carve kernel's VALU issue cycles at the clock of the timed run with it)."""
+    probe = vc.ClockProbe(0)
+    rd, cp = vc.measure_bandwidth(0, 1 << 28, 2)   # work on other streams while the probe wave is resident
+    assert rd > 0 and cp > 0
+    r = probe.stop()
+    assert r["samples"] >= 2 and r["covered_ms"] > 0.0
+    assert 0.3e9 < r["mean_hz"] < 3.5e9, r          # MI355X: 2.4 GHz peak shader clock
+    assert r["min_hz"] <= r["mean_hz"] * 1.01 and r["max_hz"] >= r["mean_hz"] * 0.99
+    assert probe.stop() == r                         # idempotent
+    # a probe that fills its buffer ends by itself
+    short = vc.ClockProbe(0, max_samples=4)
+    time.sleep(0.01)
+    assert short.stop()["samples"] == 4

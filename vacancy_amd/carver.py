@@ -440,6 +440,36 @@ def halo_exchange(carvers):
             "rccl_version": int(info.get("version", 0)), "slabs": len(carvers)}
 
 
+class ClockProbe:
+    """Shader clock of the device while other work runs on it (vcy_clock_probe_*): one wave on a stream of its own
+    samples the clock counter against the 100 MHz reference until stop().  `with ClockProbe(dev) as p: ...; p.result`."""
+
+    def __init__(self, device_id=0, max_samples=1 << 16):
+        self._lib = capi.load()
+        self._p = C.c_void_p()
+        self.result = None
+        if self._lib.vcy_clock_probe_start(int(device_id), int(max_samples), C.byref(self._p)) != 0:
+            raise RuntimeError("vcy_clock_probe_start: " + last_error())
+
+    def stop(self):
+        if self._p:
+            mean, lo, hi, cov, n = C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_int()
+            rc = self._lib.vcy_clock_probe_stop(self._p, C.byref(mean), C.byref(lo), C.byref(hi), C.byref(n), C.byref(cov))
+            self._p = C.c_void_p()
+            if rc != 0:
+                raise RuntimeError("vcy_clock_probe_stop: " + last_error())
+            self.result = {"mean_hz": mean.value, "min_hz": lo.value, "max_hz": hi.value, "samples": n.value,
+                           "covered_ms": cov.value}
+        return self.result
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.stop()
+        return False
+
+
 def measure_bandwidth(device_id=0, nbytes=1 << 31, reps=3):
     """(read GB/s, device-to-device copy GB/s) measured on this GPU (vcy_measure_bandwidth)."""
     lib = capi.load()
