@@ -1172,6 +1172,22 @@ def main():
             variants["two_batches"] = rate_record(ms, pre, ker, args.mode, uo, {
                 "batches": [half, nv - half],
                 "pairs_processed_frac": pairs_of(c0, [lambda c: c.CarveBatchDevice(ba), lambda c: c.CarveBatchDevice(bb)])})
+            # The timed step repeats ONE set of views, so the tables derived from the views (x tables, bounding boxes, the
+            # view records: host work + a 0.5 MB upload) come from the context's one-entry cache every step.  A sequence of NEW
+            # views per launch pays them: two sets -- the views, and the same views rotated by one position -- alternate here,
+            # so every launch misses the cache; same work on the device.
+            rot = views[1:] + views[:1]
+            bsets = [batch, vc.VoxelCarver.prepare_batch(rot, d_sdf[1:] + d_sdf[:1])]
+            flip = [0]
+
+            def alternating(c):
+                flip[0] ^= 1
+                return c.CarveBatchDevice(bsets[flip[0]])
+
+            ms, pre, ker = measure(cs, alternating, reps=6)
+            variants["new_views_every_step"] = rate_record(ms, pre, ker, args.mode, uo, {
+                "view_table_cache": "missed by every launch (two alternating view sets); the headline step hits it",
+                "ms_per_step_over_headline": round(ms - elapsed / args.steps * 1e3, 3)})
             for c in reversed(cs):
                 c.close()
         except StopIteration:

@@ -1012,8 +1012,14 @@ __global__ __launch_bounds__(256) void add_chunk_offsets_kernel(u64* __restrict_
 // The same in ONE launch (round 4; three launches before: chunks, their sums, the offsets added -- each a dependent
 // kernel boundary in the middle of an extraction made of short kernels): a workgroup scans its 1024 elements, publishes
 // its sum, and adds up the sums of the chunks before it, waiting for those that are not published yet.  A chunk only
-// ever waits for EARLIER chunks, which were dispatched before it and wait for nobody later: no deadlock whatever is
-// resident.  Publication is (sum, epoch): the epoch grows with every scan of a context, so the flags are never cleared.
+// ever waits for chunks with LOWER block indices, and every XCD's dispatcher starts its share of a grid (blocks
+// b = xcd mod 8) in increasing order: the lowest unfinished chunk of the grid is therefore always resident or next in
+// line on its XCD, whatever else occupies the device, it waits for nobody, and by induction every chunk gets there.
+// (Round 5 built the form that needs no assumption about dispatch order -- chunk numbers drawn as tickets from an
+// atomic counter -- for a single-pass prefix over the workgroups of mc_active / mc_owner: device-scope atomics on one
+// address retire at about one per 10 ns here, 0.33 ms for 32 768 workgroups; profiles/r05/mc_lookback.txt.  The grids
+// of this kernel are at most kChainedScanMaxChunks = 1024 blocks, fewer than the 2048 workgroups of this size the
+// device holds at once.)  Publication is (sum, epoch): the epoch grows with every scan of a context, so the flags are never cleared.
 // Every chunk reads all its predecessors -- quadratic, which is why this form is only taken up to kChainedScanMaxChunks
 // (1024^3: 64 chunks for the word blocks, about 10 for the surface cells).
 constexpr int kChainedScanMaxChunks = 1024;

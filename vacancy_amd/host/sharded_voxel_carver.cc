@@ -163,6 +163,10 @@ bool ShardedVoxelCarver::Init() {
       LOGE("%s\n", vcy_last_error());
       return false;
     }
+    // Several slabs are driven from one host thread here and in vcy_carve_batch_silhouettes_sharded: a launch of few
+    // views over a carved slab must not make that thread wait for the slab's live-workgroup count ("livesync" 1, worth
+    // 0.1 ms per launch on a whole 1024^3 grid) before it can enqueue the next slab's work.
+    if (count > 1) (void)vcy_set_param(ctx, "livesync", 0);
     impl_->slabs.push_back(ctx);
   }
   return true;

@@ -66,6 +66,10 @@ class ShardedVoxelCarver:
                 self.close()
                 return False
             # (every slab keeps its own stream: a device's second slab fills the tail of its first one's launch)
+            if self.k > 1 and hasattr(c, "set_param"):
+                # one host thread drives the k slabs of a device: it must not wait for one slab's live-workgroup count
+                # ("livesync" 1) before it can enqueue the next slab's launch
+                c.set_param("livesync", 0)
             self.slabs.append(c)
             self.by_device[s % g].append(c)
             self.z_ranges.append((z0, z1))
