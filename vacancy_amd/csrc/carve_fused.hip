@@ -228,6 +228,12 @@ __device__ __forceinline__ bool in_fast_div_range(float z) {
 }
 
 typedef const float __attribute__((address_space(1))) * gfloat_ptr;  // known-global loads
+// base[idx] for idx < 2^30 with the BYTE offset formed in 32 bits: where `base` is uniform the load then takes a scalar
+// base and one 32-bit vector offset (global_load_dword v, v, s[..]) instead of a 64-bit vector address
+__device__ __forceinline__ float load_u32_index(gfloat_ptr base, unsigned idx) {
+  typedef const char __attribute__((address_space(1))) * gchar_ptr;
+  return *(gfloat_ptr)((gchar_ptr)base + (idx << 2));
+}
 typedef const float __attribute__((address_space(4))) * cfloat_ptr;  // read-only: scalar loads
 
 // Generic sample for a voxel the staged tile does not cover (rare): global-memory taps and the
@@ -565,8 +571,7 @@ __device__ __forceinline__ TileInfo footprint_of(const FusedView& fv, float xl, 
     for (int i = 0; i < 3; ++i) pc[i] = (corner & 4) ? pxy[corner & 3][i] + az[i] : pxy[corner & 3][i];
     float u = pc[0], w = pc[1];
     if (!ortho) {
-      bad |= !in_fast_div_range(pc[2]);  // in front of the camera, reciprocal finite and normal
-      const float rz = __builtin_amdgcn_rcpf(pc[2]);
+      const float rz = __builtin_amdgcn_rcpf(pc[2]);  // (its operand range is checked on zmin / zmax below)
       u = __builtin_fmaf(fx * rz, pc[0], v.cx);
       w = __builtin_fmaf(fy * rz, pc[1], v.cy);
     }
@@ -577,6 +582,9 @@ __device__ __forceinline__ TileInfo footprint_of(const FusedView& fv, float xl, 
     zmin = fminf(zmin, pc[2]);
     zmax = fmaxf(zmax, pc[2]);
   }
+  // in front of the camera, reciprocals finite and normal: every corner depth inside div_fast's range -- tested on the
+  // smallest and the largest (a NaN depth would slip through fminf / fmaxf, but NaN / huge inputs end up in mag, next line)
+  if (!ortho) bad |= !in_fast_div_range(zmin) || !in_fast_div_range(zmax);
   // finite inputs (NaN / huge values anywhere end up in mag), image coordinates of sane size
   bad |= !(mag[0] < 0x1p60f) || !(mag[1] < 0x1p60f) || !(mag[2] < 0x1p60f);
   bad |= !(umin > -1.0e6f) || !(umax < 1.0e6f) || !(wmin > -1.0e6f) || !(wmax_ < 1.0e6f);
@@ -661,6 +669,11 @@ __device__ __forceinline__ TileInfo footprint_of(const FusedView& fv, float xl, 
         const int uy = __any(small && nyw >= 3) ? 3 : (__any(small && nyw >= 2) ? 2 : 1);
         if (wm != nullptr) {
           gfloat_ptr lvl = wm + (L == 3 ? (size_t)fv.wmax_plane : (size_t)0);
+          // (the 3 x 3 path indexes from `wm` itself with the plane folded into a 32-bit index: in the pre-pass the
+          // view is uniform, so the load takes a scalar base and one vector offset instead of a 64-bit vector address;
+          // images are at most 8192 x 8192 and there are four planes: < 2^28 elements.  Width and rows are below
+          // 2^24: full-rate 24-bit multiplies.)
+          const unsigned origin = __umul24((unsigned)v.width, (unsigned)ty0) + (unsigned)tx0 + (L == 3 ? (unsigned)fv.wmax_plane : 0u);
           if (nxw <= 3 && nyw <= 3) {
             // the usual case (footprints up to 24 pixels wide): as many lookups as the widest footprint among
             // the wave's views needs (uniform counts ux x uy, typically 2 x 2; narrower ones repeat their last
@@ -670,11 +683,11 @@ __device__ __forceinline__ TileInfo footprint_of(const FusedView& fv, float xl, 
             float t[9];
 #pragma unroll
             for (int bq = 0; bq < 3; ++bq) {
-              const unsigned ro = (unsigned)v.width * (unsigned)(ty0 + min(bq << L, max(ph - k, 0))) + (unsigned)tx0;
+              const unsigned ro = origin + __umul24((unsigned)v.width, (unsigned)min(bq << L, max(ph - k, 0)));
 #pragma unroll
               for (int aq = 0; aq < 3; ++aq) {
                 t[3 * bq + aq] = -INFINITY;
-                if (aq < ux && bq < uy) t[3 * bq + aq] = lvl[ro + (unsigned)min(aq << L, max(pw - k, 0))];
+                if (aq < ux && bq < uy) t[3 * bq + aq] = load_u32_index(wm, ro + (unsigned)min(aq << L, max(pw - k, 0)));
               }
             }
 #pragma unroll
@@ -709,15 +722,16 @@ __device__ __forceinline__ TileInfo footprint_of(const FusedView& fv, float xl, 
         // Voxels outside the ROI are not an issue: a `sure` tile has none.
         // (not looked up for a tile the upper bound already drops: `ub < -1`, the view is never processed)
         if (want_lower && ti.sure && !(ti.ub < -1.0f) && wm != nullptr && fv.has_lower && nxw <= 3 && nyw <= 3) {
-          gfloat_ptr lvl = wm + 2 * (size_t)fv.wmax_plane + (L == 3 ? (size_t)fv.wmax_plane : (size_t)0);
+          const unsigned origin = __umul24((unsigned)v.width, (unsigned)ty0) + (unsigned)tx0 +
+                                  (L == 3 ? 3u : 2u) * (unsigned)fv.wmax_plane;  // planes 2 / 3: of the negated image
           float t[9], mneg = -INFINITY;  // max of -g = -(min of g)
 #pragma unroll
           for (int bq = 0; bq < 3; ++bq) {
-            const unsigned ro = (unsigned)v.width * (unsigned)(ty0 + min(bq << L, max(ph - k, 0))) + (unsigned)tx0;
+            const unsigned ro = origin + __umul24((unsigned)v.width, (unsigned)min(bq << L, max(ph - k, 0)));
 #pragma unroll
             for (int aq = 0; aq < 3; ++aq) {
               t[3 * bq + aq] = -INFINITY;
-              if (aq < ux && bq < uy) t[3 * bq + aq] = lvl[ro + (unsigned)min(aq << L, max(pw - k, 0))];
+              if (aq < ux && bq < uy) t[3 * bq + aq] = load_u32_index(wm, ro + (unsigned)min(aq << L, max(pw - k, 0)));
             }
           }
 #pragma unroll
@@ -831,26 +845,65 @@ __device__ __forceinline__ TileInfo unpack_footprint(const FootprintRecord r) {
   return ti;
 }
 
+// Exact n / d for 32-bit unsigned n (Granlund-Montgomery, as in mc_kernels.hip): three integer instructions where the
+// compiler's division by a run-time value takes about twenty.
+struct FastDivU32 {
+  uint32_t d, m, s1, s2;
+};
+__device__ __forceinline__ uint32_t fast_div_u32(uint32_t n, const FastDivU32& f) {
+  const uint32_t t = __umulhi(n, f.m);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+FastDivU32 make_fast_div_u32(uint32_t d) {
+  FastDivU32 f;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;  // ceil(log2 d)
+  f.d = d;
+  f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l < 1 ? 0 : l - 1;
+  return f;
+}
+
 // Pre-pass of the raw-tile carve kernels: blockIdx.y = view, thread = wave brick (linear, x fastest: the carve
 // kernel's wave (bx, wave) of brick row (by, bz) is brick (bz * nby + by) * nbw + 4 bx + wave).
+// VALU-bound (round 5: 441 vector instructions per pair, 0.41 of the 0.6 ms it takes at 1024^3 x 32 at two cycles each;
+// profiles/r05/prepass.txt) -- hence the fast divisions of the brick number (div_nbw, div_nby: by nbw and nby, for launches of
+// fewer than 2^32 bricks), the depth-range test on two values instead of eight, 24-bit multiplies and a scalar base
+// for the window lookups in footprint_of.
 template <bool SAMEF, bool GEN>
 __global__ __launch_bounds__(256) void footprint_records_kernel(GridParams g, const FusedView* __restrict__ views,
                                                                 int nbw, int nby, int64_t nbricks, ModeParams mode,
                                                                 int want_bound, int want_lower,
-                                                                FootprintRecord* __restrict__ records) {
+                                                                FootprintRecord* __restrict__ records,
+                                                                FastDivU32 div_nbw, FastDivU32 div_nby, int small32) {
   const int64_t brick = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (brick >= nbricks) return;
   const int vi = blockIdx.y;
-  const int bxw = (int)(brick % nbw);
-  const int64_t rowb = brick / nbw;
-  const int by = (int)(rowb % nby), bz = (int)(rowb / nby);
+  int bxw, by, bz;
+  if (small32) {  // (uniform)
+    const uint32_t b32 = (uint32_t)brick;
+    const uint32_t rowb = fast_div_u32(b32, div_nbw);
+    bxw = (int)(b32 - rowb * (uint32_t)nbw);
+    const uint32_t zz = fast_div_u32(rowb, div_nby);
+    by = (int)(rowb - zz * (uint32_t)nby);
+    bz = (int)zz;
+  } else {
+    bxw = (int)(brick % nbw);
+    const int64_t rowb = brick / nbw;
+    by = (int)(rowb % nby);
+    bz = (int)(rowb / nby);
+  }
   const int x_lo = min(bxw * WX, g.nx - 1), x_hi = min(bxw * WX + WX - 1, g.nx - 1);
   const int y_hi = min(by * BY + BY - 1, g.ny - 1), z_hi = min(bz * BZ + BZ - 1, g.nz_local - 1);
   // (the view is uniform: its record arrives through scalar loads)
   const FusedView& fv = views[vi];
-  const TileInfo ti = footprint_of<SAMEF, kTileRaw, GEN>(fv, g.px[x_lo], g.px[x_hi], g.py[by * BY], g.py[y_hi],
-                                                          g.pz[g.z0 + bz * BZ], g.pz[g.z0 + z_hi], mode.ortho != 0,
-                                                          mode.outside == VCY_OUTSIDE_MAX, want_bound != 0, want_lower != 0);
+  gfloat_ptr ax = (gfloat_ptr)g.px, ay = (gfloat_ptr)g.py, az = (gfloat_ptr)g.pz;  // (uniform bases, 32-bit offsets)
+  const TileInfo ti = footprint_of<SAMEF, kTileRaw, GEN>(
+      fv, load_u32_index(ax, (unsigned)x_lo), load_u32_index(ax, (unsigned)x_hi), load_u32_index(ay, (unsigned)(by * BY)),
+      load_u32_index(ay, (unsigned)y_hi), load_u32_index(az, (unsigned)(g.z0 + bz * BZ)),
+      load_u32_index(az, (unsigned)(g.z0 + z_hi)), mode.ortho != 0, mode.outside == VCY_OUTSIDE_MAX, want_bound != 0,
+      want_lower != 0);
   records[(int64_t)vi * nbricks + brick] = pack_footprint(ti, fv.v);
 }
 
@@ -2122,9 +2175,11 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     }
     if (!big && !in_kernel_prologue) {
       const dim3 pgrid((unsigned)((nbricks + 255) / 256), (unsigned)n_views);
+      const FastDivU32 div_nbw = make_fast_div_u32((uint32_t)nbw), div_nby = make_fast_div_u32((uint32_t)nby);
 #define VCY_PREPASS(SF, GN)                                                                                       \
   hipLaunchKernelGGL((footprint_records_kernel<SF, GN>), pgrid, dim3(256), 0, c->stream, gc, d_views, nbw, nby,   \
-                     nbricks, m, need_bound ? 1 : 0, want_lower ? 1 : 0, recs)
+                     nbricks, m, need_bound ? 1 : 0, want_lower ? 1 : 0, recs, div_nbw, div_nby,                  \
+                     nbricks < 0xffffffffLL ? 1 : 0)
       if (samef) { if (gen) VCY_PREPASS(true, true); else VCY_PREPASS(true, false); }
       else { if (gen) VCY_PREPASS(false, true); else VCY_PREPASS(false, false); }
 #undef VCY_PREPASS
