@@ -368,7 +368,7 @@ def side_config(device, build, label, n, nv, w, h, mode, steps, warmup=1, settle
             t_k = ctr.get("trace_avg_ns", 0.0) * 1e-9
             if roof["traffic"] and t_k > 0:
                 roof["hbm_real_frac"] = round(roof["traffic"] / t_k / 1e9 / HBM_PEAK_GBS, 4)
-                roof["traffic_note"] = "per launch of the profiled run (%s launches per step there)" % ctr.get("trace_calls_per_step", "?")
+                roof["traffic_note"] = "HBM bytes of ONE launch of the carve kernel (a step is kernel_launches_per_step launches)"
             vcyc = valu_issue_cycles(ctr)
             clk = ctr.get("shader_clock_hz") or CLOCK_HZ
             if vcyc and t_k > 0:

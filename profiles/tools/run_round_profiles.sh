@@ -19,6 +19,12 @@ bash profiles/tools/profile_gpu.sh gpurun_out/$RND/cull0 --no-mc --cull 0
 python profiles/tools/summarize_pmc.py "$O/cull0" "$O/pmc_1024x32_cull0.json" --key default_1024_32_b1_c0 --counters "$CTR"
 bash profiles/tools/profile_gpu.sh gpurun_out/$RND/tsdf --no-mc --mode tsdf
 python profiles/tools/summarize_pmc.py "$O/tsdf" "$O/pmc_1024x32_tsdf.json" --key tsdf_1024_32_b1_c1 --counters "$CTR"
+# the other single-GPU configurations of BASELINE.json (bench.py's `configs` block reads these): trace + HBM bytes +
+# VALU counters + clock of configs[1] (512^3 x 16 TSDF) and of the configs[4] shape (2048^3 x 64, four launches per step)
+PASSES="trace fetch write sq1 grbm" bash profiles/tools/profile_gpu.sh gpurun_out/$RND/config1 --no-mc --config 1
+python profiles/tools/summarize_pmc.py "$O/config1" "$O/pmc_512x16_tsdf_config1.json" --key tsdf_512_16_b1_c1 --counters "$CTR"
+PASSES="trace fetch write sq1 grbm" STEPS_TRACE="--steps 3 --warmup 1" bash profiles/tools/profile_gpu.sh gpurun_out/$RND/config4 --no-mc --config 4
+python profiles/tools/summarize_pmc.py "$O/config4" "$O/pmc_2048x64_config4.json" --key default_2048_64_b1_c1 --counters "$CTR"
 # marching cubes: trace with the extraction inside, HBM bytes of its kernels
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$O/mc" -o trace --output-format csv -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-variants ) > "$O/mc_trace.log" 2>&1
 ( cd /tmp && rocprofv3 --pmc FETCH_SIZE -d "$O/mc" -o fetch --output-format csv -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-variants ) > "$O/mc_fetch.log" 2>&1
@@ -56,10 +62,18 @@ VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --launch torchrun --slabs-per-
 echo "2 ranks (gloo) rc=$?" >> "$O/status.txt"
 VCY_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --launch torchrun --steps 3 --warmup 1 --no-cpu-baseline --no-variants > "$O/bench_2ranks_one_device_rccl.json" 2> "$O/bench_2ranks_one_device_rccl.err"
 echo "2 ranks (rccl on one device, expected to be refused) rc=$?" >> "$O/status.txt"
+# round 5: the 8-rank launches rehearsed on this one device (gloo for the exchange: RCCL refuses two ranks per device), the
+# in-process form with eight "GPUs", the streamed emulation (sharded against replicated SDF producer), ExtractVoxel phases
+VCY_BENCH_FORCE_DEVICE=0 VCY_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --launch torchrun --allow-gloo --verify-mesh --variants streamed --steps 10 > "$O/bench_8ranks_one_device_gloo.json" 2> "$O/bench_8ranks_one_device_gloo.err"; echo "8 ranks torchrun gloo rc=$?" >> "$O/status.txt"
+VCY_BENCH_FORCE_DEVICE=0 timeout 900 python bench.py --gpus 8 --launch inprocess --verify-mesh --variants streamed --steps 10 > "$O/bench_inprocess_8x_one_device.json" 2> "$O/bench_inprocess_8x_one_device.err"; echo "8x inprocess rc=$?" >> "$O/status.txt"
+timeout 1200 python profiles/tools/streamed_emulation.py > "$O/streamed_emulation.txt" 2>&1; echo "streamed emulation rc=$?" >> "$O/status.txt"
+timeout 1200 python profiles/tools/slab_emulation.py > "$O/slab_emulation.txt" 2>&1; echo "slab emulation rc=$?" >> "$O/status.txt"
+VCY_XV_TIMING=1 timeout 300 python profiles/tools/xv_timing.py > "$O/extract_voxel_phases.txt" 2>&1
+for m in default tsdf; do timeout 300 python profiles/tools/first_view.py 1024 $m; done > "$O/first_view.txt" 2>&1
 # the bench lines: with the counters of this session next to them
 mkdir -p profiles && cp "$CTR" profiles/counters.json
 python bench.py > "$O/bench_1024x32_default.json" 2> "$O/bench_default.err"; echo "bench default rc=$?" >> "$O/status.txt"
 python bench.py --config 1 --no-variants > "$O/bench_512x16_tsdf_config1.json" 2> "$O/bench_config1.err"; echo "bench config1 rc=$?" >> "$O/status.txt"
-python bench.py --config 4 --steps 5 --warmup 1 --variants streamed --no-cpu-baseline --no-mc > "$O/bench_2048x64_config4.json" 2> "$O/bench_config4.err"; echo "bench config4 rc=$?" >> "$O/status.txt"
+python bench.py --config 4 --steps 5 --warmup 1 --variants streamed --no-cpu-baseline > "$O/bench_2048x64_config4.json" 2> "$O/bench_config4.err"; echo "bench config4 rc=$?" >> "$O/status.txt"
 cat "$O/status.txt"
 ls "$O"
