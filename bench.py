@@ -837,15 +837,16 @@ def main():
     avg_prepass_ms, avg_kernel_ms = read_logs(devs, args.steps) if args.batch else (0.0, my_elapsed_ms / args.steps)
     main_kernel_launches = kernel_launches[0] if args.batch else float(nv * len(devs))
     # The shader clock of THIS run, for the VALU issue fraction below: one wave on a stream of its own samples the clock
-    # counter (vcy_clock_probe_*) during three more steps of the same workload queued right behind the timed region --
+    # counter (vcy_clock_probe_*) during six more steps of the same workload queued right behind the timed region --
     # not inside it: beside the timed steps the probe's second hardware queue costs the carve kernel 1.7 %
-    # (profiles/r05/clock_probe_ab.txt); an idle device would have dropped its clock, three more steps keep it where it was.
+    # (profiles/r05/clock_probe_ab.txt); an idle device would have dropped its clock, six more steps keep it where it was
+    # (the clock over the second half of the probe's span is the one used: setting the probe up idles the device for a millisecond).
     live_clock = None
     if world == 1 and args.batch and "VCY_BENCH_NO_CLOCK_PROBE" not in os.environ:
         try:
             probe = vc.ClockProbe(local_rank)
             try:
-                run_steps(devs, main_step, 3)
+                run_steps(devs, main_step, 6)
                 sync_all(devs)
             finally:
                 live_clock = probe.stop()
@@ -917,12 +918,13 @@ def main():
                         "cycles per wave instruction) and issue_floor (measured: this kernel / the same kernel without "
                         "its tile loads and stores, for the variants whose control flow does not depend on the data)"}
     if live_clock is not None:
-        roofline["shader_clock_live"] = ({"ghz_mean": round(live_clock["mean_hz"] / 1e9, 4), "ghz_min": round(live_clock["min_hz"] / 1e9, 4),
+        roofline["shader_clock_live"] = ({"ghz_settled": round(live_clock["settled_hz"] / 1e9, 4), "ghz_mean": round(live_clock["mean_hz"] / 1e9, 4),
+                                          "ghz_min": round(live_clock["min_hz"] / 1e9, 4),
                                           "ghz_max": round(live_clock["max_hz"] / 1e9, 4), "samples": live_clock["samples"],
                                           "covered_ms": round(live_clock["covered_ms"], 3),
                                           "note": "s_memtime against s_memrealtime (100 MHz), one probe wave on its own stream "
-                                                  "during three more steps of the same workload right behind the timed region "
-                                                  "(vcy_clock_probe_*)"}
+                                                  "during six more steps of the same workload right behind the timed region; "
+                                                  "ghz_settled = over the second half of that span (vcy_clock_probe_*)"}
                                          if "mean_hz" in live_clock else live_clock)
     if ctr is None:
         roofline["counters_note"] = ctr_note
@@ -963,15 +965,15 @@ def main():
         roofline["frac_binding"] = roofline["valu_issue_frac_flat2"]
         roofline["frac_binding_note"] = ("VALU issue cycles (2 per wave instruction) / SIMD cycles of the launch, counters "
                                          "and shader clock of the PROFILED box (shader_clock_ghz_profiled)")
-        if live_clock and live_clock.get("mean_hz", 0) > 1e8:
+        if live_clock and live_clock.get("settled_hz", 0) > 1e8:
             # the same instruction count (it does not depend on the box: same kernel, same inputs) against THIS run's
             # kernel duration (HIP events) and THIS run's shader clock (the probe wave beside the timed steps)
-            roofline["valu_issue_frac_flat2_live"] = round(vcyc / (N_SIMD * live_clock["mean_hz"] * avg_launch_ms * 1e-3), 4)
+            roofline["valu_issue_frac_flat2_live"] = round(vcyc / (N_SIMD * live_clock["settled_hz"] * avg_launch_ms * 1e-3), 4)
             roofline["frac_binding"] = roofline["valu_issue_frac_flat2_live"]
             roofline["frac_binding_note"] = ("VALU issue cycles (2 per wave instruction; the instruction count of the committed "
                                              "counter pass, which does not depend on the box) / SIMD cycles of the launch at "
                                              "THIS run's kernel duration and shader clock (shader_clock_live: a probe wave "
-                                             "sampling the clock counter during three more steps right behind the timed region)")
+                                             "sampling the clock counter during six more steps right behind the timed region, second half of its span)")
     floor, _ = load_counters("issue_floor", build) if world == 1 else (None, None)
     if floor:
         roofline["issue_floor"] = {k: floor[k] for k in floor if k not in ("build",)}

@@ -422,14 +422,16 @@ int vcy_measure_bandwidth(int device_id, uint64_t bytes, int reps, double* read_
 /* Measurement aid, not on the carve path: the shader clock the device runs at WHILE other work is on it.  _start puts one
  * wave on a stream of its own that samples the shader clock counter against the constant 100 MHz reference every ~30 us
  * (at most max_samples samples, then it ends by itself); _stop ends it, frees everything and returns the clock over the
- * whole span (mean_hz), the slowest / fastest interval, the number of samples and the time they cover.  bench.py runs it
- * during three more steps of its workload queued right behind the timed region (a second active hardware queue costs the
+ * whole span (mean_hz) and over its second half (settled_hz: the device idles for a millisecond while the probe is set
+ * up, and its clock takes some milliseconds of load to come back), the slowest / fastest interval, the number of samples
+ * and the time they cover.  bench.py runs it
+ * during six more steps of its workload queued right behind the timed region (a second active hardware queue costs the
  * carve kernel 1.7 %, so not inside it): the VALU issue fraction of the carve kernel is then priced at the clock of the
  * run that is reported, not at the clock of the box the counters were collected on. */
 typedef struct vcy_clock_probe vcy_clock_probe;
 int vcy_clock_probe_start(int device_id, int max_samples, vcy_clock_probe** out);
-int vcy_clock_probe_stop(vcy_clock_probe* probe, double* mean_hz, double* min_hz, double* max_hz, int* n_samples,
-                         double* covered_ms);
+int vcy_clock_probe_stop(vcy_clock_probe* probe, double* mean_hz, double* settled_hz, double* min_hz, double* max_hz,
+                         int* n_samples, double* covered_ms);
 
 const char* vcy_last_error(void);
 /* "vacancy_amd <version> (gfx950) src:<hash>": the hash covers every source file the library was built from

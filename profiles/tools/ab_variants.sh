@@ -7,7 +7,7 @@ for v in "$@"; do
   lib=build/variants/$v/libvacancy_hip.so
   [ "$v" = "prod" ] && lib=vacancy_amd/csrc/libvacancy_hip.so
   echo -n "$v  state: "; VCY_HIP_LIB=$lib python profiles/tools/state_hash.py 2>&1 | tail -1
-  VCY_HIP_LIB=$lib python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-mc --variants modes > "$OUT/$v.json" 2> "$OUT/$v.err"
+  VCY_HIP_LIB=$lib python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-mc --no-configs --variants modes > "$OUT/$v.json" 2> "$OUT/$v.err"
   python - "$v" "$OUT/$v.json" <<'PY'
 import json,sys
 try:

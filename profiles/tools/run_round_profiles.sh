@@ -15,6 +15,8 @@ rm -f "$CTR" "$O/status.txt"
 # carve workloads: trace + counters (no marching cubes inside these runs)
 bash profiles/tools/profile_gpu.sh gpurun_out/$RND/default --no-mc
 python profiles/tools/summarize_pmc.py "$O/default" "$O/pmc_1024x32_default.json" --key default_1024_32_b1_c1 --counters "$CTR"
+python profiles/tools/per_dispatch.py "$O/default/trace_kernel_trace.csv" > "$O/kernel_trace_carve_fused_per_dispatch.txt"
+grep -o '"avg_launch_ms": [0-9.]*' "$O/default/trace.log" | head -1 | sed 's/^/bench line of the same (traced) run: /' >> "$O/kernel_trace_carve_fused_per_dispatch.txt"
 bash profiles/tools/profile_gpu.sh gpurun_out/$RND/cull0 --no-mc --cull 0
 python profiles/tools/summarize_pmc.py "$O/cull0" "$O/pmc_1024x32_cull0.json" --key default_1024_32_b1_c0 --counters "$CTR"
 bash profiles/tools/profile_gpu.sh gpurun_out/$RND/tsdf --no-mc --mode tsdf
@@ -70,6 +72,11 @@ timeout 1200 python profiles/tools/streamed_emulation.py > "$O/streamed_emulatio
 timeout 1200 python profiles/tools/slab_emulation.py > "$O/slab_emulation.txt" 2>&1; echo "slab emulation rc=$?" >> "$O/status.txt"
 VCY_XV_TIMING=1 timeout 300 python profiles/tools/xv_timing.py > "$O/extract_voxel_phases.txt" 2>&1
 for m in default tsdf; do timeout 300 python profiles/tools/first_view.py 1024 $m; done > "$O/first_view.txt" 2>&1
+timeout 300 python profiles/tools/write_ceiling.py > "$O/write_ceiling.txt" 2>&1
+# the summaries profiles/rNN/ keeps of the traced runs
+for w in default cull0 tsdf; do cp "$O/$w/trace_kernel_stats.csv" "$O/kernel_stats_1024x32_$w.csv"; done
+cp "$O/config1/trace_kernel_stats.csv" "$O/kernel_stats_512x16_tsdf_config1.csv"; cp "$O/config4/trace_kernel_stats.csv" "$O/kernel_stats_2048x64_config4.csv"
+cp "$O/mc/trace_kernel_stats.csv" "$O/kernel_stats_1024x32_default_with_mc.csv"
 # the bench lines: with the counters of this session next to them
 mkdir -p profiles && cp "$CTR" profiles/counters.json
 python bench.py > "$O/bench_1024x32_default.json" 2> "$O/bench_default.err"; echo "bench default rc=$?" >> "$O/status.txt"

@@ -1451,6 +1451,7 @@ def test_clock_probe_runs_beside_other_work():
     r = probe.stop()
     assert r["samples"] >= 2 and r["covered_ms"] > 0.0
     assert 0.3e9 < r["mean_hz"] < 3.5e9, r          # MI355X: 2.4 GHz peak shader clock
+    assert 0.3e9 < r["settled_hz"] < 3.5e9, r       # (the second half of the span)
     assert r["min_hz"] <= r["mean_hz"] * 1.01 and r["max_hz"] >= r["mean_hz"] * 0.99
     assert probe.stop() == r                         # idempotent
     # a probe that fills its buffer ends by itself

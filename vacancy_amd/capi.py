@@ -174,7 +174,8 @@ def load():
         "vcy_carve_log": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, P(C.c_int), C.c_int]),
         "vcy_measure_bandwidth": (C.c_int, [C.c_int, C.c_uint64, C.c_int, P(C.c_double), P(C.c_double)]),
         "vcy_clock_probe_start": (C.c_int, [C.c_int, C.c_int, P(vp)]),
-        "vcy_clock_probe_stop": (C.c_int, [vp, P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_int), P(C.c_double)]),
+        "vcy_clock_probe_stop": (C.c_int, [vp, P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_int),
+                                           P(C.c_double)]),
         "vcy_last_error": (C.c_char_p, []),
         "vcy_version": (C.c_char_p, []),
     }

@@ -453,12 +453,13 @@ class ClockProbe:
 
     def stop(self):
         if self._p:
-            mean, lo, hi, cov, n = C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_int()
-            rc = self._lib.vcy_clock_probe_stop(self._p, C.byref(mean), C.byref(lo), C.byref(hi), C.byref(n), C.byref(cov))
+            mean, settled, lo, hi, cov, n = C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_int()
+            rc = self._lib.vcy_clock_probe_stop(self._p, C.byref(mean), C.byref(settled), C.byref(lo), C.byref(hi), C.byref(n),
+                                                C.byref(cov))
             self._p = C.c_void_p()
             if rc != 0:
                 raise RuntimeError("vcy_clock_probe_stop: " + last_error())
-            self.result = {"mean_hz": mean.value, "min_hz": lo.value, "max_hz": hi.value, "samples": n.value,
+            self.result = {"mean_hz": mean.value, "settled_hz": settled.value, "min_hz": lo.value, "max_hz": hi.value, "samples": n.value,
                            "covered_ms": cov.value}
         return self.result
 

@@ -97,8 +97,8 @@ extern "C" int vcy_clock_probe_start(int device_id, int max_samples, vcy_clock_p
   return VCY_OK;
 }
 
-extern "C" int vcy_clock_probe_stop(vcy_clock_probe* p, double* mean_hz, double* min_hz, double* max_hz, int* n_samples,
-                                    double* covered_ms) {
+extern "C" int vcy_clock_probe_stop(vcy_clock_probe* p, double* mean_hz, double* settled_hz, double* min_hz, double* max_hz,
+                                    int* n_samples, double* covered_ms) {
   using namespace vcy;
   if (!p) {
     set_error("invalid argument");
@@ -119,7 +119,7 @@ extern "C" int vcy_clock_probe_stop(vcy_clock_probe* p, double* mean_hz, double*
     set_error("clock probe: %s", hipGetErrorString(e));
     rc = VCY_ERR_HIP;
   }
-  double lo = 0.0, hi = 0.0, mean = 0.0, covered = 0.0;
+  double lo = 0.0, hi = 0.0, mean = 0.0, covered = 0.0, settled = 0.0;
   if (rc == VCY_OK && n >= 2) {
     // per interval: shader cycles / reference ticks x 100 MHz; the mean over the whole span
     lo = 1e30;
@@ -134,8 +134,14 @@ extern "C" int vcy_clock_probe_stop(vcy_clock_probe* p, double* mean_hz, double*
     if (span > 0.0) mean = (double)(s[(size_t)n - 1].shader - s[0].shader) / span * 100.0e6;
     covered = span / 100.0e6 * 1e3;
     if (lo > 1e29) lo = 0.0;
+    // the second half of the span alone: the device has idled for a millisecond while the probe was set up, and its
+    // clock needs some milliseconds of load to come back (profiles/r04/clock_ramp.txt)
+    const size_t h = (size_t)n / 2;
+    const double span2 = (double)(s[(size_t)n - 1].real - s[h].real);
+    settled = span2 > 0.0 ? (double)(s[(size_t)n - 1].shader - s[h].shader) / span2 * 100.0e6 : mean;
   }
   if (mean_hz) *mean_hz = mean;
+  if (settled_hz) *settled_hz = settled;
   if (min_hz) *min_hz = lo;
   if (max_hz) *max_hz = hi;
   if (n_samples) *n_samples = n;
