@@ -12,9 +12,9 @@ run() {  # label, seconds, command...
   tail -2 $O/fuzz_last.log >> $O/fuzz_regression.txt
 }
 run "tests/fuzz/fuzz_marching_cubes.py 0..2300" $B python tests/fuzz/fuzz_marching_cubes.py 0 2300
-run "tests/fuzz/fuzz_incremental.py 2000..2120 (rows of whole bricks)" $B python tests/fuzz/fuzz_incremental.py 2000 2120
-run "tests/fuzz/fuzz_incremental.py 0..100" $B python tests/fuzz/fuzz_incremental.py 0 100
-run "tests/fuzz/fuzz_incremental.py 3000..3100 (modes)" $B python tests/fuzz/fuzz_incremental.py 3000 3100
-run "tests/fuzz/fuzz_random_scenes.py 0..200" $B python tests/fuzz/fuzz_random_scenes.py 0 200
-run "tests/fuzz/fuzz_fine_grids.py 0..100" $B python tests/fuzz/fuzz_fine_grids.py 0 100
+run "tests/fuzz/fuzz_incremental.py 2000..3200 (rows of whole bricks)" $B python tests/fuzz/fuzz_incremental.py 2000 3200
+run "tests/fuzz/fuzz_incremental.py 0..1200" $B python tests/fuzz/fuzz_incremental.py 0 1200
+run "tests/fuzz/fuzz_incremental.py 3000..4200 modes (nearest neighbour, weights != 1, update limits in reach)" $B python tests/fuzz/fuzz_incremental.py 3000 4200 modes
+run "tests/fuzz/fuzz_random_scenes.py 0..4000" $B python tests/fuzz/fuzz_random_scenes.py 0 4000
+run "tests/fuzz/fuzz_fine_grids.py 0..1500" $B python tests/fuzz/fuzz_fine_grids.py 0 1500
 cat $O/fuzz_regression.txt
