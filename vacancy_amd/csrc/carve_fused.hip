@@ -865,6 +865,27 @@ FastDivU32 make_fast_div_u32(uint32_t d) {
   return f;
 }
 
+// Launch constants of carve_fused_kernel's block decode (which workgroup block of bricks a launch index is), computed on
+// the host: a single-view launch runs 2 M waves that live a few microseconds, each CU has ONE scalar unit, and the five
+// integer divisions by run-time values at the head of every wave -- 25 scalar instructions and a v_rcp_iflag round trip
+// each -- were a fifth of the scalar work that bounds such a launch (profiles/r05/first_view_floor.txt).
+struct BlockDecode {
+  int layer, q, rem, dealt;            // workgroups per brick layer, layer / 8, layer % 8, 8 q (layers of the launch)
+  FastDivU32 dq, drem, dnbx, dnby;     // divisions by q, rem (1 when rem == 0: never used then), nbx, nby
+};
+BlockDecode make_block_decode(unsigned grid_x, int nbx, int nby) {
+  BlockDecode d;
+  d.layer = nbx * nby;
+  d.q = d.layer >> 3;
+  d.rem = d.layer & 7;
+  d.dealt = 8 * d.q * (int)(grid_x / (unsigned)std::max(d.layer, 1));
+  d.dq = make_fast_div_u32((uint32_t)std::max(d.q, 1));
+  d.drem = make_fast_div_u32((uint32_t)std::max(d.rem, 1));
+  d.dnbx = make_fast_div_u32((uint32_t)std::max(nbx, 1));
+  d.dnby = make_fast_div_u32((uint32_t)std::max(nby, 1));
+  return d;
+}
+
 // Pre-pass of the raw-tile carve kernels: blockIdx.y = view, thread = wave brick (linear, x fastest: the carve
 // kernel's wave (bx, wave) of brick row (by, bz) is brick (bz * nby + by) * nbw + 4 bx + wave).
 // VALU-bound (round 5: 441 vector instructions per pair, 0.41 of the 0.6 ms it takes at 1024^3 x 32 at two cycles each;
@@ -966,7 +987,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
                                                           const FusedView* __restrict__ views,
                                                           const float* __restrict__ c0_all,
                                                           int nviews, ModeParams mode, int nbx,
-                                                          int nby, int cull_enabled, int state_flags,
+                                                          int nby, BlockDecode bd, int cull_enabled, int state_flags,
                                                           const FootprintRecord* __restrict__ records,
                                                           int64_t nbricks, float* __restrict__ brick_min,
                                                           const int* __restrict__ wg_list,
@@ -1041,14 +1062,14 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     // over 8 layers, every y range: balanced for a slab of few layers too (a rank's slab of an 8-GPU run has 16, and
     // dealing whole layers gives XCD 7 the two most expensive ones of an outer slab).  The workgroups a layer has
     // beyond a multiple of eight go round-robin as they come.
-    const int layer = nbx * nby, nlayers = (int)gridDim.x / layer, q = layer >> 3, rem = layer & 7;
-    const int dealt = 8 * q * nlayers;
+    // (layer, q, rem, dealt and the divisions by q and rem: launch constants from the host, BlockDecode)
+    const int layer = bd.layer, q = bd.q, rem = bd.rem, dealt = bd.dealt;
     if (b < dealt) {
       const int xcd = b & 7, j = b >> 3;
-      const int l = j / q, within = j - l * q;
+      const int l = (int)fast_div_u32((uint32_t)j, bd.dq), within = j - l * q;
       b = l * layer + ((xcd + l) & 7) * q + within;
     } else {
-      const int r = b - dealt, l = r / rem;
+      const int r = b - dealt, l = (int)fast_div_u32((uint32_t)r, bd.drem);
       b = l * layer + 8 * q + (r - l * rem);
     }
 #elif defined(VCY_XCD_LAYERS)
@@ -1067,12 +1088,18 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     if (b < per * 8) b = (b & 7) * per + (b >> 3);
 #endif
   }
-  const int bx = b % nbx;
-  b /= nbx;
-  const int by = b % nby;
-  const int bz = b / nby;
+  const int brow = (int)fast_div_u32((uint32_t)b, bd.dnbx);  // (b >= 0: a launch covers fewer than 2^31 workgroups)
+  const int bx = b - brow * nbx;
+  const int bz = (int)fast_div_u32((uint32_t)brow, bd.dnby);
+  const int by = brow - bz * nby;
   // (the wave index is uniform, which the compiler cannot see: readfirstlane keeps the x tables in scalar loads)
   const int x_first = __builtin_amdgcn_readfirstlane(bx * BX + wave * WX);  // wave brick origin
+#if defined(VCY_DEV_EXIT_AT) && VCY_DEV_EXIT_AT == 1
+  if (x_first >= 0) {
+    coop_leave();
+    return;
+  }
+#endif
   if (x_first >= g.nx) {                    // (a wave may leave alone: see coop_leave)
     coop_leave();
     return;
@@ -1125,6 +1152,12 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
                                                want_bound && TRUNC && UPDATE != VCY_UPDATE_MAX, (lds_u32*)tinfo);
   }
   wave_lds_fence();
+#if defined(VCY_DEV_EXIT_AT) && VCY_DEV_EXIT_AT == 2  // development build: where a wave's scalar instructions go (profiles/tools/salu_attribution.sh)
+  {
+    coop_leave();
+    return;
+  }
+#endif
   const unsigned long long view_mask = (nviews >= 64) ? ~0ull : ((1ull << nviews) - 1ull);
   // (a launch covers fewer than 2^31 wave bricks: launch_carve_fused)
   // Views that cannot change this brick whatever its voxels hold now: every sample below the truncation limit, or
@@ -1153,6 +1186,12 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   }
 #endif
 
+#if defined(VCY_DEV_EXIT_AT) && VCY_DEV_EXIT_AT == 3  // development build: where a wave's scalar instructions go (profiles/tools/salu_attribution.sh)
+  {
+    coop_leave();
+    return;
+  }
+#endif
   // ---- load the wave brick's state ----------------------------------------------------------
   CountT* __restrict__ cnt = (CountT*)g.cnt;
   // update_num in registers: an int for kMax, a float for the weighted-average modes (see apply_sample)
@@ -1287,6 +1326,12 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   VCY_PT(0);
   VCY_PT_COUNT(10);
 
+#if defined(VCY_DEV_EXIT_AT) && VCY_DEV_EXIT_AT == 4  // development build: where a wave's scalar instructions go (profiles/tools/salu_attribution.sh)
+  {
+    coop_leave();
+    return;
+  }
+#endif
   // ---- views ------------------------------------------------------------------------------
   int n_processed = 0;  // (wave-uniform: an SGPR; only read with "paircount" on)
   while (vi < nviews) {
@@ -1597,6 +1642,12 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   const int64_t row0_w = ((int64_t)min(zl_w, g.nz_local - 1) * g.ny + min(y_w, g.ny - 1)) * g.nx;
   // ("paircount" 1: (brick, view) pairs processed, per brick layer of the launch -- what the slab planner's
   // estimate is checked against, and what bench.py reports as the fraction of pairs the scene leaves)
+#if defined(VCY_DEV_EXIT_AT) && VCY_DEV_EXIT_AT == 5  // development build: where a wave's scalar instructions go (profiles/tools/salu_attribution.sh)
+  {
+    coop_leave();
+    return;
+  }
+#endif
   if (pair_count != nullptr && lane == 0) atomicAdd(&pair_count[bz], (unsigned long long)n_processed);
 #ifndef VCY_NO_BRICK_MIN_WRITE
   if (brick_min != nullptr && implied) {  // (lanes outside the grid hold copies of voxels inside it)
@@ -1723,7 +1774,7 @@ void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const Gri
   hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, CM, TQ_, GEN_, DIV_>), grid, dim3(64 * kWgWaves),  \
                      (size_t)kWgWaves * tile_f4_per_wave<TQ_>() * sizeof(float4) + (size_t)kWgWaves * nv * sizeof(TileInfo) + \
                          ((fresh & 8) ? coop_lds_bytes<CountT>() : 0), s,                                         \
-                     g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt)
+                     g, dv, c2, nv, m, nbx, nby, make_block_decode(grid.x, nbx, nby), cull, fresh, recs, nbricks, bmin, wgl, pcnt)
 #define VCY_FUSED_G(CM, TQ_)                                                                                     \
   do {                                                                                                           \
     if (gen) VCY_FUSED(CM, TQ_, true, 0);                                                                        \
