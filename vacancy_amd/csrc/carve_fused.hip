@@ -1881,6 +1881,26 @@ bool sane(float f) { return f >= 0x1p-40f && f <= 0x1p40f; }
 
 }  // namespace
 
+// The c0 records of a launch (FusedView layout note: c0_all[view][x brick][kC0Stride]) from the views' first rotation
+// column and the x axis table, on the device: blockIdx.y = view, thread = (x brick, k).  One fp32 multiply per entry --
+// the same IEEE product the host formed until round 5, when a launch with NEW views still waited for the previous
+// launch, uploaded 0.5 MB of these from pageable memory and waited again (prepare_views).
+namespace {
+__global__ __launch_bounds__(256) void c0_records_kernel(const FusedView* __restrict__ views, const float* __restrict__ px,
+                                                         int nx, int nbw, float* __restrict__ c2) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int b = t >> 3, k = t & 7;
+  if (b >= nbw) return;
+  const ViewParams& v = views[blockIdx.y].v;  // (uniform: scalar loads)
+  const float p = px[min(b * WX + k, nx - 1)];
+  float* rec = c2 + ((size_t)blockIdx.y * nbw + b) * kC0Stride;
+  rec[2 * k + 0] = v.r[0][0] * p;
+  rec[2 * k + 1] = v.r[1][0] * p;
+  rec[16 + k] = v.r[2][0] * p;
+  rec[24 + k] = 0.0f;  // (unused quarter of the 128-byte record)
+}
+}  // namespace
+
 // True when the fused kernel can take these views (otherwise the per-view kernel does).
 bool fused_eligible(const vcy_ctx* c, int n_views, const vcy_view* views) {
   const vcy_update_option& u = c->opt.update_option;
@@ -1953,19 +1973,29 @@ int prepare_views(vcy_ctx* c, int n_views, const ViewParams* vp, bool need_bound
                       c->fused_cache_ortho == c->fused_ortho && c->fused_cache_at == (void*)d_c2 &&
                       c->fused_cache_z[0] == zlo && c->fused_cache_z[1] == zhi;
   if (!cached) {
-    std::vector<float> c2(c2_floats, 0.0f);
-    for (int vi = 0; vi < n_views; ++vi)
-      for (int b = 0; b < nbw; ++b) {
-        float* rec = &c2[((size_t)vi * nbw + b) * kC0Stride];
-        for (int k = 0; k < WX; ++k) {
-          const float px = c->h_px[std::min(b * WX + k, c->nx - 1)];
-          rec[2 * k + 0] = vp[vi].r[0][0] * px;
-          rec[2 * k + 1] = vp[vi].r[1][0] * px;
-          rec[16 + k] = vp[vi].r[2][0] * px;
-        }
+    // The view blocks are built in page-locked host memory -- two buffers taken in turn, each with an event that says
+    // when the copy out of it has been made -- and the c0 records by a kernel behind that copy: a launch with new
+    // views queues behind the previous one like any other work on the stream (round 5; until then this path waited
+    // for the stream twice and uploaded the c0 records, 0.5 MB at 1024^3 x 32, from a host vector).
+    static_assert(kC0Stride == 32 && WX == 8, "c0_records_kernel's record layout");
+    if (c->fused_stage_bytes < fv_bytes) {
+      for (int q = 0; q < 2; ++q) {
+        if (c->ev_fused_stage[q]) (void)hipEventSynchronize(c->ev_fused_stage[q]);
+        if (c->h_fused_stage[q]) (void)hipHostFree(c->h_fused_stage[q]);
+        c->h_fused_stage[q] = nullptr;
       }
-    std::vector<FusedView> fv((size_t)n_views);
-    std::memset((void*)fv.data(), 0, fv_bytes);
+      c->fused_stage_bytes = 0;
+      const size_t room = fv_bytes + fv_bytes / 2 + 4096;
+      for (int q = 0; q < 2; ++q) {
+        VCY_HIP_CHECK(hipHostMalloc(&c->h_fused_stage[q], room, hipHostMallocDefault));
+        if (!c->ev_fused_stage[q]) VCY_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fused_stage[q], hipEventDisableTiming));
+      }
+      c->fused_stage_bytes = room;
+    }
+    c->fused_stage_idx ^= 1;
+    VCY_HIP_CHECK(hipEventSynchronize(c->ev_fused_stage[c->fused_stage_idx]));  // (the copy of two launches ago: long made)
+    FusedView* fv = (FusedView*)c->h_fused_stage[c->fused_stage_idx];
+    std::memset((void*)fv, 0, fv_bytes);
     bool samef = true;
     for (int vi = 0; vi < n_views; ++vi) {
       fv[vi].v = vp[vi];
@@ -2019,11 +2049,12 @@ int prepare_views(vcy_ctx* c, int n_views, const ViewParams* vp, bool need_bound
         max_quads = std::max(max_quads, ((rx1 - rx0) / 4) * (ry1 - ry0));
       }
     }
-    // the scratch may still be read by the previous launch on this stream
-    VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
-    VCY_HIP_CHECK(hipMemcpyAsync(d_c2, c2.data(), c2_bytes, hipMemcpyHostToDevice, c->stream));
-    VCY_HIP_CHECK(hipMemcpyAsync(d_views, fv.data(), fv_bytes, hipMemcpyHostToDevice, c->stream));
-    VCY_HIP_CHECK(hipStreamSynchronize(c->stream));  // host vectors die at return
+    // (the scratch may still be read by the previous launch: the copy and the kernel are queued behind it on the stream)
+    VCY_HIP_CHECK(hipMemcpyAsync(d_views, fv, fv_bytes, hipMemcpyHostToDevice, c->stream));
+    VCY_HIP_CHECK(hipEventRecord(c->ev_fused_stage[c->fused_stage_idx], c->stream));
+    hipLaunchKernelGGL(c0_records_kernel, dim3((unsigned)((nbw * WX + 255) / 256), (unsigned)n_views), dim3(256), 0, c->stream,
+                       d_views, c->d_px, c->nx, nbw, d_c2);
+    VCY_HIP_CHECK(hipGetLastError());
     c->fused_cache_vp.assign((const char*)vp, (const char*)vp + vp_bytes);
     c->fused_cache_wmax = c->d_wmax;
     c->fused_cache_bound = need_bound;

@@ -483,6 +483,10 @@ void vcy_destroy(vcy_ctx* c) {
   (void)hipFree(c->d_mc_flags);
   (void)hipFree(c->d_mc_cells);
   (void)hipFree(c->d_fused_scratch);
+  for (int q = 0; q < 2; ++q) {
+    if (c->ev_fused_stage[q]) (void)hipEventDestroy(c->ev_fused_stage[q]);
+    if (c->h_fused_stage[q]) (void)hipHostFree(c->h_fused_stage[q]);
+  }
   (void)hipFree(c->d_wmax);
   (void)hipFree(c->d_records);
   (void)hipFree(c->d_wg_list);

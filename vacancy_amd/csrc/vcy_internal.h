@@ -137,6 +137,10 @@ struct vcy_ctx {
   float* d_wmax = nullptr;            // window-maximum planes of the views of one fused launch
   size_t wmax_bytes = 0;
   bool fused_ortho = false;           // projection model of the launch being prepared
+  void* h_fused_stage[2] = {nullptr, nullptr};  // page-locked staging of the view blocks, taken in turn (prepare_views)
+  hipEvent_t ev_fused_stage[2] = {nullptr, nullptr};  // "the copy out of staging buffer q has been made"
+  size_t fused_stage_bytes = 0;
+  int fused_stage_idx = 0;
   bool fused_cache_valid = false;     // d_fused_scratch holds what these view parameters give (launch_carve_fused)
   std::vector<char> fused_cache_vp;   // the ViewParams of the launch that filled it
   const float* fused_cache_wmax = nullptr;
