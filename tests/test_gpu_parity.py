@@ -1372,6 +1372,46 @@ def test_sharded_silhouette_producer_equals_per_slab_producer(split, kw, monkeyp
     vc.capi.load().vcy_halo_shutdown()  # releases the producer groups as well
 
 
+def test_one_rank_of_the_process_per_gpu_producer_equals_the_batch_call():
+    """vacancy_amd.dist.carve_silhouettes_sharded with world == 1 (what `bench.py --variants streamed` runs on one GPU,
+    and the degenerate case of the one-process-per-GPU job): the rank builds every SDF image in place in the set its
+    slabs carve from -- no exchange, no copy on another stream -- over several chunks, so that both image sets are
+    reused while an earlier chunk's carve may still be queued.  State == CarveBatchSilhouettes == the oracle."""
+    import torch
+    from vacancy_amd import dist as vdist
+    n, nv, w, h = 40, 75, 128, 96
+    uo = UpdateOption(voxel_update=1, use_truncation=True, truncation_band=0.1)
+    opt = synth.sphere_option(n, uo)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    rng = np.random.RandomState(11)
+    for i in range(0, nv, 4):
+        masks[i] = (rng.rand(h, w) < 0.4).astype(np.uint8) * 255
+
+    def slabs():
+        out = []
+        for r in range(2):
+            c = vc.VoxelCarver(opt, z_range=vdist.slab_range(n, r, 2))
+            assert c.Init(), vc.last_error()
+            out.append(c)
+        return out
+
+    a, b = slabs(), slabs()
+    for c in a:
+        assert c.CarveBatchSilhouettes(views, masks), vc.last_error()
+    # a pending kernel on torch's own stream must not matter to the carvers' streams
+    junk = torch.empty(1 << 24, device="cuda").normal_()
+    info = vdist.carve_silhouettes_sharded(b, 0, 1, views, masks, chunk=16)
+    assert info["views_built_by_this_rank"] == nv and junk.numel() > 0
+    for ca, cb in zip(a, b):
+        assert ca.state_diff(cb) == 0
+    orc = O.OracleGrid(opt)
+    for i in range(nv):
+        orc.carve(views[i], O.make_sdf(masks[i], use_truncation=True, band=0.1))
+    os_, ou = orc.download()
+    assert np.array_equal(np.concatenate([c.download()[1] for c in b]), ou)
+    assert np.array_equal(np.concatenate([c.download()[0] for c in b]).view(np.uint32), os_.view(np.uint32))
+
+
 def test_make_sdf_batch_into_caller_owned_images():
     """vcy_make_sdf_batch_device: a rank's share of the SDF images of a one-process-per-GPU job, built into images the
     caller owns (one allocation, as the all-gather's send buffer is) -- bit-equal to the oracle's transform."""

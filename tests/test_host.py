@@ -324,3 +324,109 @@ def test_voxel_cubes_without_a_gpu_equals_the_oracle():
         v = one_by_one["vertices"][24 * t:24 * t + 24]
         assert np.array_equal(np.unique(v[:, 0]), np.unique(np.array([lo_t[0] + pos[t][0], hi_t[0] + pos[t][0]], np.float32)))
         assert np.array_equal(np.unique(v[:, 2]), np.unique(np.array([lo_t[2] + pos[t][2], hi_t[2] + pos[t][2]], np.float32)))
+
+
+def _png_decode_filter0(path):
+    """An independent decoder for what WritePng8 emits (8-bit, non-interlaced, every row filter 0): chunk walk with CRC
+    check, zlib inflate.  Returns (width, height, channels, pixels)."""
+    import struct
+    import zlib
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr, seen_end = 8, b"", None, False
+    while pos < len(raw):
+        (ln,), typ = struct.unpack(">I", raw[pos:pos + 4]), raw[pos + 4:pos + 8]
+        body = raw[pos + 8:pos + 8 + ln]
+        (crc,) = struct.unpack(">I", raw[pos + 8 + ln:pos + 12 + ln])
+        assert crc == (zlib.crc32(typ + body) & 0xffffffff), typ
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"IDAT":
+            idat += body
+        elif typ == b"IEND":
+            seen_end = True
+        pos += 12 + ln
+    assert seen_end and pos == len(raw)
+    w, h, depth, ctype, comp, flt, inter = ihdr
+    assert (depth, comp, flt, inter) == (8, 0, 0, 0)
+    ch = {0: 1, 4: 2, 2: 3, 6: 4}[ctype]
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * ch + 1)
+    assert not rows[:, 0].any()
+    return w, h, ch, rows[:, 1:].reshape(h, w, ch)
+
+
+def test_host_outputs_are_read_back_byte_for_byte(tmp_path):
+    """Rows f3 / f4 of SURVEY section 8: what the facade WRITES.  `Mesh::WritePlyBinary` (ours; the reference has only the
+    ASCII writer, mesh.cc:583-631) is parsed back -- header, 12-byte vertices, 13-byte face records -- to the mesh it was
+    given and to what the ASCII writer says about the same mesh; `SignedDistance2Color` (voxel_carver.cc:239-267) is
+    compared with a numpy restatement on the SDF of every bunny mask; `Image::WritePng` (image.h:103-118; zlib here, stb
+    in the reference) is decoded by a decoder of the test's own, by Pillow when it is there, and by the facade's Load."""
+    import subprocess
+    _build_host()
+    out = str(tmp_path)
+    masks = B.load_masks()
+    sdfs = []
+    for i, m in enumerate(masks):
+        # (view 3: not normalised, so that values beyond both ends of the colour ramp occur)
+        sdfs.append(O.make_sdf(m, None, None, i != 3, False, 0.1) * (np.float32(0.01) if i == 3 else np.float32(1)))
+        sdfs[-1].astype(np.float32).tofile(os.path.join(out, "sdf_%d.f32" % i))
+    lines = subprocess.run([os.path.join(ROOT, "vacancy_amd", "host", "host_selftest"), B.BUNNY, "io", out],
+                           check=True, capture_output=True, text=True).stdout.splitlines()
+    assert [l for l in lines if l.startswith("PLY")][0].split() == ["PLY", "1", "5000", "9000"]
+    # ---- the mesh the selftest builds, restated
+    i5 = np.arange(5000)
+    V = np.stack([np.float32(0.1) * i5.astype(np.float32) - np.float32(250.0),
+                  np.float32(1.0) / (np.float32(1.0) + i5.astype(np.float32)),
+                  (i5 % 7).astype(np.float32) * np.float32(-1234.5678)], 1).astype(np.float32)
+    i9 = np.arange(9000)
+    F = np.stack([i9 % 5000, (i9 * 7 + 1) % 5000, (i9 * 13 + 2) % 5000], 1).astype(np.int32)
+    # ---- binary PLY
+    raw = open(os.path.join(out, "mesh_binary.ply"), "rb").read()
+    end = raw.index(b"end_header\n") + len(b"end_header\n")
+    assert raw[:end].decode() == ("ply\nformat binary_little_endian 1.0\nelement vertex 5000\nproperty float x\n"
+                                  "property float y\nproperty float z\nelement face 9000\n"
+                                  "property list uchar int vertex_indices\nend_header\n")
+    assert len(raw) == end + 12 * 5000 + 13 * 9000
+    v = np.frombuffer(raw, "<f4", 3 * 5000, end).reshape(-1, 3)
+    rec = np.frombuffer(raw, np.uint8, 13 * 9000, end + 12 * 5000).reshape(-1, 13)
+    assert (rec[:, 0] == 3).all()
+    f = np.ascontiguousarray(rec[:, 1:]).view("<i4").reshape(-1, 3)
+    assert np.array_equal(v.view(np.uint32), V.view(np.uint32)) and np.array_equal(f, F)
+    empty = open(os.path.join(out, "mesh_empty.ply"), "rb").read()
+    assert empty.endswith(b"end_header\n") and b"element vertex 0\n" in empty and b"element face 0\n" in empty
+    # ---- the ASCII file of the same mesh: the reference's layout, %g digits (ostream default, mesh.cc:613-628)
+    txt = open(os.path.join(out, "mesh_ascii.ply")).read().split("\n")
+    assert txt[:9] == ["ply", "format ascii 1.0", "element vertex 5000", "property float x", "property float y",
+                       "property float z", "element face 9000", "property list uchar int vertex_indices", "end_header"]
+    assert txt[9] == "%g %g %g " % tuple(float(x) for x in V[0]) and txt[9 + 4999] == "%g %g %g " % tuple(float(x) for x in V[4999])
+    assert txt[9 + 5000] == "3 0 1 2 " and txt[9 + 5000 + 8999] == "3 %d %d %d " % tuple(F[8999]) and txt[-1] == ""
+    va = np.array([[float(t) for t in l.split()] for l in txt[9:9 + 5000]])
+    assert np.allclose(va, V, rtol=1e-5, atol=0)  # six significant digits
+    # ---- SignedDistance2Color against numpy, PNG against three decoders
+    rows = {int(l.split()[1]): l.split()[2:] for l in lines if l.startswith("PNGRT")}
+    assert len(rows) == 6 and all(r == ["1", "1", "1"] for r in rows.values()), rows
+    assert [l for l in lines if l.startswith("PNGEMPTY")][0].split()[1] == "0"   # empty image: WritePng returns false
+    try:
+        from PIL import Image as PILImage
+    except ImportError:
+        PILImage = None
+    for i, sdf in enumerate(sdfs):
+        lo, hi = (np.float32(-0.25), np.float32(0.125)) if i == 3 else (np.float32(-1.0), np.float32(1.0))
+        d = sdf.astype(np.float32)
+        kp = np.minimum(np.maximum((hi - d) / hi, np.float32(0)), np.float32(1))          # voxel_carver.cc:251-252
+        kn = np.minimum(np.maximum((d - lo) / (-lo), np.float32(0)), np.float32(1))       # :258-259
+        cp = (np.float32(255) * kp).astype(np.uint8)                                      # truncation, as static_cast does
+        cn = (np.float32(255) * kn).astype(np.uint8)
+        pos = d > 0
+        want = np.stack([np.where(pos, 255, cn), np.where(pos, cp, cn), np.where(pos, cp, 255)], 2).astype(np.uint8)
+        got = np.fromfile(os.path.join(out, "vis_%d.rgb" % i), np.uint8).reshape(want.shape)
+        assert np.array_equal(got, want), i
+        if i == 3:  # both clamps fired, and the ramp in between is there
+            assert (cp[pos] == 0).any() and (cn[~pos] == 0).any() and len(np.unique(want)) > 20
+        w, h, ch, px = _png_decode_filter0(os.path.join(out, "vis_%d.png" % i))
+        assert (w, h, ch) == (want.shape[1], want.shape[0], 3) and np.array_equal(px, want)
+        w, h, ch, px = _png_decode_filter0(os.path.join(out, "mask_%d.png" % i))
+        assert ch == 1 and np.array_equal(px[:, :, 0], masks[i])
+        if PILImage is not None:
+            assert np.array_equal(np.asarray(PILImage.open(os.path.join(out, "vis_%d.png" % i))), want)
+            assert np.array_equal(np.asarray(PILImage.open(os.path.join(out, "mask_%d.png" % i))), masks[i])

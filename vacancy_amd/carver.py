@@ -470,6 +470,12 @@ class ClockProbe:
         self.stop()
         return False
 
+    def __del__(self):  # a probe that is dropped must not keep its wave resident (it also ends by itself after 2 s)
+        try:
+            self.stop()
+        except Exception:
+            pass
+
 
 def measure_bandwidth(device_id=0, nbytes=1 << 31, reps=3):
     """(read GB/s, device-to-device copy GB/s) measured on this GPU (vcy_measure_bandwidth)."""

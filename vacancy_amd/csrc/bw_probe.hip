@@ -31,16 +31,24 @@ __global__ __launch_bounds__(256) void bw_read_kernel(const float* __restrict__ 
 struct ClockSample {
   unsigned long long shader, real;
 };
+// The wave also ends by itself after `max_ticks` of the 100 MHz reference (kClockProbeMaxMs): while it is resident every
+// implicitly device-synchronising call of the workload (hipFree / hipMalloc of a growing pool, hipHostFree) blocks until
+// it has finished, so a probe nobody stops must not hold the device for long -- and the probed region must be warmed up
+// so that it allocates nothing (bench.py runs it behind the timed steps of a workload that has already run).
+constexpr int kClockProbeMaxSamples = 1 << 16;  // ~1.8 s at a sample every ~28 us
+constexpr double kClockProbeMaxMs = 2000.0;
 __global__ __launch_bounds__(64) void clock_probe_kernel(ClockSample* __restrict__ samples, int max_samples,
-                                                         const volatile int* __restrict__ stop, int* __restrict__ count) {
+                                                         const volatile int* __restrict__ stop, int* __restrict__ count,
+                                                         unsigned long long max_ticks) {
   if (threadIdx.x != 0) return;
   int k = 0;
+  const unsigned long long t_begin = wall_clock64();
   for (; k < max_samples; ++k) {
     ClockSample s;
     s.shader = __builtin_readcyclecounter();  // s_memtime
     s.real = wall_clock64();                  // s_memrealtime, 100 MHz
     samples[k] = s;
-    if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+    if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || s.real - t_begin > max_ticks) {
       ++k;
       break;
     }
@@ -63,7 +71,7 @@ struct vcy_clock_probe {
 
 extern "C" int vcy_clock_probe_start(int device_id, int max_samples, vcy_clock_probe** out) {
   using namespace vcy;
-  if (!out || max_samples < 2 || max_samples > (1 << 22)) {
+  if (!out || max_samples < 2 || max_samples > kClockProbeMaxSamples) {
     set_error("invalid argument");
     return VCY_ERR_INVALID_ARG;
   }
@@ -81,7 +89,8 @@ extern "C" int vcy_clock_probe_start(int device_id, int max_samples, vcy_clock_p
     e = hipMemsetAsync(p->d_count, 0, sizeof(int), p->stream);
   }
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, p->stream, p->d_samples, max_samples, p->h_stop, p->d_count);
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, p->stream, p->d_samples, max_samples, p->h_stop, p->d_count,
+                       (unsigned long long)(kClockProbeMaxMs * 1.0e5));
     e = hipGetLastError();
   }
   if (e != hipSuccess) {

@@ -36,6 +36,7 @@ struct RcclApi {
   ncclResult_t (*GetVersion)(int*) = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // (optional: the error path of the sharded producer)
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
@@ -97,6 +98,7 @@ bool load_rccl() {
   VCY_SYM(GroupEnd, "ncclGroupEnd");
   VCY_SYM(GetErrorString, "ncclGetErrorString");
 #undef VCY_SYM
+  *(void**)(&g_rccl.CommAbort) = dlsym(h, "ncclCommAbort");
   g_rccl.handle = h;
   return true;
 }
@@ -472,6 +474,20 @@ int vcy_carve_batch_silhouettes_sharded(vcy_ctx* const* slabs, int n_slabs, int 
   };
   HostBarrier barrier(R);
   const auto t_entry = std::chrono::steady_clock::now();
+  // A collective that failed on one rank after others had enqueued it: ncclCommAbort on every communicator of the group
+  // ends the stranded kernels; the group (and the producer with its streams) is dropped after the threads have joined
+  // and rebuilt by the next call.
+  std::atomic<bool> aborted(false);
+  std::mutex abort_mutex;
+  auto abort_group = [&]() {
+    std::lock_guard<std::mutex> lk(abort_mutex);
+    if (aborted.load() || !comm) return;
+    aborted.store(true);
+    for (ncclComm_t& cm : comm->comms) {
+      if (cm && g_rccl.CommAbort) (void)g_rccl.CommAbort(cm);
+      if (g_rccl.CommAbort) cm = nullptr;  // (aborted communicators are gone: destroy_group must not touch them)
+    }
+  };
 
   auto worker = [&](int r) {
     ProducerRank& pr = pg->ranks[(size_t)r];
@@ -561,9 +577,20 @@ int vcy_carve_batch_silhouettes_sharded(vcy_ctx* const* slabs, int n_slabs, int 
       }
       if (R > 1) {
         if (comm) {  // the exchange: ONE all-gather per chunk, every device receives every rank's images
-          if (failed.load() == VCY_OK) {
+          // Whether this chunk is gathered is decided JOINTLY: a rank that skipped the collective (its producer, a HIP
+          // call or its carve failed) while the others had enqueued theirs would leave them waiting for ever in their
+          // closing hipStreamSynchronize, with g_rccl_mutex held.  Every rank has finished what can fail before the
+          // first barrier; between the two barriers nobody writes `failed`, so every rank reads the same value.
+          barrier.wait();
+          const bool gather = failed.load() == VCY_OK;
+          barrier.wait();
+          if (gather) {
             const ncclResult_t nr = g_rccl.AllGather(send, pr.recv[set], send_bytes, ncclUint8, comm->comms[(size_t)r], pr.aux);
-            if (nr != ncclSuccess) fail(VCY_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(nr));
+            if (nr != ncclSuccess) {
+              // (some ranks may already have enqueued theirs: only aborting the communicators gets them out)
+              fail(VCY_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(nr));
+              abort_group();
+            }
           }
         } else {  // (test hook: several ranks on one device -- the same data movement as device copies)
           if (failed.load() == VCY_OK) hip_ok(hipEventRecord(pr.ev_sent, pr.aux), "hipEventRecord");
@@ -611,6 +638,12 @@ int vcy_carve_batch_silhouettes_sharded(vcy_ctx* const* slabs, int n_slabs, int 
   for (std::thread& t : threads) t.join();
   const float wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
   for (int s = 0; s < n_slabs; ++s) slabs[s]->stream_wall_ms = wall;
+  if (aborted.load()) {
+    g_groups.erase(std::remove(g_groups.begin(), g_groups.end(), comm), g_groups.end());
+    destroy_group(comm);
+    g_producers.erase(std::remove(g_producers.begin(), g_producers.end(), pg), g_producers.end());
+    destroy_producer(pg);
+  }
   (void)hipSetDevice(slabs[0]->device);
   if (failed.load() != VCY_OK) {
     set_error("%s", err_text.c_str());

@@ -1009,26 +1009,34 @@ __global__ __launch_bounds__(256) void add_chunk_offsets_kernel(u64* __restrict_
   if (i < n) data[i] += offs[i >> 10];
 }
 
-// The same in ONE launch (round 4; three launches before: chunks, their sums, the offsets added -- each a dependent
-// kernel boundary in the middle of an extraction made of short kernels): a workgroup scans its 1024 elements, publishes
-// its sum, and adds up the sums of the chunks before it, waiting for those that are not published yet.  A chunk only
-// ever waits for chunks with LOWER block indices, and every XCD's dispatcher starts its share of a grid (blocks
-// b = xcd mod 8) in increasing order: the lowest unfinished chunk of the grid is therefore always resident or next in
-// line on its XCD, whatever else occupies the device, it waits for nobody, and by induction every chunk gets there.
-// (Round 5 built the form that needs no assumption about dispatch order -- chunk numbers drawn as tickets from an
-// atomic counter -- for a single-pass prefix over the workgroups of mc_active / mc_owner: device-scope atomics on one
-// address retire at about one per 10 ns here, 0.33 ms for 32 768 workgroups; profiles/r05/mc_lookback.txt.  The grids
-// of this kernel are at most kChainedScanMaxChunks = 1024 blocks, fewer than the 2048 workgroups of this size the
-// device holds at once.)  Publication is (sum, epoch): the epoch grows with every scan of a context, so the flags are never cleared.
-// Every chunk reads all its predecessors -- quadratic, which is why this form is only taken up to kChainedScanMaxChunks
-// (1024^3: 64 chunks for the word blocks, about 10 for the surface cells).
+// The same in ONE launch (three launches otherwise: chunks, their sums, the offsets added -- each a dependent kernel
+// boundary in the middle of an extraction made of short kernels): a workgroup scans 1024 elements, publishes its sum,
+// and adds up the sums of the chunks before it, waiting for those that are not published yet.
+// WHICH chunk a workgroup scans is a ticket drawn from a device-scope counter when the workgroup starts, not its
+// blockIdx: chunk c is only ever waited for by chunks drawn AFTER it, i.e. by workgroups that started after the one
+// holding c did -- and that one is running, it needs nothing but its own data to publish.  Forward progress therefore
+// rests on no assumption about the order in which the dispatchers start workgroups, whatever else occupies the device
+// (other contexts' streams, a persistent probe wave, a long carve): the lowest unpublished ticket always belongs to a
+// resident workgroup.  One atomic per workgroup on one address retires at about one per 10 ns here; the grids of this
+// kernel are at most kChainedScanMaxChunks = 1024 blocks (1024^3: 64 chunks for the word blocks, about 10 for the
+// surface cells), i.e. 0.6 us and 0.1 us.  (That price is what ruled tickets out for a single-pass prefix over the
+// 32 768 workgroups of mc_active / mc_owner, profiles/r05/mc_lookback.txt -- not for this kernel.)
+// The counter is never cleared: the host passes the number of tickets drawn before this launch (`ticket_base`; every
+// launched workgroup draws exactly one).  Publication is (sum, epoch): the epoch grows with every scan of a context, so
+// the flags are never cleared either.  Every chunk reads all its predecessors -- quadratic, which is why this form is
+// only taken up to kChainedScanMaxChunks.
 constexpr int kChainedScanMaxChunks = 1024;
 __global__ __launch_bounds__(256) void scan_chained_kernel(u64* __restrict__ data, int64_t n, u64* __restrict__ chunk_sums,
                                                            uint32_t* __restrict__ chunk_flags, uint32_t epoch,
-                                                           u64* __restrict__ total) {
+                                                           u64* __restrict__ total, uint32_t* __restrict__ ticket,
+                                                           uint32_t ticket_base) {
   __shared__ u64 sm[256];
   __shared__ u64 sm_before;
-  const int chunk = blockIdx.x;
+  __shared__ int sm_chunk;
+  if (threadIdx.x == 0)
+    sm_chunk = (int)(__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base);
+  __syncthreads();
+  const int chunk = sm_chunk;  // 0 .. gridDim.x - 1, each exactly once
   const int64_t base = (int64_t)chunk * 1024 + (int64_t)threadIdx.x * 4;
   u64 v[4], s = 0;
 #pragma unroll
@@ -1073,14 +1081,25 @@ __global__ __launch_bounds__(256) void scan_chained_kernel(u64* __restrict__ dat
   if (chunk == (int)gridDim.x - 1 && threadIdx.x == 255) *total = run;  // (the last element's inclusive value)
 }
 
+// What a chained scan needs from its caller: the publication flags of ONE scan slot (kChainedScanMaxChunks words), the
+// slot's ticket counter and how many tickets have been drawn from it so far (advanced here).
+struct ChainedScanSlot {
+  uint32_t* flags;
+  uint32_t* ticket;
+  uint32_t* tickets_drawn;  // (host)
+  uint32_t epoch;
+};
+
 // in-place exclusive scan; *d_total (device) receives the grand total.  `scratch` holds the chunk
 // sums of every level (n/1024 + n/1024^2 + ... + a few elements).
-int exclusive_scan_u64(u64* d, int64_t n, u64* d_total, u64* scratch, hipStream_t stream, uint32_t* flags = nullptr,
-                       uint32_t epoch = 0) {
+int exclusive_scan_u64(u64* d, int64_t n, u64* d_total, u64* scratch, hipStream_t stream,
+                       const ChainedScanSlot* slot = nullptr) {
   const int64_t nchunks = (n + 1023) / 1024;
-  if (flags != nullptr && nchunks <= kChainedScanMaxChunks) {
-    hipLaunchKernelGGL(scan_chained_kernel, dim3((unsigned)nchunks), dim3(256), 0, stream, d, n, scratch, flags, epoch, d_total);
+  if (slot != nullptr && nchunks <= kChainedScanMaxChunks) {
+    hipLaunchKernelGGL(scan_chained_kernel, dim3((unsigned)nchunks), dim3(256), 0, stream, d, n, scratch, slot->flags,
+                       slot->epoch, d_total, slot->ticket, *slot->tickets_drawn);
     VCY_HIP_CHECK(hipGetLastError());
+    *slot->tickets_drawn += (uint32_t)nchunks;  // (modulo 2^32, like the counter)
     return VCY_OK;
   }
   hipLaunchKernelGGL(scan_chunks_kernel, dim3((unsigned)nchunks), dim3(256), 0, stream, d, n, scratch);
@@ -1484,11 +1503,22 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   // publication flags of the chained scans (scan_chained_kernel): an allocation of their own, zeroed once -- they
   // must never hold a FUTURE epoch, so they do not live in scratch whose layout changes with the extraction
   if (!c->d_mc_flags) {
-    VCY_HIP_CHECK(hipMalloc(&c->d_mc_flags, sizeof(uint32_t) * 2 * (size_t)kChainedScanMaxChunks));
-    VCY_HIP_CHECK(hipMemsetAsync(c->d_mc_flags, 0, sizeof(uint32_t) * 2 * (size_t)kChainedScanMaxChunks, s));
+    // [2 slots][kChainedScanMaxChunks] flags, then the two ticket counters
+    const size_t fbytes = sizeof(uint32_t) * (2 * (size_t)kChainedScanMaxChunks + 2);
+    VCY_HIP_CHECK(hipMalloc(&c->d_mc_flags, fbytes));
+    VCY_HIP_CHECK(hipMemsetAsync(c->d_mc_flags, 0, fbytes, s));
     c->mc_scan_epoch = 0;
+    c->mc_scan_tickets[0] = c->mc_scan_tickets[1] = 0;
   }
   uint32_t* d_flags = (uint32_t*)c->d_mc_flags;
+  auto scan_slot = [&](int which) {
+    ChainedScanSlot sl;
+    sl.flags = d_flags + which * kChainedScanMaxChunks;
+    sl.ticket = d_flags + 2 * kChainedScanMaxChunks + which;
+    sl.tickets_drawn = &c->mc_scan_tickets[which];
+    sl.epoch = ++c->mc_scan_epoch;
+    return sl;
+  };
   u64* d_total = (u64*)base;
   p.in = d_in;
   p.ok = d_ok;
@@ -1611,7 +1641,11 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
                        d_woff, d_wcounts, (int64_t)nblocks);
   }
   MC_TRY(hipGetLastError());
-  int rc = exclusive_scan_u64(d_wcounts, nblocks, d_total, d_scan, s, d_flags, ++c->mc_scan_epoch);
+  int rc;
+  {
+    const ChainedScanSlot sl = scan_slot(0);
+    rc = exclusive_scan_u64(d_wcounts, nblocks, d_total, d_scan, s, &sl);
+  }
   if (rc != VCY_OK) return rc;
 
   // ---- the surface cells ------------------------------------------------------------------------
@@ -1655,7 +1689,8 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
     hipLaunchKernelGGL(mc_owner_kernel, dim3(b.blocks), dim3(256), 0, s, p, T, d_act, b.list, d_total, cap_cells, b.info,
                        b.nact, b.counts);
     MC_TRY(hipGetLastError());
-    return exclusive_scan_u64(b.counts, b.blocks, b.total, b.scan, s, d_flags + kChainedScanMaxChunks, ++c->mc_scan_epoch);
+    const ChainedScanSlot sl = scan_slot(1);
+    return exclusive_scan_u64(b.counts, b.blocks, b.total, b.scan, s, &sl);
   };
   // output staging, cached in the context and grown on demand; then the emit pass
   auto enqueue_emit = [&](const CellBuffers& b, int64_t cap_cells, int64_t cap_v, int64_t cap_f) -> int {

@@ -144,28 +144,45 @@ int count_width_for(const vcy_ctx* c, int64_t max_count) {
   return std::min(w, c->cnt_bytes_wire);
 }
 
-// Re-allocates d_cnt at `bytes` per counter, converting what it holds (nothing on a fresh slab).
+// Switches d_cnt to `bytes` per counter, converting what it holds (nothing on a fresh slab).  The array of the other
+// width is KEPT (d_cnt_spare) once both exist: a vcy_reset followed by a carve across the 256th view used to pay two
+// allocations of 1 - 2 GB, two device-wide synchronisations (hipFree) and a pipeline stall per cycle.  The conversion is
+// ordered on the context's stream like every other access to the counters, so nothing waits here either.
 static int set_count_width(vcy_ctx* c, int bytes) {
   if (bytes == c->cnt_bytes) return VCY_OK;
   const int64_t nvox = c->slice * (int64_t)(c->halo_lo + c->nz_local());
+  const size_t need = (size_t)nvox * bytes;
   void* d_new = nullptr;
-  VCY_HIP_CHECK(hipMalloc(&d_new, (size_t)nvox * bytes));
+  size_t new_cap = 0;
+  if (c->d_cnt_spare && c->cnt_spare_cap >= need) {
+    d_new = c->d_cnt_spare;
+    new_cap = c->cnt_spare_cap;
+    c->d_cnt_spare = nullptr;
+    c->cnt_spare_cap = 0;
+  } else {
+    VCY_HIP_CHECK(hipMalloc(&d_new, need));
+    new_cap = need;
+  }
   int rc = VCY_OK;
   if (!c->fresh) {
     rc = convert_counts(c->stream, c->d_cnt, c->cnt_bytes, d_new, bytes, nvox);
   } else if (c->halo_lo && c->halo_valid) {
     rc = convert_counts(c->stream, c->d_cnt, c->cnt_bytes, d_new, bytes, c->slice * (int64_t)c->halo_lo);
   }
-  if (rc == VCY_OK && hipStreamSynchronize(c->stream) != hipSuccess) {
-    set_error("counter widening failed");
-    rc = VCY_ERR_HIP;
-  }
   if (rc != VCY_OK) {
+    (void)hipStreamSynchronize(c->stream);
     (void)hipFree(d_new);
     return rc;
   }
-  (void)hipFree(c->d_cnt);
+  // the old array becomes the spare (a smaller spare that was passed over goes back to the allocator)
+  if (c->d_cnt_spare) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_cnt_spare);
+  }
+  c->d_cnt_spare = c->d_cnt;
+  c->cnt_spare_cap = c->cnt_cap;
   c->d_cnt = d_new;
+  c->cnt_cap = new_cap;
   c->cnt_bytes = bytes;
   return VCY_OK;
 }
@@ -191,11 +208,8 @@ int fill_state(vcy_ctx* c) {
   c->views_carved = 0;
   c->halo_valid = false;
   c->cnt_implied = true;
-  // counters start over at one byte (fresh: nothing to convert; the wide array goes back to the allocator)
-  if (c->d_cnt && c->cnt_bytes != count_width_for(c, 0)) {
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    return set_count_width(c, count_width_for(c, 0));
-  }
+  // counters start over at one byte (fresh: nothing to convert; the wide array is kept as the spare)
+  if (c->d_cnt && c->cnt_bytes != count_width_for(c, 0)) return set_count_width(c, count_width_for(c, 0));
   return VCY_OK;
 }
 
@@ -418,6 +432,7 @@ int vcy_create(const vcy_carver_option* o, int device_id, int z_begin, int z_end
   const int64_t nvox = c->slice * (int64_t)(c->halo_lo + c->nz_local());
   VCY_TRY(hipMalloc(&c->d_sdf, (size_t)nvox * sizeof(float)));
   VCY_TRY(hipMalloc(&c->d_cnt, (size_t)nvox * c->cnt_bytes));
+  c->cnt_cap = (size_t)nvox * c->cnt_bytes;
   VCY_TRY(hipMalloc(&c->d_px, sizeof(float) * n[0]));
   VCY_TRY(hipMalloc(&c->d_py, sizeof(float) * n[1]));
   VCY_TRY(hipMalloc(&c->d_pz, sizeof(float) * n[2]));
@@ -466,6 +481,8 @@ void vcy_destroy(vcy_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   (void)hipFree(c->d_sdf);
   (void)hipFree(c->d_cnt);
+  (void)hipFree(c->d_cnt_spare);
+  (void)hipFree(c->d_halo_tmp);
   (void)hipFree(c->d_px);
   (void)hipFree(c->d_py);
   (void)hipFree(c->d_pz);
@@ -994,24 +1011,34 @@ int vcy_halo_copy_from(vcy_ctx* c, vcy_ctx* below) {
   }
   VCY_HIP_CHECK(hipSetDevice(below->device));
   { int rcm = materialize(below); if (rcm != VCY_OK) return rcm; }
-  if (below->cnt_bytes != c->cnt_bytes) {  // (slabs that have not seen the same number of views: the wider width for both)
-    const int wide = std::max(below->cnt_bytes, c->cnt_bytes);
-    int rcw = set_count_width(below, wide);
-    if (rcw == VCY_OK) {
-      VCY_HIP_CHECK(hipSetDevice(c->device));
-      { int rcm = flush_pending(c); if (rcm != VCY_OK) return rcm; }
-      rcw = set_count_width(c, wide);
-    }
-    if (rcw != VCY_OK) return rcw;
-    VCY_HIP_CHECK(hipSetDevice(below->device));
-  }
   VCY_HIP_CHECK(hipStreamSynchronize(below->stream));  // its carve must have finished
   VCY_HIP_CHECK(hipSetDevice(c->device));
+  { int rcm = flush_pending(c); if (rcm != VCY_OK) return rcm; }
   const int64_t s = c->slice;
   const float* sdf_src = below->owned_slab_sdf() + (int64_t)(below->nz_local() - 2) * s;
-  const char* cnt_src = (const char*)below->owned_slab_cnt() + (int64_t)(below->nz_local() - 2) * s * c->cnt_bytes;
+  const char* cnt_src = (const char*)below->owned_slab_cnt() + (int64_t)(below->nz_local() - 2) * s * below->cnt_bytes;
   VCY_HIP_CHECK(hipMemcpyPeerAsync(c->d_sdf, c->device, sdf_src, below->device, 2 * s * sizeof(float), c->stream));
-  VCY_HIP_CHECK(hipMemcpyPeerAsync(c->d_cnt, c->device, cnt_src, below->device, 2 * s * c->cnt_bytes, c->stream));
+  if (below->cnt_bytes == c->cnt_bytes) {
+    VCY_HIP_CHECK(hipMemcpyPeerAsync(c->d_cnt, c->device, cnt_src, below->device, 2 * s * c->cnt_bytes, c->stream));
+  } else {
+    // Slabs that have not seen the same number of views hold counters of different widths.  Neither array is
+    // re-allocated for the exchange (the neighbour's would be, from THIS caller's thread, while its own driver thread may
+    // be using it): its two slices travel as they are into a staging buffer of this context and are converted into this
+    // slab's width behind the copy -- widening is exact, narrowing saturates, and halo counters are only ever read as
+    // `update_num >= 1` (convert_counts_kernel).
+    const size_t tmp_need = (size_t)(2 * s) * below->cnt_bytes;
+    if (c->halo_tmp_bytes < tmp_need) {
+      VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
+      (void)hipFree(c->d_halo_tmp);
+      c->d_halo_tmp = nullptr;
+      c->halo_tmp_bytes = 0;
+      VCY_HIP_CHECK(hipMalloc(&c->d_halo_tmp, tmp_need));
+      c->halo_tmp_bytes = tmp_need;
+    }
+    VCY_HIP_CHECK(hipMemcpyPeerAsync(c->d_halo_tmp, c->device, cnt_src, below->device, tmp_need, c->stream));
+    const int rcc = convert_counts(c->stream, c->d_halo_tmp, below->cnt_bytes, c->d_cnt, c->cnt_bytes, 2 * s);
+    if (rcc != VCY_OK) return rcc;
+  }
   c->halo_valid = true;
   return VCY_OK;
 }

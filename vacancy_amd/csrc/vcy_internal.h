@@ -71,6 +71,11 @@ struct vcy_ctx {
 
   float* d_sdf = nullptr;      // includes halo slices
   void* d_cnt = nullptr;
+  void* d_cnt_spare = nullptr;        // the counter array of the OTHER width, kept once it exists (set_count_width): a
+  size_t cnt_spare_cap = 0;           // reset / carve cycle across the 256th view then allocates and frees nothing
+  size_t cnt_cap = 0;                 // bytes allocated behind d_cnt
+  void* d_halo_tmp = nullptr;         // two slices of a neighbour's counters at ITS width (vcy_halo_copy_from)
+  size_t halo_tmp_bytes = 0;
   float* d_px = nullptr;
   float* d_py = nullptr;
   float* d_pz = nullptr;
@@ -162,6 +167,7 @@ struct vcy_ctx {
   size_t mc_scratch_bytes = 0;
   void* d_mc_flags = nullptr;         // publication flags of the chained scans (mc_kernels.hip, scan_chained_kernel)
   uint32_t mc_scan_epoch = 0;         // ... and the epoch of the last scan (flags never hold a later one)
+  uint32_t mc_scan_tickets[2] = {0, 0};  // chunk tickets drawn so far from the two scan slots' counters (scan_chained_kernel)
   void* d_mc_cells = nullptr;         // per-active-cell arrays of the extraction
   size_t mc_cells_bytes = 0;
   void* d_mc_out = nullptr;           // device staging of the extracted mesh

@@ -189,14 +189,18 @@ def carve_silhouettes_sharded(carvers, rank, world, views, silhouettes, chunk=32
         t0 = time.perf_counter()
         mine = list(range(rank, m, world))
         if mine:
-            outs = [send.data_ptr() + 4 * k * stride for k in range(len(mine))]
+            # (vcy_make_sdf_batch_device returns with the images complete: it waits for the context's stream.  A job of ONE
+            # rank builds them in place in the set the carve reads -- there is nothing to exchange, and a device copy on
+            # torch's stream would be ordered against neither the carvers' own streams nor the next chunk's producer)
+            target = rv if world == 1 else send
+            outs = [target.data_ptr() + 4 * k * stride for k in range(len(mine))]
             ok = c0.make_sdf_batch_into([views[first + j] for j in mine], [silhouettes[first + j] for j in mine], outs)
             if not ok:
                 from .carver import last_error
                 raise RuntimeError("vcy_make_sdf_batch_device: " + last_error())
         t1 = time.perf_counter()
         if world == 1:
-            rv[:per * stride].copy_(send)
+            pass  # built in place, above
         elif on_gpu:
             torch.cuda.current_stream().synchronize()
             dist.all_gather_into_tensor(rv, send)  # the exchange step of the streamed path

@@ -7,6 +7,7 @@
 
 #include "vacancy/camera.h"
 #include "vacancy/image.h"
+#include "vacancy/mesh.h"
 #include "vacancy/voxel_carver.h"
 
 namespace {
@@ -52,6 +53,58 @@ int main(int argc, char* argv[]) {
     long long touched = 0;
     for (int k : n) touched += k > 0;
     std::printf("CUSTOMCAM %d %d %d %d %d %lld\n", a ? 1 : 0, b ? 1 : 0, c ? 1 : 0, d ? 1 : 0, e ? 1 : 0, touched);
+    return 0;
+  }
+  if (argc > 3 && std::string(argv[2]) == "io") {
+    // Host outputs nothing else looks at (rows f3 / f4): tests/test_host.py reads every byte of these files back.
+    //   <out>/mesh_ascii.ply, mesh_binary.ply, mesh_empty.ply: the same small mesh through both writers
+    //   <out>/sdf_<i>.f32 (written by the test) -> SignedDistance2Color -> <out>/vis_<i>.rgb (raw) and vis_<i>.png
+    //   PNGRT lines: WritePng -> Load gives the pixels back (1 and 3 channels)
+    const std::string out = argv[3];
+    vacancy::Mesh mesh;
+    std::vector<Eigen::Vector3f> v;
+    std::vector<Eigen::Vector3i> f;
+    for (int i = 0; i < 5000; ++i)  // (values with short and long %g forms, negative zero, denormal-free)
+      v.push_back(Eigen::Vector3f(0.1f * i - 250.0f, 1.0f / (1.0f + i), (i % 7) * -1234.5678f));
+    for (int i = 0; i < 9000; ++i) f.push_back(Eigen::Vector3i(i % 5000, (i * 7 + 1) % 5000, (i * 13 + 2) % 5000));
+    mesh.set_vertices(v);
+    mesh.set_vertex_indices(f);
+    bool ok = mesh.WritePly(out + "/mesh_ascii.ply") && mesh.WritePlyBinary(out + "/mesh_binary.ply");
+    vacancy::Mesh empty;
+    ok = ok && empty.WritePlyBinary(out + "/mesh_empty.ply");
+    ok = ok && !mesh.WritePlyBinary(out + "/no/such/dir/x.ply");
+    std::printf("PLY %d %zu %zu\n", ok ? 1 : 0, v.size(), f.size());
+    for (int i = 0; i < 6; ++i) {
+      vacancy::Image1b m;
+      if (!m.Load(dir + "/mask_" + vacancy::zfill(i) + ".png")) return 1;
+      vacancy::Image1f sdf(m.width(), m.height());
+      std::FILE* fp = std::fopen((out + "/sdf_" + std::to_string(i) + ".f32").c_str(), "rb");
+      if (!fp) return 4;
+      const size_t n = sdf.data().size();
+      if (std::fread(sdf.data_ptr()->data(), sizeof(float), n, fp) != n) return 5;
+      std::fclose(fp);
+      vacancy::Image3b vis;
+      // (the ranges examples.cc passes: -1 .. 1 for normalised fields; view 3 with a narrower one so that both clamps fire)
+      const float lo = i == 3 ? -0.25f : -1.0f, hi = i == 3 ? 0.125f : 1.0f;
+      vacancy::SignedDistance2Color(sdf, &vis, lo, hi);
+      fp = std::fopen((out + "/vis_" + std::to_string(i) + ".rgb").c_str(), "wb");
+      if (!fp) return 6;
+      std::fwrite(vis.data().data(), 1, vis.data().size(), fp);
+      std::fclose(fp);
+      bool rt = vis.WritePng(out + "/vis_" + std::to_string(i) + ".png");
+      vacancy::Image3b back;
+      rt = rt && back.Load(out + "/vis_" + std::to_string(i) + ".png") && back.width() == vis.width() &&
+           back.height() == vis.height() && back.data() == vis.data();
+      bool rt1 = m.WritePng(out + "/mask_" + std::to_string(i) + ".png");
+      vacancy::Image1b back1;
+      rt1 = rt1 && back1.Load(out + "/mask_" + std::to_string(i) + ".png") && back1.data() == m.data() &&
+            back1.width() == m.width();
+      vacancy::Image3b wrong;
+      const bool refuses = !wrong.Load(out + "/mask_" + std::to_string(i) + ".png");  // 1 channel into a 3-channel image
+      std::printf("PNGRT %d %d %d %d\n", i, rt ? 1 : 0, rt1 ? 1 : 0, refuses ? 1 : 0);
+    }
+    vacancy::Image1b none;
+    std::printf("PNGEMPTY %d\n", none.WritePng(out + "/none.png") ? 1 : 0);
     return 0;
   }
   for (int i = 0; i < 6; ++i) {

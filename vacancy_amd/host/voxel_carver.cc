@@ -52,21 +52,32 @@ vcy_view ToView(const Camera& camera, const Eigen::Vector2i& roi_min, const Eige
 // (voxel_carver.cc:435,492-493) runs when the queue is applied -- inside the next call that reads the state.  The
 // library keeps HIP-event times of every fused launch ("carvetimer"); they are logged here, one line per launch, in the
 // reference's words, by the calls that apply the queue.
-void LogAppliedCarves(vcy_ctx* ctx) {
-  constexpr int kMax = 256;
-  float pre[kMax], ker[kMax];
-  int32_t first[kMax];
-  int n = 0;
-  if (vcy_carve_log(ctx, kMax, nullptr, pre, ker, first, &n, 1) != VCY_OK) return;
-  double ms = 0.0;
-  for (int i = 0; i < n; ++i) {
-    if (first[i] && i > 0) {
-      LOGI("VoxelCarver::Carve main loop %02f\n", ms);
-      ms = 0.0;
+// The timer costs three event records per fused launch: it is only on while the log level emits LOGI (checked at every
+// call that applies the queue, so a level changed after Init is followed; `*timer_on` is the facade's view of the param).
+void LogAppliedCarves(vcy_ctx* ctx, bool* timer_on) {
+  const bool want = get_log_level() <= LogLevel::kInfo;
+  if (*timer_on) {
+    // every record the library holds (its log ends at 8192 launches, vcy_carve_log), not a first screenful of them
+    constexpr int kCap = 8192;
+    std::vector<float> pre(kCap), ker(kCap);
+    std::vector<int32_t> first(kCap);
+    int n = 0;
+    if (vcy_carve_log(ctx, kCap, nullptr, pre.data(), ker.data(), first.data(), &n, 1) == VCY_OK && want) {
+      double ms = 0.0;
+      for (int i = 0; i < n; ++i) {
+        if (first[i] && i > 0) {
+          LOGI("VoxelCarver::Carve main loop %02f\n", ms);
+          ms = 0.0;
+        }
+        ms += static_cast<double>(pre[i]) + ker[i];
+      }
+      if (n > 0) LOGI("VoxelCarver::Carve main loop %02f\n", ms);
     }
-    ms += static_cast<double>(pre[i]) + ker[i];
   }
-  if (n > 0) LOGI("VoxelCarver::Carve main loop %02f\n", ms);
+  if (want != *timer_on) {
+    vcy_set_param(ctx, "carvetimer", want ? 1 : 0);
+    *timer_on = want;
+  }
 }
 }  // namespace
 
@@ -133,6 +144,7 @@ struct VoxelCarver::Impl {
   VoxelCarverOption option;
   vcy_ctx* ctx = nullptr;
   int device = 0;
+  bool carve_timer = false;  // "carvetimer" as last set by this facade (LogAppliedCarves)
   ~Impl() { vcy_destroy(ctx); }
 };
 
@@ -169,7 +181,8 @@ bool VoxelCarver::Init() {
   // one context holds the whole grid: no slab merge, so the mesh needs no edge keys (the reference's
   // MarchingCubes returns vertices and faces)
   vcy_set_param(impl_->ctx, "meshkeys", 0);
-  vcy_set_param(impl_->ctx, "carvetimer", 1);  // (three events per fused launch: LogAppliedCarves)
+  impl_->carve_timer = get_log_level() <= LogLevel::kInfo;  // (three events per fused launch: only when they are logged)
+  vcy_set_param(impl_->ctx, "carvetimer", impl_->carve_timer ? 1 : 0);
   return true;
 }
 
@@ -252,7 +265,7 @@ bool VoxelCarver::Carve(const std::vector<const Camera*>& cameras, const std::ve
   // masks are streamed to the device, SDFs built there, views fused in chunks of 32
   const bool ok = vcy_carve_batch_silhouettes(impl_->ctx, n, views.data(), masks.data()) == VCY_OK;
   if (!ok) LOGE("%s\n", vcy_last_error());
-  LogAppliedCarves(impl_->ctx);
+  LogAppliedCarves(impl_->ctx, &impl_->carve_timer);
   return ok;
 }
 
@@ -264,9 +277,10 @@ void VoxelCarver::ExtractIsoSurface(Mesh* mesh, double iso_level, bool linear_in
   if (vcy_extract_iso(impl_->ctx, iso_level, linear_interp ? 1 : 0, &m) != VCY_OK) {
     LOGE("%s\n", vcy_last_error());
     vcy_mesh_free(&m);
+    LogAppliedCarves(impl_->ctx, &impl_->carve_timer);  // (the queue may have been applied before the failure)
     return;
   }
-  LogAppliedCarves(impl_->ctx);
+  LogAppliedCarves(impl_->ctx, &impl_->carve_timer);
   static_assert(sizeof(Eigen::Vector3f) == 3 * sizeof(float), "packed vector layout");
   static_assert(sizeof(Eigen::Vector3i) == 3 * sizeof(int), "packed vector layout");
   std::vector<Eigen::Vector3f>* v = mesh->mutable_vertices();
@@ -287,9 +301,10 @@ void VoxelCarver::ExtractVoxel(Mesh* mesh, bool inside_empty) {
   if (vcy_extract_voxel(impl_->ctx, inside_empty ? 1 : 0, &m) != VCY_OK) {
     LOGE("%s\n", vcy_last_error());
     vcy_mesh_free(&m);
+    LogAppliedCarves(impl_->ctx, &impl_->carve_timer);
     return;
   }
-  LogAppliedCarves(impl_->ctx);
+  LogAppliedCarves(impl_->ctx, &impl_->carve_timer);
   std::vector<Eigen::Vector3f>* v = mesh->mutable_vertices();
   std::vector<Eigen::Vector3i>* f = mesh->mutable_vertex_indices();
   v->resize(static_cast<size_t>(m.n_vertices));
@@ -313,7 +328,7 @@ bool VoxelCarver::Download(std::vector<float>* sdf, std::vector<int>* update_num
   if (sdf) sdf->resize(total);
   if (update_num) update_num->resize(total);
   const bool ok = vcy_download(impl_->ctx, sdf ? sdf->data() : nullptr, update_num ? update_num->data() : nullptr) == VCY_OK;
-  LogAppliedCarves(impl_->ctx);
+  LogAppliedCarves(impl_->ctx, &impl_->carve_timer);
   return ok;
 }
 
