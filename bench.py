@@ -99,6 +99,9 @@ def parse(argv=None):
                     help="N > 1: merge the slabs' meshes by edge key and compare them, array for array, with the mesh a "
                          "single context holding the whole grid extracts after the same views (on rank 0's GPU; outside "
                          "the timed region)")
+    ap.add_argument("--no-preflight", action="store_true",
+                    help="N > 1: skip the small-grid run of the whole sharded path (carve, halo all-gather, extraction, merge "
+                         "against a single context) that precedes the timed region by default")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="no GPU work: launch, rendezvous and the halo all-gather of this configuration with "
                          "rank-stamped host buffers (CPU test of the multi-rank launch path)")
@@ -309,6 +312,120 @@ def bytes_per_voxel_view(mode, nv, uo):
     return 4.0 if mode == "default" else 4.0 + (1 if min(nv, uo.voxel_max_update_num + 1) <= 255 else 2)
 
 
+def contract_roofline(roofline, *, mode, cull, n, nv, bpv, launches_per_step, pairs_frac, variants, mc, configs, build, world):
+    """The `roofline` object of the JSON line as the contract reads it: `achieved`, `frac` and `avg_launch_ms` are SURVEY
+    8(d)'s figure -- algorithmic bytes of EVERY voxel*view / duration of the carve kernel -- for a launch that really
+    evaluates every voxel*view: the same kernel with view dropping off, measured in this run right after the timed region
+    (`frac_source` says so).  The headline launch drops (brick, view) pairs that provably change nothing and keeps the
+    state in registers across the views, so the same formula applied to IT is not a bandwidth fraction (it exceeds 1);
+    that figure moves to `headline_kernel.per_view_api_equivalent`, next to the per-processed-pair fraction.  Everything a
+    reader needs to recompute the fractions of this line sits inside this object (the driver's record keeps `config`,
+    `roofline` and `cpu_baseline` only): marching cubes by device and by wall time, the single-view launches of the
+    reference's own call pattern, the other single-GPU configurations."""
+    vv_bytes = float(n) ** 3 * nv * bpv  # whole grid, all views (all ranks together)
+    head = {"avg_launch_ms": roofline.get("avg_launch_ms"), "algorithmic_bytes_per_launch": roofline.get("algorithmic_bytes_per_launch"),
+            "traffic": roofline.get("traffic"), "hbm_real_gbs": roofline.get("hbm_real_gbs"),
+            "hbm_real_frac": roofline.get("hbm_real_frac"), "pairs_processed_frac": pairs_frac,
+            "per_view_api_equivalent": {"gbs": roofline.get("achieved"), "frac": roofline.get("frac"),
+                                        "note": "algorithmic bytes of every voxel*view / this launch's duration: what a per-view "
+                                                "implementation (the reference's API, one state read per voxel*view) would have to "
+                                                "stream to finish the same work in the same time -- NOT bytes this kernel moves"}}
+    if isinstance(pairs_frac, (int, float)) and roofline.get("achieved"):
+        head["frac_processed_pairs"] = round(pairs_frac * roofline["achieved"] / HBM_PEAK_GBS, 4)
+        head["frac_processed_pairs_note"] = ("pairs_processed_frac x algorithmic bytes / this launch's duration / peak: the rate at "
+                                             "which the (brick, view) pairs that are really evaluated go through the kernel")
+    for k in ("valu_issue_frac_flat2", "valu_issue_frac_flat2_live", "valu_wave_insts_per_launch", "valu_insts_per_voxel_view",
+              "shader_clock_ghz_profiled", "traffic_note"):
+        if k in roofline:
+            head[k] = roofline[k]
+    src = None
+    c0 = (variants or {}).get("cull0") if cull else None
+    if cull and isinstance(c0, dict) and c0.get("kernel_ms"):
+        ker = c0["kernel_ms"]
+        roofline["achieved"] = round(vv_bytes / (ker * 1e-3) / 1e9, 1)
+        roofline["avg_launch_ms"] = round(ker / launches_per_step, 4)
+        roofline["step_device_ms_dropping_off"] = c0.get("ms_per_step")
+        ctr0, why0 = load_counters("%s_%d_%d_b1_c0" % (mode, n, nv), build) if world == 1 else (None, "counters are collected on one GPU")
+        roofline["traffic"] = ctr0.get("hbm_bytes_per_launch") if ctr0 else None
+        if ctr0 is None:
+            roofline["traffic_note"] = why0
+        src = ("carve_fused_kernel with view dropping OFF (vcy_set_param cull 0): every voxel*view of the workload evaluated, "
+               "same grid, views and images, measured in this run after the timed region (variants.cull0)")
+    elif cull and "frac_processed_pairs" in head:
+        roofline["achieved"] = round(head["frac_processed_pairs"] * HBM_PEAK_GBS, 1)
+        src = "processed pairs only (no dropping-off run in this invocation): pairs_processed_frac x algorithmic bytes / duration"
+    elif cull:
+        # (neither a dropping-off run nor a pair count: nothing that is a fraction can be stated)
+        roofline["achieved"] = None
+        src = "unavailable: run without --no-variants (dropping-off launch) or on one GPU (pair count)"
+    else:
+        src = "the timed launch itself (view dropping is off: every voxel*view evaluated)"
+    roofline["frac"] = round(roofline["achieved"] / HBM_PEAK_GBS, 4) if roofline.get("achieved") else None
+    roofline["frac_source"] = src
+    roofline["bound"] = "hbm"
+    roofline["bound_note"] = ("the contract's roof (SURVEY 8d: algorithmic HBM bytes); what binds the kernel in practice is VALU "
+                              "issue: frac_binding / issue_floor / headline_kernel.valu_issue_frac_flat2")
+    roofline["headline_kernel"] = head
+    for k in ("hbm_real_gbs", "hbm_real_frac", "valu_issue_frac_flat2", "valu_issue_frac_flat2_live", "valu_wave_insts_per_launch",
+              "valu_insts_per_voxel_view", "algorithmic_bytes_per_launch", "note", "bound_contract", "bound_actual",
+              "frac_of_measured_read", "frac_every_voxel_view"):
+        roofline.pop(k, None)
+    roofline["algorithmic_bytes_per_launch"] = vv_bytes / launches_per_step / max(1, world)
+    roofline["algorithmic_bytes_per_voxel_view"] = bpv
+    if roofline.get("measured_read_gbs") and roofline.get("achieved"):
+        roofline["frac_of_measured_read"] = round(roofline["achieved"] / roofline["measured_read_gbs"], 4)
+    # marching cubes, the second half of the metric: device (kernels) and wall (call -> mesh in host memory)
+    if isinstance(mc, dict) and "device_ms" in mc:
+        cells = float(n - 1) ** 3
+        roofline["mc"] = {k: mc.get(k) for k in ("device_ms", "wall_ms", "mcells_per_s", "mcells_per_s_wall", "roofline_frac",
+                                                 "roofline_frac_wall", "traffic", "vertices", "faces",
+                                                 "device_ms_every_brick_read", "roofline_frac_every_brick_read")}
+        roofline["mc"]["cells"] = cells
+        roofline["mc"]["algorithmic_bytes_per_cell"] = 4.0
+    # the reference's call pattern (one view per launch) and the other modes, from the same run
+    pv = {}
+    for name in ("per_view_interleaved", "per_view_defer0", "per_view_tsdf"):
+        r = (variants or {}).get(name)
+        if isinstance(r, dict) and "value" in r:
+            pv[name] = {k: r.get(k) for k in ("value", "carve_ms_first_view", "carve_ms_per_view_after_first", "algorithmic_frac",
+                                              "mc_device_ms_median", "mc_wall_ms_median", "mode")}
+    if pv:
+        roofline["per_view_launches"] = pv
+    modes = {}
+    for name in ("cull0", "tsdf", "hard_scene", "two_batches", "new_views_every_step"):
+        r = (variants or {}).get(name)
+        if isinstance(r, dict) and "value" in r:
+            modes[name] = {k: r.get(k) for k in ("value", "ms_per_step", "kernel_ms", "prepass_ms", "algorithmic_frac_kernel_alone",
+                                                 "pairs_processed_frac", "mode")}
+    if modes:
+        roofline["same_kernel_other_workloads"] = modes
+    st = (variants or {}).get("streamed_silhouettes")
+    if isinstance(st, dict) and "wall_ms" in st:
+        roofline["streamed_silhouettes"] = {k: st.get(k) for k in ("wall_ms", "producer_ms", "carve_ms", "overlap", "value_pcie_inclusive")}
+    if isinstance(configs, dict):
+        side = {}
+        for key, r in configs.items():
+            if not isinstance(r, dict) or "value" not in r:
+                continue
+            e = {"workload": r.get("workload"), "value": r.get("value"), "ms_per_step": r.get("ms_per_step")}
+            rf = r.get("roofline")
+            if isinstance(rf, dict):
+                e.update({"per_view_api_equivalent_frac" if r.get("workload", "").find("default") >= 0 else "frac": rf.get("frac"),
+                          "kernel_ms_per_step": rf.get("kernel_ms_per_step"), "prepass_ms_per_step": rf.get("prepass_ms_per_step"),
+                          "traffic": rf.get("traffic"), "hbm_real_frac": rf.get("hbm_real_frac"),
+                          "valu_issue_frac_flat2": rf.get("valu_issue_frac_flat2")})
+            for k in ("sequence_wall_ms", "carve_wall_ms", "extract_voxel_wall_ms", "mc_wall_ms"):
+                if k in r:
+                    e[k] = r[k]
+            if isinstance(r.get("mc"), dict):
+                e["mc"] = {k: r["mc"].get(k) for k in ("device_ms", "wall_ms", "mcells_per_s", "mcells_per_s_wall", "roofline_frac",
+                                                      "roofline_frac_wall")}
+            side[key] = e
+        if side:
+            roofline["other_configs"] = side
+    return roofline
+
+
 def side_config(device, build, label, n, nv, w, h, mode, steps, warmup=1, settle_ms=40.0, mc_runs=3):
     """One of BASELINE.json's OTHER single-GPU configurations, measured in the same process after the headline's timed
     region (so that the driver's record holds a number for each): the same step -- reset + fused carve of nv resident SDF
@@ -391,6 +508,7 @@ def side_config(device, build, label, n, nv, w, h, mode, steps, warmup=1, settle
                          "mcells_per_s": round(cells / (dv * 1e-3) / 1e6, 1),
                          "mcells_per_s_wall": round(cells / (wl * 1e-3) / 1e6, 1),
                          "roofline_frac": round(cells * 4.0 / (dv * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "roofline_frac_wall": round(cells * 4.0 / (wl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "vertices": int(nvert), "faces": int(nface)}
         except Exception as e:
             rec["mc"] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -498,6 +616,35 @@ def run_inprocess(args, why=None):
     # inputs resident in HBM of every device before the timed region
     imgs = [cs[0].upload_sdf(sdf0) for cs in sh.by_device]
     batches = [vc.VoxelCarver.prepare_batch(views, [imgs[g]] * nv) for g in range(G)]
+    # before anything is timed: the whole sharded path once on a small grid, merged mesh against a single context
+    # (the one-process-per-GPU form does the same; config.preflight_mesh_check)
+    preflight = None
+    if G * k > 1 and not args.no_preflight and args.batch:
+        try:
+            from vacancy_amd import dist as vdist_
+            pn, pnv = 256, 8
+            popt = synth.sphere_option(pn, uo)
+            pviews, pmasks = synth.sphere_views(pn, pnv, 320, 240)
+            psdf = vc.make_sdf(pmasks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
+            psh = ShardedVoxelCarver(popt, devices, k)
+            if not psh.Init():
+                raise RuntimeError(vc.last_error())
+            psh.set_param("cull", args.cull)
+            psh.set_param("meshkeys", 1)
+            pimgs = [cs[0].upload_sdf(psdf) for cs in psh.by_device]
+            pb = [vc.VoxelCarver.prepare_batch(pviews, [pimgs[g]] * pnv) for g in range(G)]
+            psh.carve_batch(pb, steps=1)
+            pmeshes = psh.extract_slabs(0.0, True)
+            pref = whole_grid_mesh(popt, devices[0], lambda w: w.CarveBatchDevice(pb[0]), args.batch, args.cull)
+            preflight = {"mesh_check": compare_meshes(vdist_.merge_meshes(pmeshes), pref), "grid": pn, "views": pnv,
+                         "collective": {k_: dict(psh.last_collective or {}).get(k_) for k_ in ("backend", "ranks", "version", "op", "bytes_per_rank")}}
+            for g, cs in enumerate(psh.by_device):
+                cs[0].free_device(pimgs[g])
+            psh.close()
+        except Exception as e:
+            preflight = {"error": "%s: %s" % (type(e).__name__, e)}
+        if not (isinstance(preflight.get("mesh_check"), dict) and preflight["mesh_check"].get("merged_equals_single_context")):
+            sys.stderr.write("bench: PREFLIGHT MESH CHECK DID NOT PASS: %r\n" % (preflight,))
     warm_steps, warm_ms = 0, 0.0
     if args.warmup > 0:
         warm_ms = sh.carve_batch(batches, steps=args.warmup)
@@ -524,6 +671,31 @@ def run_inprocess(args, why=None):
                 "avg_launch_ms": round(avg_launch_ms, 4),
                 "note": "per GPU, of the device whose carve kernel takes longest; algorithmic bytes as in the one-GPU "
                         "line (4 B per voxel*view of that device's slab); what binds the kernel: see the one-GPU line"}
+    if args.batch and args.cull:
+        # the timed launches drop (brick, view) pairs that provably change nothing: `frac` counts the pairs really
+        # evaluated (the one-GPU line measures the dropping-off launch itself; see contract_roofline)
+        pairs = None
+        try:
+            sh.set_param("paircount", 1)
+            sh.carve_batch(batches, steps=1)
+            proc = tot = 0
+            for c in sh.slabs:
+                a, b, _ = c.last_carve_pairs()
+                proc, tot = proc + a, tot + b
+            sh.set_param("paircount", 0)
+            pairs = round(proc / float(tot), 4) if tot else None
+        except Exception as e:
+            pairs = "%s: %s" % (type(e).__name__, e)
+        roofline["headline_kernel"] = {"avg_launch_ms": roofline["avg_launch_ms"], "pairs_processed_frac": pairs,
+                                       "per_view_api_equivalent": {"gbs": roofline["achieved"], "frac": roofline["frac"]}}
+        if isinstance(pairs, float):
+            roofline["achieved"] = round(pairs * achieved, 1)
+            roofline["frac"] = round(pairs * achieved / HBM_PEAK_GBS, 4)
+            roofline["frac_source"] = ("processed pairs: pairs_processed_frac x algorithmic bytes / launch duration (the launch "
+                                       "evaluates that share of the voxel*views; the rest is dropped as provably unchanged)")
+        else:
+            roofline["achieved"] = roofline["frac"] = None
+            roofline["frac_source"] = "unavailable (pair count failed)"
     mc = None
     collective = None
     if not args.no_mc:
@@ -600,6 +772,9 @@ def run_inprocess(args, why=None):
                         "kernel_ms": round(stats[g]["kernel_ms"], 3), "idle_ms": round(stats[g]["idle_ms"], 3),
                         "step_ms": round(stats[g]["period_ms"], 3),
                         "slabs_z": [list(sh.z_ranges[s]) for s in range(g, G * k, G)]} for g in range(G)]}
+    if preflight is not None:
+        out["config"]["preflight_mesh_check"] = preflight.get("mesh_check", preflight)
+        out["config"]["collective"] = preflight.get("collective")
     if why:
         out["config"]["launch_note"] = why
     if variants is not None:
@@ -826,6 +1001,47 @@ def main():
     def main_step(c):
         return c.CarveBatchDevice(batch)
 
+    # N > 1: before anything is timed, the WHOLE multi-GPU path once on a small grid -- sharded carve, the halo all-gather
+    # through the collective backend, per-slab extraction, merge by edge key -- compared with one context holding that
+    # grid: a record from a node nobody has run on before says by itself whether its exchange worked
+    # (config.preflight_mesh_check, config.collective).
+    preflight = None
+    if world > 1 and not args.no_preflight and args.batch:
+        try:
+            pn, pnv, pw, ph = 256, 8, 320, 240
+            popt = synth.sphere_option(pn, uo)
+            pviews, pmasks = synth.sphere_views(pn, pnv, pw, ph)
+            psdf = vc.make_sdf(pmasks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
+            pslabs = vdist.slabs_of_rank(pn, rank, world, k_slabs)
+            pcs = make_carvers(popt, args.cull, pslabs)
+            pimg = pcs[0].upload_sdf(psdf)
+            pbatch = vc.VoxelCarver.prepare_batch(pviews, [pimg] * pnv)
+            for c in pcs:
+                c.set_param("meshkeys", 1)
+                if not c.CarveBatchDevice(pbatch):
+                    raise RuntimeError(vc.last_error())
+            pinfo = vdist.exchange_halo(pcs, rank, world) or {}
+            pmeshes = [c.ExtractIsoSurface(0.0, True) for c in pcs]
+
+            def pbarrier():
+                sync_all(pcs)
+                if backend == "nccl":
+                    torch.cuda.synchronize()
+                dist.barrier()
+
+            pcheck = vdist.merged_mesh_check(
+                pmeshes, [sid for sid, _, _ in pslabs], rank, world, world * k_slabs,
+                lambda: whole_grid_mesh(popt, local_rank, lambda w: w.CarveBatchDevice(pbatch), args.batch, args.cull), pbarrier)
+            preflight = {"grid": pn, "views": pnv, "collective": {k_: pinfo.get(k_) for k_ in ("backend", "ranks", "version", "op", "bytes_per_rank")},
+                         "mesh_check": pcheck}
+            pcs[0].free_device(pimg)
+            for c in reversed(pcs):
+                c.close()
+        except Exception as e:
+            preflight = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0 and not (isinstance(preflight.get("mesh_check"), dict) and preflight["mesh_check"].get("merged_equals_single_context")):
+            sys.stderr.write("bench: PREFLIGHT MESH CHECK DID NOT PASS: %r\n" % (preflight,))
+
     warm_steps, warm_ms = warm_up(devs, main_step, args.warmup, args.settle_ms)
     clear_logs(devs)
     barrier()
@@ -1011,27 +1227,9 @@ def main():
                 my_meshes.append(mesh)
             mesh_check = None
             if args.verify_mesh and not single:
-                # one node: the slab meshes travel through shared memory files, rank 0 merges and compares
-                import numpy as np
-                import shutil
-                base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
-                tag = os.path.join(base, "vcy_verify_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getuid()))
-                os.makedirs(tag, exist_ok=True)
-                for (sid, _, _), m in zip(my_slabs, my_meshes):
-                    np.savez(os.path.join(tag, "slab_%d.npz" % sid), vertices=m["vertices"], faces=m["faces"],
-                             keys=m["keys"], n_foreign=np.int64(m["n_foreign"]))
-                barrier()
-                if rank == 0:
-                    parts = []
-                    for sid in range(world * k_slabs):
-                        z = np.load(os.path.join(tag, "slab_%d.npz" % sid))
-                        parts.append({"vertices": z["vertices"], "faces": z["faces"], "keys": z["keys"],
-                                      "n_foreign": int(z["n_foreign"])})
-                    ref = whole_grid_mesh(opt, local_rank, lambda w: w.CarveBatchDevice(batch), args.batch, args.cull)
-                    mesh_check = compare_meshes(vdist.merge_meshes(parts), ref)
-                barrier()
-                if rank == 0:
-                    shutil.rmtree(tag, ignore_errors=True)
+                mesh_check = vdist.merged_mesh_check(
+                    my_meshes, [sid for sid, _, _ in my_slabs], rank, world, world * k_slabs,
+                    lambda: whole_grid_mesh(opt, local_rank, lambda w: w.CarveBatchDevice(batch), args.batch, args.cull), barrier)
             if dist is not None:
                 t = torch.tensor([mc_ms, mc_wall, float(nvert), float(nface)], dtype=torch.float64, device=red_dev)
                 tmax = t.clone()
@@ -1049,7 +1247,9 @@ def main():
                   "calls_device_wall_ms": mc_calls,
                   "mesh_arrays": "vertices, faces" if single else "vertices, faces, edge keys (slab merge)",
                   "vertices": int(nvert), "faces": int(nface),
-                  "roofline_frac": round(cells * 4.0 / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                  "mcells_per_s_wall": round(cells / (mc_wall * 1e-3) / 1e6, 1),
+                  "roofline_frac": round(cells * 4.0 / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                  "roofline_frac_wall": round(cells * 4.0 / (mc_wall * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             if mesh_check is not None:
                 mc["mesh_check"] = mesh_check
             if single:
@@ -1096,11 +1296,29 @@ def main():
         return round(proc / float(tot), 4) if tot else None
 
     pairs_main = None
-    if world == 1 and args.batch:
+    if args.batch:
+        # (every rank counts the pairs of its slabs; the fraction is over the whole grid)
+        proc = tot = 0
+        err = None
         try:
-            pairs_main = pairs_of(dev, main_step)
+            for c in devs:
+                c.set_param("paircount", 1)
+                c.reset()
+                if not main_step(c):
+                    raise RuntimeError(vc.last_error())
+                a, b, _ = c.last_carve_pairs()
+                proc, tot = proc + a, tot + b
+                c.set_param("paircount", 0)
         except Exception as e:
-            pairs_main = "%s: %s" % (type(e).__name__, e)
+            err = "%s: %s" % (type(e).__name__, e)
+            proc = tot = 0
+        if dist is not None:
+            t = torch.tensor([float(proc), float(tot), 1.0 if err else 0.0], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t)
+            proc, tot = t[0].item(), t[1].item()
+            if t[2].item() > 0 and err is None:
+                err = "pair count failed on another rank"
+        pairs_main = err if err else (round(proc / float(tot), 4) if tot else None)
 
     # The same library in other modes, on another scene and through its other entry points, measured in the same run
     # (warm device, steps queued back to back) so that the headline's dependence on scene and call pattern is in the
@@ -1362,6 +1580,9 @@ def main():
                                  "for settle_ms: an idle MI355X needs ~40 ms of continuous load to settle its clocks"},
         "roofline": roofline, "mc": mc, "collective": collective,
     }
+    if preflight is not None:
+        out["config"]["preflight_mesh_check"] = preflight.get("mesh_check", preflight)
+        out["config"]["collective"] = preflight.get("collective")
     if per_gpu is not None:
         out["per_gpu"] = per_gpu
         out["config"]["launch"] = "torch.distributed.run (one process per GPU)"
@@ -1386,6 +1607,10 @@ def main():
         out["configs"]["wall_s_spent"] = round(time.perf_counter() - t_cfg, 2)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, views, sdfs, args.cpu_seconds)
+    if args.batch:
+        out["roofline"] = contract_roofline(roofline, mode=args.mode, cull=args.cull, n=n, nv=nv, bpv=bytes_per_vv(args.mode, uo),
+                                            launches_per_step=launches_per_step, pairs_frac=pairs_main, variants=variants, mc=mc,
+                                            configs=out.get("configs"), build=build, world=world)
     if rank == 0:
         emit(out)
     for p in d_sdf:

@@ -283,6 +283,22 @@ int vcy_halo_allgather(vcy_ctx* const* slabs, int n_slabs);
 /* Releases what vcy_halo_allgather keeps between calls (communicators, streams and staging buffers per
  * device set); the next exchange builds them again.  Call when no exchange is in flight. */
 void vcy_halo_shutdown(void);
+/* One process per GPU WITHOUT torch -- the same single all-gather for a C++ host that runs one process per device
+ * (the north star's host model; vacancy_amd/dist.py is its torch.distributed twin; no reference counterpart: the
+ * reference is one OpenMP process).  vcy_comm_create: rank `rank` of `world` on `device_id`; rank 0 draws an
+ * ncclUniqueId and every rank receives it through `rendezvous` -- "file:<path>" (a path private to the job on a
+ * filesystem all ranks of the node see: rank 0 publishes the id by an atomic rename, the others poll for it) or
+ * "tcp:<host>:<port>" (rank 0 listens, the others connect, retrying until it does) -- then ncclCommInitRank.  Blocks
+ * until all ranks have joined or `timeout_ms` has passed (<= 0: 120 s).  world == 1 needs no rendezvous (NULL is fine).
+ * vcy_halo_allgather_ranks: `my_slabs` = this rank's slab contexts in slab order -- the grid's slab ids rank,
+ * rank + world, ... (vacancy_amd.dist.slabs_of_rank), every rank holding the SAME number; each packs its last two
+ * slices, ONE ncclAllGather (rank-major), every slab installs the pack of the slab below it.
+ * vcy_rendezvous_exchange is the rendezvous by itself (128 bytes from rank 0 to every rank): what the CPU tests run. */
+typedef struct vcy_comm vcy_comm;
+int vcy_comm_create(int rank, int world, int device_id, const char* rendezvous, int timeout_ms, vcy_comm** out);
+void vcy_comm_destroy(vcy_comm* comm);
+int vcy_halo_allgather_ranks(vcy_comm* comm, vcy_ctx* const* my_slabs, int n_my_slabs);
+int vcy_rendezvous_exchange(int rank, int world, const char* rendezvous, void* payload128, int timeout_ms);
 /* What the last vcy_halo_allgather of this process did, as text:
  * "backend=rccl op=ncclAllGather version=V ranks=R bytes_per_rank=B calls=N lib=..." or "none". */
 const char* vcy_last_collective(void);

@@ -128,6 +128,120 @@ def test_unequal_slabs_merge_to_the_serial_mesh(world, k, bounds):
         assert ret["nv"] == 8672
 
 
+def _preflight_worker(rank, world, port, k, spoil, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        masks = B.load_masks()
+        views = B.bunny_views(lambda t, q: O.affine_inverse(O.pose_from_tum(t, q)))
+        g = O.OracleGrid(B.bunny_option(10.0))
+        for i in range(6):
+            g.carve(views[i], O.make_sdf(masks[i]))
+        nz = g.dims[2]
+        slabs = vdist.slabs_of_rank(nz, rank, world, k)
+        meshes = [O.marching_cubes_slab(g, z0, z1) for _, z0, z1 in slabs]
+        if spoil and rank == world - 1:  # a rank whose exchange went wrong: one vertex off by one bit
+            v = meshes[-1]["vertices"].copy()
+            v.view(np.uint32)[-1, 0] ^= 1
+            meshes[-1] = dict(meshes[-1], vertices=v)
+        calls = []
+        check = vdist.merged_mesh_check(meshes, [sid for sid, _, _ in slabs], rank, world, world * k,
+                                        lambda: (calls.append(rank), g.marching_cubes())[1], dist.barrier)
+        assert (check is None) == (rank != 0) and calls == ([0] if rank == 0 else [])
+        if rank == 0:
+            ret["check"] = dict(check)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k,spoil", [(2, 1, False), (3, 2, False), (2, 1, True)])
+def test_preflight_mesh_check_of_a_multi_rank_job(world, k, spoil):
+    """What `bench.py --gpus N` runs on a small grid before its timed region (vacancy_amd.dist.merged_mesh_check): every
+    rank leaves its slabs' meshes in shared memory, rank 0 merges them by edge key and compares with the single-context
+    mesh -- the record of a first run on a real node then says whether the exchange + merge worked.  Here over gloo with
+    the oracle's slab extraction, once with a spoiled slab (one vertex bit flipped on the last rank): it must say no."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_preflight_worker, args=(world, port, k, spoil, ret), nprocs=world, join=True)
+        c = ret["check"]
+        assert c["merged_equals_single_context"] is (not spoil)
+        assert c["vertices"] == c["single_context_vertices"] == 8672 and c["faces"] == 17270 and c["slabs"] == world * k
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    assert not os.path.exists(os.path.join(base, "vcy_verify_%s_%s" % (port, os.getuid())))  # cleaned up
+
+
+def _rendezvous_worker(rank, world, where, ret):
+    import ctypes as C
+    from vacancy_amd import capi
+    lib = capi.load()
+    buf = (C.c_ubyte * 128)()
+    if rank == 0:
+        for i in range(128):
+            buf[i] = (i * 7 + 3) & 255
+    rc = lib.vcy_rendezvous_exchange(rank, world, where.encode(), buf, 20000)
+    ret[rank] = (rc, bytes(buf))
+
+
+@pytest.mark.parametrize("kind,world", [("file", 2), ("file", 8), ("tcp", 2), ("tcp", 4)])
+def test_native_rendezvous_hands_rank_zeros_id_to_every_rank(kind, world, tmp_path):
+    """The process-per-GPU exchange of a C++ host (vcy_comm_create: ncclGetUniqueId on rank 0, the id to every rank through
+    a rendezvous, ncclCommInitRank) needs no torch; its rendezvous -- a file published by atomic rename, or a TCP port on
+    which rank 0 serves the id -- is plain host code and runs here: `world` PROCESSES, the late ones and the early ones,
+    all end up with rank 0's 128 bytes.  (The collective behind it needs GPUs: tests/test_gpu_parity.py runs it with
+    one rank; a multi-rank run has not happened on hardware.)"""
+    import torch.multiprocessing as mp
+    if kind == "file":
+        where = "file:" + str(tmp_path / "vcy_id")
+    else:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        where = "tcp:127.0.0.1:%d" % port
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_rendezvous_worker, args=(world, where, ret), nprocs=world, join=True)
+        want = bytes((i * 7 + 3) & 255 for i in range(128))
+        assert sorted(ret.keys()) == list(range(world))
+        for r in range(world):
+            assert ret[r] == (0, want), r
+
+
+def test_native_rendezvous_argument_checks_and_timeouts(tmp_path):
+    import ctypes as C
+    from vacancy_amd import capi
+    lib = capi.load()
+    buf = (C.c_ubyte * 128)()
+    assert lib.vcy_rendezvous_exchange(0, 1, None, buf, 100) == capi.VCY_ERR_INVALID_ARG
+    assert lib.vcy_rendezvous_exchange(0, 1, b"file:/nowhere", buf, 100) == 0          # one rank: nothing to exchange
+    assert lib.vcy_rendezvous_exchange(2, 2, b"file:/tmp/x", buf, 100) == capi.VCY_ERR_INVALID_ARG
+    assert lib.vcy_rendezvous_exchange(1, 2, b"smoke:signals", buf, 100) == capi.VCY_ERR_INVALID_ARG
+    assert b"file:<path>" in lib.vcy_last_error()
+    assert lib.vcy_rendezvous_exchange(1, 2, ("file:" + str(tmp_path / "never")).encode(), buf, 50) != 0   # rank 0 never comes
+    assert b"did not appear" in lib.vcy_last_error()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    assert lib.vcy_rendezvous_exchange(1, 2, ("tcp:127.0.0.1:%d" % port).encode(), buf, 50) != 0
+    assert lib.vcy_rendezvous_exchange(0, 2, ("tcp:127.0.0.1:%d" % port).encode(), buf, 50) != 0            # nobody connects
+    # a truncated id file is not an id
+    (tmp_path / "short").write_bytes(b"abc")
+    assert lib.vcy_rendezvous_exchange(1, 2, ("file:" + str(tmp_path / "short")).encode(), buf, 50) != 0
+    # without a device the communicator cannot be built, and says so instead of hanging
+    comm = C.c_void_p()
+    n = C.c_int(0)
+    lib.vcy_device_count(C.byref(n))
+    if n.value == 0:
+        assert lib.vcy_comm_create(0, 1, 0, None, 100, C.byref(comm)) != 0 and not comm.value
+
+
 def test_slabs_of_rank_with_planned_cuts():
     b = [0, 168, 296, 408, 512, 616, 728, 864, 1024]
     assert vdist.slabs_of_rank(1024, 3, 8, 1, b) == [(3, 408, 512)]

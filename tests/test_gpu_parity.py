@@ -615,6 +615,43 @@ def test_native_rccl_halo_allgather_equals_host_exchange():
         assert_mesh_equal(ca.ExtractIsoSurface(0.0, True), cb.ExtractIsoSurface(0.0, True), "after shutdown")
 
 
+def test_native_process_per_gpu_exchange_with_one_rank():
+    """vcy_comm_create + vcy_halo_allgather_ranks: the halo all-gather of a C++ host that runs one process per GPU
+    (ncclGetUniqueId -> rendezvous -> ncclCommInitRank; no torch).  With the one GPU of this box: ONE rank holding three
+    slabs of the grid -- a real ncclCommInitRank communicator and a real ncclAllGather carrying the three packs -- and the
+    slabs' meshes, merged by edge key, equal the single-context mesh.  (More than one rank needs more than one GPU.)"""
+    import ctypes as C
+    from vacancy_amd import dist as vdist
+    lib = vc.capi.load()
+    n, nv = 44, 5
+    opt = synth.sphere_option(n, UpdateOption(voxel_update=1, use_truncation=True, truncation_band=0.1))
+    views, masks = synth.sphere_views(n, nv, 160, 120)
+    slabs = []
+    for r in range(3):
+        c = vc.VoxelCarver(opt, z_range=vdist.slab_range(n, r, 3))
+        assert c.Init(), vc.last_error()
+        for i in range(nv):
+            assert c.CarveSilhouette(views[i], masks[i])
+        slabs.append(c)
+    whole = vc.VoxelCarver(opt)
+    assert whole.Init()
+    for i in range(nv):
+        assert whole.CarveSilhouette(views[i], masks[i])
+    comm = C.c_void_p()
+    assert lib.vcy_comm_create(0, 1, 0, None, 1000, C.byref(comm)) == 0, vc.last_error()
+    arr = (C.c_void_p * 3)(*[c.ctx for c in slabs])
+    assert lib.vcy_halo_allgather_ranks(comm, arr, 3) == 0, vc.last_error()
+    text = lib.vcy_last_collective().decode()
+    assert "op=ncclAllGather" in text and "ranks=1" in text, text
+    meshes = [c.ExtractIsoSurface(0.0, True) for c in slabs]
+    assert_mesh_equal(vdist.merge_meshes(meshes), whole.ExtractIsoSurface(0.0, True), "3 slabs, one rank")
+    # a second exchange reuses the staging; a slab from another device set is refused
+    assert lib.vcy_halo_allgather_ranks(comm, arr, 3) == 0
+    assert lib.vcy_halo_allgather_ranks(comm, arr, 0) == vc.capi.VCY_ERR_INVALID_ARG
+    lib.vcy_comm_destroy(comm)
+    lib.vcy_comm_destroy(None)
+
+
 def test_torch_shares_device_memory_with_the_library():
     """bench.py's multi-GPU halo exchange hands torch CUDA tensors to the C-ABI: the library and
     torch must sit on the same HIP runtime in one process."""
@@ -1498,3 +1535,75 @@ def test_clock_probe_runs_beside_other_work():
     short = vc.ClockProbe(0, max_samples=4)
     time.sleep(0.01)
     assert short.stop()["samples"] == 4
+
+
+def test_extractions_on_eight_streams_beside_a_long_carve():
+    """The chained scan of an extraction (scan_chained_kernel) draws its chunk numbers as tickets, so its forward progress
+    does not depend on the order in which workgroups of a grid are started -- which is exactly what other contexts'
+    streams perturb.  Eight contexts (a stream each, grids large enough for several chunks per scan) extract at the same
+    time from eight host threads, round after round at changing iso levels, while a ninth context keeps the device
+    busy with long carve launches on its own stream; every mesh equals the oracle's."""
+    import threading
+    n, nv, w, h = 264, 6, 320, 240
+    opt = synth.sphere_option(n)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    orc = O.OracleGrid(opt)
+    sdfs = [O.make_sdf(m) for m in masks]
+    for i in range(nv):
+        orc.carve(views[i], sdfs[i])
+    isos = [0.0, 0.013, -0.02, 0.05]
+    want = [orc.marching_cubes(iso, True) for iso in isos]
+    ctxs = []
+    for _ in range(8):
+        c = vc.VoxelCarver(opt)
+        assert c.Init(), vc.last_error()
+        c.set_param("mcskip", 0)   # the dense pass: the scans cover every word block (several 1024-block chunks)
+        for i in range(nv):
+            assert c.Carve(views[i], sdfs[i])
+        c.sync()
+        ctxs.append(c)
+    # the ninth context: 512^3, 32 views without view dropping, launched again and again until the others are done
+    big = vc.VoxelCarver(synth.sphere_option(512))
+    assert big.Init(), vc.last_error()
+    big.set_param("cull", 0)
+    bviews, bmasks = synth.sphere_views(512, 32, 640, 480)
+    bimgs = [big.upload_sdf(O.make_sdf(m)) for m in bmasks[:1]] * 32
+    batch = vc.VoxelCarver.prepare_batch(bviews, bimgs)
+    stop = threading.Event()
+    errors = []
+
+    def keep_busy():
+        try:
+            while not stop.is_set():
+                for _ in range(4):
+                    assert big.CarveBatchDevice(batch), vc.last_error()
+                big.sync()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def extract(c, out):
+        try:
+            for rnd in range(3):
+                for k, iso in enumerate(isos):
+                    out.append((k, c.ExtractIsoSurface(iso, True)))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    busy = threading.Thread(target=keep_busy)
+    busy.start()
+    outs = [[] for _ in ctxs]
+    ths = [threading.Thread(target=extract, args=(c, o)) for c, o in zip(ctxs, outs)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    stop.set()
+    busy.join(timeout=300)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in ths) and not busy.is_alive(), "an extraction did not finish: the scan hung"
+    for ci, o in enumerate(outs):
+        assert len(o) == 3 * len(isos)
+        for k, m in o:
+            assert_mesh_equal(m, want[k], "context %d iso %g" % (ci, isos[k]))
+    # (several chunks per scan: the word blocks of this grid exceed one 1024-block chunk)
+    assert (n - 1) * (n - 1) * ((n + 63) // 64) > 256 * 1024

@@ -148,6 +148,10 @@ def load():
         "vcy_halo_copy_from": (C.c_int, [vp, vp]),
         "vcy_halo_allgather": (C.c_int, [P(vp), C.c_int]),
         "vcy_halo_shutdown": (None, []),
+        "vcy_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, P(vp)]),
+        "vcy_comm_destroy": (None, [vp]),
+        "vcy_halo_allgather_ranks": (C.c_int, [vp, P(vp), C.c_int]),
+        "vcy_rendezvous_exchange": (C.c_int, [C.c_int, C.c_int, C.c_char_p, vp, C.c_int]),
         "vcy_last_collective": (C.c_char_p, []),
         "vcy_state_equal": (C.c_int, [vp, vp, P(C.c_int64)]),
         "vcy_device_count": (C.c_int, [P(C.c_int)]),

@@ -11,8 +11,16 @@
 //
 // librccl.so is opened on first use (dlopen): the carve path needs no collective, and a host
 // process that already carries an RCCL (PyTorch ships its own librccl.so) keeps using that one.
+#include <arpa/inet.h>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
 #include <rccl/rccl.h>
+#include <sys/socket.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -35,6 +43,8 @@ struct RcclApi {
   void* handle = nullptr;
   ncclResult_t (*GetVersion)(int*) = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;                        // (process-per-GPU form, vcy_comm_create)
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // (optional: the error path of the sharded producer)
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -92,6 +102,8 @@ bool load_rccl() {
   } while (0)
   VCY_SYM(GetVersion, "ncclGetVersion");
   VCY_SYM(CommInitAll, "ncclCommInitAll");
+  VCY_SYM(GetUniqueId, "ncclGetUniqueId");
+  VCY_SYM(CommInitRank, "ncclCommInitRank");
   VCY_SYM(CommDestroy, "ncclCommDestroy");
   VCY_SYM(AllGather, "ncclAllGather");
   VCY_SYM(GroupStart, "ncclGroupStart");
@@ -672,6 +684,298 @@ const char* vcy_last_collective(void) {
     g_last_text = buf;
   }
   return g_last_text.c_str();
+}
+
+}  // extern "C"
+
+
+/* ---- one process per GPU, without torch ---------------------------------------------------------------------------
+ * The north star keeps the host in C++; its multi-GPU form is "one process per GPU ... a single RCCL all-gather of
+ * boundary slabs".  vacancy_amd/dist.py does that exchange through torch.distributed; a C++ host has no torch.  Here
+ * is the same exchange for it: every process creates a vcy_comm (rank r of `world`, its device), the ncclUniqueId of
+ * rank 0 reaches the others through a RENDEZVOUS that needs nothing but the filesystem or a TCP port of the node
+ * ("file:<path>" or "tcp:<host>:<port>"), ncclCommInitRank builds the communicator, and vcy_halo_allgather_ranks is
+ * the one collective: this rank's slabs (slab ids rank, rank + world, ...) pack their last two slices, ONE
+ * ncclAllGather hands every rank every pack (rank-major, as vacancy_amd.dist.exchange_halo lays them out), every slab
+ * installs the pack of the slab below it.  No reference counterpart (the reference is single-process OpenMP).         */
+namespace vcy {
+namespace {
+
+constexpr size_t kRendezvousBytes = 128;  // sizeof(ncclUniqueId)
+static_assert(sizeof(ncclUniqueId) == kRendezvousBytes, "rendezvous payload = one ncclUniqueId");
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+bool write_all(int fd, const void* buf, size_t n) {
+  const char* p = (const char*)buf;
+  while (n > 0) {
+    const ssize_t w = ::write(fd, p, n);
+    if (w <= 0) return false;
+    p += w;
+    n -= (size_t)w;
+  }
+  return true;
+}
+bool read_all(int fd, void* buf, size_t n) {
+  char* p = (char*)buf;
+  while (n > 0) {
+    const ssize_t r = ::read(fd, p, n);
+    if (r <= 0) return false;
+    p += r;
+    n -= (size_t)r;
+  }
+  return true;
+}
+
+// file:<path> -- rank 0 writes <path>.tmp and renames it to <path> (atomic: a reader sees all 128 bytes or no file);
+// the others poll for it.  Rank 0 removes a stale file of an earlier job before it writes; the path must be private to
+// the job (bench-style: include the job's port or pid).
+int rendezvous_file(const std::string& path, int rank, void* payload, int timeout_ms) {
+  if (rank == 0) {
+    (void)::unlink(path.c_str());
+    const std::string tmp = path + ".tmp";
+    const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+    if (fd < 0) {
+      set_error("rendezvous: cannot create %s", tmp.c_str());
+      return VCY_ERR_INVALID_ARG;
+    }
+    const bool ok = write_all(fd, payload, kRendezvousBytes);
+    ::close(fd);
+    if (!ok || ::rename(tmp.c_str(), path.c_str()) != 0) {
+      set_error("rendezvous: cannot publish %s", path.c_str());
+      return VCY_ERR_INTERNAL;
+    }
+    return VCY_OK;
+  }
+  const double t_end = now_ms() + timeout_ms;
+  while (now_ms() < t_end) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd >= 0) {
+      struct stat st;
+      const bool ok = ::fstat(fd, &st) == 0 && (size_t)st.st_size == kRendezvousBytes && read_all(fd, payload, kRendezvousBytes);
+      ::close(fd);
+      if (ok) return VCY_OK;
+    }
+    ::usleep(2000);
+  }
+  set_error("rendezvous: %s did not appear within %d ms", path.c_str(), timeout_ms);
+  return VCY_ERR_INTERNAL;
+}
+
+// tcp:<host>:<port> -- rank 0 listens on the port and sends the payload to world - 1 connections; the others connect
+// (retrying while rank 0 is not listening yet) and read it.
+int rendezvous_tcp(const std::string& host, int port, int rank, int world, void* payload, int timeout_ms) {
+  const double t_end = now_ms() + timeout_ms;
+  if (rank == 0) {
+    const int ls = ::socket(AF_INET, SOCK_STREAM, 0);
+    if (ls < 0) {
+      set_error("rendezvous: socket() failed");
+      return VCY_ERR_INTERNAL;
+    }
+    int one = 1;
+    (void)::setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    sockaddr_in addr{};
+    addr.sin_family = AF_INET;
+    addr.sin_port = htons((uint16_t)port);
+    addr.sin_addr.s_addr = htonl(INADDR_ANY);
+    if (::bind(ls, (sockaddr*)&addr, sizeof(addr)) != 0 || ::listen(ls, world) != 0) {
+      ::close(ls);
+      set_error("rendezvous: cannot listen on port %d", port);
+      return VCY_ERR_INVALID_ARG;
+    }
+    int rc = VCY_OK;
+    for (int k = 1; k < world && rc == VCY_OK; ++k) {
+      timeval tv;
+      const double left = std::max(1.0, t_end - now_ms());
+      tv.tv_sec = (long)(left / 1000.0);
+      tv.tv_usec = (long)((left - 1000.0 * tv.tv_sec) * 1000.0);
+      fd_set fds;
+      FD_ZERO(&fds);
+      FD_SET(ls, &fds);
+      if (::select(ls + 1, &fds, nullptr, nullptr, &tv) <= 0) {
+        set_error("rendezvous: %d of %d ranks connected within %d ms", k - 1, world - 1, timeout_ms);
+        rc = VCY_ERR_INTERNAL;
+        break;
+      }
+      const int cs = ::accept(ls, nullptr, nullptr);
+      if (cs < 0 || !write_all(cs, payload, kRendezvousBytes)) {
+        set_error("rendezvous: sending the id failed");
+        rc = VCY_ERR_INTERNAL;
+      }
+      if (cs >= 0) ::close(cs);
+    }
+    ::close(ls);
+    return rc;
+  }
+  addrinfo hints{}, *res = nullptr;
+  hints.ai_family = AF_INET;
+  hints.ai_socktype = SOCK_STREAM;
+  const std::string port_s = std::to_string(port);
+  if (::getaddrinfo(host.c_str(), port_s.c_str(), &hints, &res) != 0 || !res) {
+    set_error("rendezvous: cannot resolve %s", host.c_str());
+    return VCY_ERR_INVALID_ARG;
+  }
+  int rc = VCY_ERR_INTERNAL;
+  while (now_ms() < t_end) {
+    const int cs = ::socket(AF_INET, SOCK_STREAM, 0);
+    if (cs < 0) break;
+    if (::connect(cs, res->ai_addr, res->ai_addrlen) == 0) {
+      const bool ok = read_all(cs, payload, kRendezvousBytes);
+      ::close(cs);
+      if (ok) {
+        rc = VCY_OK;
+        break;
+      }
+    } else {
+      ::close(cs);
+    }
+    ::usleep(5000);
+  }
+  ::freeaddrinfo(res);
+  if (rc != VCY_OK) set_error("rendezvous: no id from %s:%d within %d ms", host.c_str(), port, timeout_ms);
+  return rc;
+}
+
+int rendezvous(const char* where, int rank, int world, void* payload, int timeout_ms) {
+  if (!where || rank < 0 || world < 1 || rank >= world || !payload || timeout_ms <= 0) {
+    set_error("rendezvous: invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  if (world == 1) return VCY_OK;
+  const std::string w(where);
+  if (w.rfind("file:", 0) == 0 && w.size() > 5) return rendezvous_file(w.substr(5), rank, payload, timeout_ms);
+  if (w.rfind("tcp:", 0) == 0) {
+    const size_t colon = w.rfind(':');
+    if (colon != std::string::npos && colon > 4) {
+      const int port = std::atoi(w.c_str() + colon + 1);
+      if (port > 0 && port < 65536) return rendezvous_tcp(w.substr(4, colon - 4), port, rank, world, payload, timeout_ms);
+    }
+  }
+  set_error("rendezvous: expected \"file:<path>\" or \"tcp:<host>:<port>\", got \"%s\"", where);
+  return VCY_ERR_INVALID_ARG;
+}
+
+}  // namespace
+}  // namespace vcy
+
+struct vcy_comm {
+  int rank = 0, world = 1, device = 0;
+  ncclComm_t comm = nullptr;
+  hipStream_t stream = nullptr;
+  char* send = nullptr;
+  char* recv = nullptr;
+  size_t send_bytes = 0, recv_bytes = 0;
+};
+
+extern "C" {
+
+int vcy_rendezvous_exchange(int rank, int world, const char* where, void* payload128, int timeout_ms) {
+  return rendezvous(where, rank, world, payload128, timeout_ms);
+}
+
+int vcy_comm_create(int rank, int world, int device_id, const char* where, int timeout_ms, vcy_comm** out) {
+  if (!out || rank < 0 || world < 1 || rank >= world) {
+    set_error("vcy_comm_create: invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  *out = nullptr;
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  if (!load_rccl()) return VCY_ERR_UNSUPPORTED;
+  VCY_HIP_CHECK(hipSetDevice(device_id));
+  ncclUniqueId id;
+  std::memset(&id, 0, sizeof(id));
+  if (rank == 0) VCY_NCCL_CHECK(g_rccl.GetUniqueId(&id));
+  {
+    const int rc = rendezvous(where ? where : "", rank, world, &id, timeout_ms > 0 ? timeout_ms : 120000);
+    if (rc != VCY_OK && world > 1) return rc;
+  }
+  vcy_comm* c = new vcy_comm();
+  c->rank = rank, c->world = world, c->device = device_id;
+  const ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) {
+    set_error("ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, device_id, g_rccl.GetErrorString(r));
+    delete c;
+    return VCY_ERR_HIP;
+  }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+    set_error("vcy_comm_create: stream");
+    return VCY_ERR_HIP;
+  }
+  *out = c;
+  return VCY_OK;
+}
+
+void vcy_comm_destroy(vcy_comm* c) {
+  if (!c) return;
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  (void)hipSetDevice(c->device);
+  if (c->stream) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamDestroy(c->stream);
+  }
+  (void)hipFree(c->send);
+  (void)hipFree(c->recv);
+  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  delete c;
+}
+
+int vcy_halo_allgather_ranks(vcy_comm* cm, vcy_ctx* const* my_slabs, int n_my_slabs) {
+  if (!cm || !my_slabs || n_my_slabs <= 0) {
+    set_error("vcy_halo_allgather_ranks: invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  for (int i = 0; i < n_my_slabs; ++i)
+    if (!my_slabs[i] || my_slabs[i]->device != cm->device) {
+      set_error("vcy_halo_allgather_ranks: slab %d is not a context on this rank's device", i);
+      return VCY_ERR_INVALID_ARG;
+    }
+  const int k = n_my_slabs, world = cm->world;
+  if (world * k == 1) {
+    my_slabs[0]->halo_valid = true;
+    return VCY_OK;
+  }
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  VCY_HIP_CHECK(hipSetDevice(cm->device));
+  const size_t pack = (size_t)vcy_halo_bytes(my_slabs[0]);
+  const size_t send_bytes = pack * (size_t)k, recv_bytes = send_bytes * (size_t)world;
+  if (cm->send_bytes < send_bytes || cm->recv_bytes < recv_bytes) {
+    VCY_HIP_CHECK(hipStreamSynchronize(cm->stream));
+    (void)hipFree(cm->send);
+    (void)hipFree(cm->recv);
+    cm->send = cm->recv = nullptr;
+    cm->send_bytes = cm->recv_bytes = 0;
+    VCY_HIP_CHECK(hipMalloc((void**)&cm->send, send_bytes));
+    VCY_HIP_CHECK(hipMalloc((void**)&cm->recv, recv_bytes));
+    cm->send_bytes = send_bytes, cm->recv_bytes = recv_bytes;
+  }
+  for (int i = 0; i < k; ++i) {
+    const int rc = vcy_halo_pack(my_slabs[i], cm->send + pack * (size_t)i);  // (applies queued views first)
+    if (rc != VCY_OK) return rc;
+  }
+  for (int i = 0; i < k; ++i) VCY_HIP_CHECK(hipStreamSynchronize(my_slabs[i]->stream));
+  // the single collective of the path
+  VCY_NCCL_CHECK(g_rccl.AllGather(cm->send, cm->recv, send_bytes, ncclUint8, cm->comm, cm->stream));
+  VCY_HIP_CHECK(hipStreamSynchronize(cm->stream));
+  for (int i = 0; i < k; ++i) {
+    const int sid = cm->rank + i * world;  // this slab's id; the slab below it is sid - 1, held by rank (sid - 1) % world
+    const char* src = nullptr;
+    if (sid > 0) {
+      const int below = sid - 1;
+      src = cm->recv + ((size_t)(below % world) * (size_t)k + (size_t)(below / world)) * pack;
+    }
+    const int rc = vcy_halo_install(my_slabs[i], src);
+    if (rc != VCY_OK) return rc;
+  }
+  for (int i = 0; i < k; ++i) VCY_HIP_CHECK(hipStreamSynchronize(my_slabs[i]->stream));
+  g_last.ranks = world;
+  g_last.bytes_per_rank = (int64_t)send_bytes;
+  g_last.calls += 1;
+  (void)g_rccl.GetVersion(&g_last.version);
+  return VCY_OK;
 }
 
 }  // extern "C"

@@ -118,7 +118,13 @@ def exchange_halo(carvers, rank, world):
     import torch.distributed as dist
 
     on_gpu = dist.get_backend() == "nccl"
-    result = {"backend": "rccl (torch.distributed nccl)" if on_gpu else "gloo (host staging)",
+    version = None
+    if on_gpu:
+        try:  # (2, 22, 7)-like: the RCCL build behind torch's nccl backend
+            version = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            version = None
+    result = {"backend": "rccl (torch.distributed nccl)" if on_gpu else "gloo (host staging)", "version": version,
               "op": "all_gather_into_tensor" if on_gpu else "all_gather", "ranks": dist.get_world_size(),
               "bytes_per_rank": nbytes * k, "bytes_received_per_rank": nbytes * k * dist.get_world_size(),
               "bytes_needed_per_slab": nbytes, "slabs_per_rank": k}
@@ -226,6 +232,43 @@ def carve_silhouettes_sharded(carvers, rank, world, views, silhouettes, chunk=32
     return {"producer_ms": t_prod * 1e3, "gather_ms": t_gather * 1e3, "carve_enqueue_ms": t_carve * 1e3,
             "wall_ms": (time.perf_counter() - t_all) * 1e3, "views_built_by_this_rank": len(range(rank, n, world)) if chunk >= n
             else sum(len(range(rank, min(chunk, n - f), world)) for f in range(0, n, chunk))}
+
+
+def merged_mesh_check(my_meshes, my_slab_ids, rank, world, n_slabs, reference_fn, barrier, tag=None):
+    """The slabs' meshes of a one-node job merged by edge key and compared, array for array, with the mesh of ONE context
+    holding the whole grid (`reference_fn()`, called on rank 0 only).  The meshes travel through files in shared memory
+    (a pickle through the collective backend would serialise them into device tensors under nccl); `barrier()` must
+    synchronise the ranks (bench.py: device sync + dist.barrier).  Returns the comparison on rank 0, None elsewhere.
+    What `bench.py --gpus N` runs on a small grid BEFORE its timed region, so that the first record a multi-GPU node
+    produces says by itself whether the exchange + merge gave the single-GPU mesh."""
+    import os
+    import shutil
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    tag = tag or os.path.join(base, "vcy_verify_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getuid()))
+    os.makedirs(tag, exist_ok=True)
+    for sid, m in zip(my_slab_ids, my_meshes):
+        np.savez(os.path.join(tag, "slab_%d.npz" % sid), vertices=m["vertices"], faces=m["faces"], keys=m["keys"],
+                 n_foreign=np.int64(m["n_foreign"]))
+    barrier()
+    check = None
+    if rank == 0:
+        parts = []
+        for sid in range(n_slabs):
+            z = np.load(os.path.join(tag, "slab_%d.npz" % sid))
+            parts.append({"vertices": z["vertices"], "faces": z["faces"], "keys": z["keys"], "n_foreign": int(z["n_foreign"])})
+        merged, ref = merge_meshes(parts), reference_fn()
+        same = (merged["vertices"].shape == ref["vertices"].shape and merged["faces"].shape == ref["faces"].shape
+                and np.array_equal(merged["vertices"].view(np.uint32), ref["vertices"].view(np.uint32))
+                and np.array_equal(merged["faces"], ref["faces"]) and np.array_equal(merged["keys"], ref["keys"]))
+        check = {"merged_equals_single_context": bool(same), "vertices": int(len(merged["vertices"])),
+                 "faces": int(len(merged["faces"])), "single_context_vertices": int(len(ref["vertices"])),
+                 "single_context_faces": int(len(ref["faces"])), "slabs": int(n_slabs),
+                 "note": "slab meshes merged by edge key (vacancy_amd.dist.merge_meshes) against one context holding the "
+                         "whole grid on rank 0's device: vertex bits, faces and edge keys, array for array"}
+    barrier()
+    if rank == 0:
+        shutil.rmtree(tag, ignore_errors=True)
+    return check
 
 
 def merge_meshes(meshes):
