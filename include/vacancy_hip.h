@@ -338,6 +338,11 @@ int vcy_reset(vcy_ctx* ctx);
  * carve kernel -- lies above the iso level (they are outside the surface whatever they hold exactly); 0 reads every
  * brick; 1 skips them where that is the faster pass (voxel rows of 1024 and more: at 512^3 the dense pass wins by 7 - 14 %);
  * 2 skips them on any size (what the parity tests ask for).
+ * "mcdirect" (default 8388608): vcy_extract_iso lets its last kernel write a mesh whose GUESSED size (the previous
+ * extraction's counts + 25 %) is at most this many bytes straight into the page-locked host arrays it returns -- one
+ * enqueue, one wait per call; larger meshes are staged in device memory and copied with their exact sizes.  0: always
+ * staged.  Results identical.  "mctiming" 1 (or VCY_MC_TIMING=1 in the environment): the host-side phases of every
+ * extraction on stderr.
  * "livelist" (default 1): a carve launch of up to 8 views over an already carved grid first lists the workgroups in
  * which some view can still change a voxel (bounds of the views' samples against the kept brick minima / the
  * truncation limit) and starts only those; 0 starts every workgroup and lets each decide for itself.

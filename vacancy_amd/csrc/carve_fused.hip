@@ -82,6 +82,47 @@ constexpr size_t coop_lds_bytes() {
          2 * VCY_WG_WAVES * sizeof(unsigned long long);  // (changed-lane masks, then "this wave takes part in the stores")
 }
 
+// ---- the few-view flavour (template parameter NB > 1 of carve_fused_kernel) -------------------------------------------
+// The reference's own call pattern (examples.cc:117-149) carves ONE view per call, with an extraction in between: every
+// view is a launch of its own, and such a launch spends more of a wave's life on the wave than on its 512 voxels -- block
+// decode, axis loads, record unpack, tile request, barrier and write-back, 378 scalar + 290 vector instructions per brick
+// next to the 290 of the voxels (profiles/r05/single_view_attribution.txt), on a CU with ONE scalar unit.  For launches of
+// up to kRowMaxViews views a WAVE therefore walks NB consecutive bricks of one (y, z) row -- a "segment"; with NB = 4 the
+// 32 x 8 x 8 block a workgroup of the NB = 1 kernel owns:
+//   - block decode, axis loads, the records of all NB x nviews pairs (lane 8 j + v), the early-out test: once;
+//   - the state of every live brick of the segment is requested up front with LDS-direct loads (global_load_lds: no
+//     registers, no waits) into a staging area of the wave, and read from there when the brick's turn comes;
+//   - ONE loop over the live (brick, view) pairs, in pair order: the tile of the next pair -- whether the next view of
+//     this brick or the first live view of the next brick -- is in flight while this one is carved, exactly as the
+//     NB = 1 kernel does between the views of its one brick;
+//   - results go back to the staging area and leave it as whole row segments: 8 lanes store the 128 contiguous bytes
+//     of sdf the segment has in one voxel row, 4 lanes its counters -- what the cooperative write-back gets from four
+//     waves and a barrier, without the barrier.
+// Waves never talk to each other; a workgroup is just kRowWaves of them.
+// MEASURED (round 6, 1024^3 @1280x720, one view per launch; profiles/r06/row_kernel.txt): bit-identical to the NB = 1
+// kernel, and SLOWER -- weighted average 3.17 ms per view against 2.63, first view 2.15 against 1.85, kMax 0.74 against
+// 0.61.  The counters say why: a segment of four bricks costs 2062 vector + 1071 scalar instructions where four NB = 1
+// waves cost 2400 + 1376 -- the decode, axis loads and barrier that are amortised were a seventh of the overhead, the
+// rest is per brick and per pair whoever walks them -- while the staging area (14 KB per wave) leaves 2.7 waves per SIMD
+// where the NB = 1 kernel has 5.7, and the run loops need the other waves to cover their LDS and scalar-load latencies.
+// Two bricks per wave and four waves per workgroup (8 KB, 5 waves per SIMD) come closest (2.91 / 1.91 / 0.67 ms) and
+// amortise next to nothing (592 + 324 per brick); workgroups of one or two waves are slower again (dispatch rate).
+// So the flavour is OFF by default ("rowkernel" 0), kept and tested as the second implementation of few-view launches.
+constexpr int kRowMaxViews = 8;          // pairs are numbered 8 j + v
+#ifndef VCY_ROW_BRICKS
+#define VCY_ROW_BRICKS 4
+#endif
+#ifndef VCY_ROW_WAVES
+#define VCY_ROW_WAVES 2
+#endif
+constexpr int kRowBricks = VCY_ROW_BRICKS;
+constexpr int kRowWaves = VCY_ROW_WAVES;
+template <typename CountT, int NB>
+constexpr size_t row_lds_bytes_per_wave() {  // two raw tiles, NB x 8 TileInfo, the state of NB bricks, NB changed-lane masks
+  return (size_t)kRawBuffers * 1024 + (size_t)NB * kRowMaxViews * 56 /* sizeof(TileInfo) */ +
+         (size_t)NB * 64 * WX * (sizeof(float) + sizeof(CountT)) + (size_t)NB * sizeof(unsigned long long);
+}
+
 constexpr int kWmaxPlanes = 2;           // window sizes 4 and 8
 constexpr int kLiveListMaxViews = 8;      // launches of up to this many views over a carved grid list their live workgroups first
 constexpr int64_t kRecordBytesMax = (int64_t)2 << 30;  // footprint records of one carve launch (see launch_carve_fused)
@@ -175,6 +216,7 @@ struct TileInfo {
   int sure;                      // bit 0: every voxel of the brick provably samples inside this tile;
                                  // bit 1: and every sample is provably >= -1 (no truncation skip possible)
 };
+static_assert(sizeof(TileInfo) == 56, "row_lds_bytes_per_wave");
 
 // Correctly rounded n/d for normal operands away from the exponent limits: v_rcp_f32 plus the
 // refinement steps of the standard fp32 division expansion (without v_div_scale/v_div_fixup).
@@ -870,11 +912,13 @@ FastDivU32 make_fast_div_u32(uint32_t d) {
 // integer divisions by run-time values at the head of every wave -- 25 scalar instructions and a v_rcp_iflag round trip
 // each -- were a fifth of the scalar work that bounds such a launch (profiles/r05/first_view_floor.txt).
 struct BlockDecode {
+  int total;                           // units (workgroup blocks; segments of the few-view flavour) of the launch
   int layer, q, rem, dealt;            // workgroups per brick layer, layer / 8, layer % 8, 8 q (layers of the launch)
   FastDivU32 dq, drem, dnbx, dnby;     // divisions by q, rem (1 when rem == 0: never used then), nbx, nby
 };
 BlockDecode make_block_decode(unsigned grid_x, int nbx, int nby) {
   BlockDecode d;
+  d.total = (int)grid_x;
   d.layer = nbx * nby;
   d.q = d.layer >> 3;
   d.rem = d.layer & 7;
@@ -938,7 +982,8 @@ __global__ __launch_bounds__(256) void footprint_records_kernel(GridParams g, co
 constexpr int kLiveThreads = 1024;
 __global__ __launch_bounds__(kLiveThreads) void live_workgroups_kernel(const FootprintRecord* __restrict__ recs, int64_t nbricks,
                                                                        int nviews, const float* __restrict__ bmin, int trunc,
-                                                                       int nbx, int nby, int nbw, int nwg, int* __restrict__ list) {
+                                                                       int nbx, int nby, int nbw, int nwg, int* __restrict__ list,
+                                                                       int unit_bricks) {
   // (one atomic per block of 1024 workgroups: one per WAVE -- 8192 of them on one counter at 1024^3 -- took 78 us of a
   // 0.8 ms single-view launch, the serialised atomics, not the 25 MB it reads)
   __shared__ int wave_count[kLiveThreads / 64];
@@ -948,8 +993,8 @@ __global__ __launch_bounds__(kLiveThreads) void live_workgroups_kernel(const Foo
   if (wg < nwg) {
     const int bx = wg % nbx, r = wg / nbx;
     const int by = r % nby, bz = r / nby;
-    for (int j = 0; j < kWgWaves; ++j) {
-      const int bxw = bx * kWgWaves + j;
+    for (int j = 0; j < unit_bricks; ++j) {  // (kWgWaves bricks of a workgroup, or the segment of a wave: kRowBricks)
+      const int bxw = bx * unit_bricks + j;
       if (bxw >= nbw) break;
       const int64_t brick = ((int64_t)bz * nby + by) * nbw + bxw;
       const float smin = bmin ? bmin[brick] : 0.0f;
@@ -979,11 +1024,17 @@ __global__ __launch_bounds__(kLiveThreads) void live_workgroups_kernel(const Foo
 
 // GEN: nearest-neighbour sampling and/or an orthographic camera, selected at run time from `mode`
 // (compiled out of the default bilinear + pinhole kernels, where the extra branches cost 16 %).
-template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX, int TQ, bool GEN, int DIV>
-__global__ __launch_bounds__(64 * kWgWaves)
-__attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDATE != VCY_UPDATE_WEIGHTED_AVERAGE)
+// NB: bricks per wave -- 1: a workgroup of kWgWaves waves, a brick each (fused launches of many views); kRowBricks: the
+// few-view flavour described at kRowBricks above (raw tiles, records from the pre-pass, rows of whole bricks).
+template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX, int TQ, bool GEN, int DIV, int NB = 1>
+__global__ __launch_bounds__(64 * (NB > 1 ? kRowWaves : kWgWaves))
+__attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : ((!GEN && !CHECKMAX && TQ == kTileRaw && UPDATE != VCY_UPDATE_WEIGHTED_AVERAGE)
                                        ? (UPDATE == kUpdateWaUnitWeight ? VCY_WAVES_WA : VCY_WAVES)
-                                       : VCY_WAVES_CHECKED))) void carve_fused_kernel(GridParams g,
+                                       : VCY_WAVES_CHECKED),
+                                   // (the few-view flavour is bounded by its LDS: 3 - 5 waves per SIMD, registers to spare)
+                                   NB > 1 ? (NB > 2 ? 4 : 5) : ((!GEN && !CHECKMAX && TQ == kTileRaw && UPDATE != VCY_UPDATE_WEIGHTED_AVERAGE)
+                                       ? (UPDATE == kUpdateWaUnitWeight ? VCY_WAVES_WA : VCY_WAVES)
+                                       : VCY_WAVES_CHECKED)))) void carve_fused_kernel(GridParams g,
                                                           const FusedView* __restrict__ views,
                                                           const float* __restrict__ c0_all,
                                                           int nviews, ModeParams mode, int nbx,
@@ -1003,7 +1054,10 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   //              bit 3 = cooperative write-back through LDS (below)
   const int fresh = state_flags & 1;
   const bool implied = (state_flags & 2) != 0;
-  const bool coop = (kWgWaves == 4 || kWgWaves == 8) && (state_flags & 8) != 0;
+  const bool coop = NB == 1 && (kWgWaves == 4 || kWgWaves == 8) && (state_flags & 8) != 0;
+  const bool nt_store = (state_flags & 16) != 0;  // cooperative write-back with streaming stores
+  constexpr bool kRows = NB > 1;  // the few-view flavour: this WAVE walks NB bricks of a row (kRowBricks)
+  static_assert(!kRows || (TQ == kTileRaw && !CHECKMAX), "the few-view flavour: raw tiles, no update limit in reach");
   // dynamic LDS: [4 waves][TQ] quads, then [4 waves][nviews] TileInfo (sized by the launch), then the staging of the
   // cooperative write-back
   extern __shared__ float4 fused_lds[];
@@ -1018,6 +1072,11 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   // and the four weights sum to 1 within 2^-23 (each is a product of u-floor(u), 1-(u-floor(u)) ...),
   // so dist <= M + 2^-22 |M| for either sign of M.  ub = M + 2^-20 |M| is that bound with slack.
   // Footprints holding a NaN or an infinity give no bound (0 * inf = NaN samples).
+  // (Round 6 also bounded a `sure` view by the EXACT maximum of its staged tile -- one 16-byte LDS read per lane and a wave
+  // reduction once the tile has landed -- against the window maxima's over-estimate: on the benchmark scenes it never
+  // dropped a single pair more and cost 8 % (profiles/r06/exact_tile.txt).  The pairs that are processed without changing
+  // anything are not lost to the windows sticking out of the footprint: a distance field varies by 1 - 2 % across a
+  // footprint, and so does the brick's state; what is compared is the MAXIMUM of the one with the MINIMUM of the other.)
   constexpr bool kNeedBound = TRUNC || UPDATE == VCY_UPDATE_MAX;
 
   VCY_SETPRIO(3);
@@ -1025,8 +1084,16 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   // (the wave index is uniform, which the compiler cannot see: keeps the LDS bases of the wave in SGPRs)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   VCY_PT_DECL;
-  float4* tile = fused_lds + wave * kTileF4;
-  TileInfo* tinfo = (TileInfo*)(fused_lds + kWgWaves * kTileF4) + wave * nviews;
+  // NB > 1: every wave has its own region [tiles | TileInfo of the NB x 8 pairs | state of NB bricks | NB masks]
+  constexpr size_t kRowWaveBytes = kRows ? row_lds_bytes_per_wave<CountT, NB>() : 0;
+  static_assert(kRowWaveBytes % 16 == 0, "wave regions are 16-byte aligned");
+  float4* tile = kRows ? (float4*)((char*)fused_lds + wave * kRowWaveBytes) : fused_lds + wave * kTileF4;
+  TileInfo* tinfo = kRows ? (TileInfo*)((char*)tile + kRawBuffers * 1024)
+                          : (TileInfo*)(fused_lds + kWgWaves * kTileF4) + wave * nviews;
+  float* stage_s = (float*)((char*)tinfo + NB * kRowMaxViews * sizeof(TileInfo));   // [NB][64 rows][WX]
+  CountT* stage_n = (CountT*)(stage_s + NB * 64 * WX);                                 // [NB][64 rows][WX]
+  typedef unsigned long long __attribute__((address_space(3))) lds_u64_row;
+  lds_u64_row* stage_mask = (lds_u64_row*)(unsigned long long*)(stage_n + NB * 64 * WX);  // [NB] changed lanes
   // (sizeof(TileInfo) * kWgWaves is a multiple of 16: the staging area is 16-byte aligned)
   static_assert((sizeof(TileInfo) * kWgWaves) % 16 == 0, "alignment of the cooperative write-back's staging");
   typedef CountT CountVec8 __attribute__((ext_vector_type(WX)));
@@ -1051,11 +1118,15 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   // workgroup b runs on XCD b % 8.  Give every XCD one contiguous eighth of the brick list: bricks
   // that follow each other on an XCD are neighbours in x and share SDF footprint pixels and
   // z-table entries in that XCD's private L2.
-  int b = blockIdx.x;
+  // NB > 1: the unit of the launch is a SEGMENT (NB bricks of a row) and every wave takes one -- the waves of a
+  // workgroup consecutive units of the same XCD's share (b mod 8 = blockIdx mod 8, the XCD the workgroup runs on)
+  int b = kRows ? ((int)(blockIdx.x & 7u) + 8 * (kRowWaves * (int)(blockIdx.x >> 3) + wave)) : (int)blockIdx.x;
   if (wg_list != nullptr) {  // only the workgroups live_workgroups_kernel listed (wg_list[0] of them)
+    if (kRows) b = (int)blockIdx.x * kRowWaves + wave;
     if (b >= wg_list[0]) return;
     b = wg_list[1 + b];
   } else {
+    if (kRows && b >= bd.total) return;
 #if !defined(VCY_XCD_LAYERS) && !defined(VCY_XCD_CONTIGUOUS)
     // Every XCD takes an eighth of EVERY brick layer -- q = layer / 8 consecutive workgroups, i.e. whole rows in (y, x)
     // order -- and a different eighth in every layer (chunk (xcd + layer) mod 8), so that each XCD sees every z and,
@@ -1093,7 +1164,8 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   const int bz = (int)fast_div_u32((uint32_t)brow, bd.dnby);
   const int by = brow - bz * nby;
   // (the wave index is uniform, which the compiler cannot see: readfirstlane keeps the x tables in scalar loads)
-  const int x_first = __builtin_amdgcn_readfirstlane(bx * BX + wave * WX);  // wave brick origin
+  // (NB > 1: the origin of the segment's first brick; moves on with the brick being carved)
+  int x_first = kRows ? bx * (NB * WX) : __builtin_amdgcn_readfirstlane(bx * BX + wave * WX);  // wave brick origin
 #if defined(VCY_DEV_EXIT_AT) && VCY_DEV_EXIT_AT == 1
   if (x_first >= 0) {
     coop_leave();
@@ -1117,7 +1189,8 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   // flow: a uniform value first computed inside a divergent branch (`if (lane < nviews)` below) reaches later uses
   // through a phi that the compiler must treat as divergent -- it then lives in a VGPR, and so did the address of the
   // c0 records that shares `nxp / WX` with it: the scalar loads of the run loops had become vector loads (-15 %).
-  const int brick_lin = (bz * nby + by) * (nxp / WX) + (x_first / WX);
+  int brick_lin = (bz * nby + by) * (nxp / WX) + (x_first / WX);
+  const int x_seg = x_first, brick_seg = brick_lin;  // (NB > 1: the segment's first brick)
   // ---- prologue: lane vi bounds the footprint of the wave brick in view vi (brick_footprints) -------
   float ub_lane;
 #ifdef VCY_PHASE_TIMING
@@ -1127,7 +1200,22 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     pt_acc[12] += t_ - pt_last;
   }
 #endif
-  if (kRaw && records != nullptr) {
+  // NB > 1: lane 8 j + v holds the pair (brick j of the segment, view v)
+  const int pair_j = lane >> 3, pair_v = lane & 7;
+  const bool pair_valid = kRows && pair_j < NB && pair_v < nviews && x_seg + pair_j * WX < g.nx;
+  if constexpr (kRows) {
+    ub_lane = INFINITY;
+    if (pair_valid) {
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      typedef const u32x2 __attribute__((address_space(1))) * grec_ptr;
+      const u32x2 raw = ((grec_ptr)records)[(int64_t)pair_v * nbricks + (brick_seg + pair_j)];
+      FootprintRecord rec;
+      rec.w0 = raw.x, rec.w1 = raw.y;
+      const TileInfo ti = unpack_footprint(rec);
+      store_tile_info((lds_u32*)tinfo, lane, ti);
+      ub_lane = ti.ub;
+    }
+  } else if (kRaw && records != nullptr) {
     // raw tiles: the footprints come from the pre-pass (footprint_records_kernel), 8 bytes per view
     ub_lane = INFINITY;
     if (lane < nviews) {
@@ -1158,7 +1246,8 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     return;
   }
 #endif
-  const unsigned long long view_mask = (nviews >= 64) ? ~0ull : ((1ull << nviews) - 1ull);
+  const unsigned long long view_mask = kRows ? __ballot(pair_valid) : ((nviews >= 64) ? ~0ull : ((1ull << nviews) - 1ull));
+  unsigned long long live = view_mask;  // pairs / views that may still change something (NB > 1: set here, from the kept minima)
   // (a launch covers fewer than 2^31 wave bricks: launch_carve_fused)
   // Views that cannot change this brick whatever its voxels hold now: every sample below the truncation limit, or
   // (kMax) not above the brick's minimum as the previous launch left it.  All of them: nothing to read or write.
@@ -1168,10 +1257,13 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     if (TRUNC || have_min) {
       bool drop0 = TRUNC && ub_lane < -1.0f;
       if (have_min) {
-        const float smin0 = ((cfloat_ptr)brick_min)[brick_lin];  // (uniform: a scalar load)
+        float smin0;
+        if constexpr (kRows) smin0 = pair_valid ? brick_min[brick_seg + pair_j] : 0.0f;  // (this lane's brick)
+        else smin0 = ((cfloat_ptr)brick_min)[brick_lin];  // (uniform: a scalar load)
         drop0 = drop0 || ub_lane <= smin0;  // (a brick with an untouched voxel holds lowest(): never true)
       }
-      if ((__ballot(!drop0) & view_mask) == 0ull) {
+      live = __ballot(!drop0) & view_mask;
+      if (live == 0ull) {
         coop_leave();
         return;
       }
@@ -1228,13 +1320,55 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   // rows are whole bricks when nx % 8 == 0: the run is one 32-byte (sdf) and one 8/16-byte (update_num) vector
   const bool vec_io = (g.nx & (WX - 1)) == 0;
   typedef CountT CountVec __attribute__((ext_vector_type(WX)));
-  if (fresh) {  // a fresh slab is known to be untouched everywhere: nothing to read
+  if constexpr (kRows) {
+    // The state of every live brick of the segment, requested NOW with LDS-direct loads into the wave's staging area
+    // (row = the carving lane that owns it, 8 voxels per row): no registers, no waits -- the first tile wait below covers
+    // them (loads complete in order).  An sdf request r is one z slice of a brick: lane L -> dword L & 7 of row
+    // 8 r + (L >> 3), i.e. eight 32-byte row pieces; the pieces of the NB bricks of a row are requested back to back, so
+    // the memory system sees the row's 128 contiguous bytes together.  Counters: 8 (u8) or 16 (u16) bytes per row.
+#pragma unroll
+    for (int k = 0; k < WX; ++k) {
+      s[k] = kInvalidSdf;
+      n[k] = (NT)0;
+    }
+    if (lane < NB) stage_mask[lane] = 0ull;  // (a brick that is never begun is neither read nor stored)
+    if (!fresh) {
+      const int yl = min(by * BY + (lane >> 3), g.ny - 1);
+      const unsigned off_s = (unsigned)yl * (unsigned)g.nx + (unsigned)(lane & 7);   // (floats; + slice base + brick origin)
+      constexpr int kCntPerDword = 4 / (int)sizeof(CountT);            // counters per dword: 4 (u8) or 2 (u16)
+      constexpr int kCntDwordsPerRow = WX / kCntPerDword;              // 2 or 4
+      constexpr int kCntRowsPerReq = 64 / kCntDwordsPerRow;            // 32 or 16 rows per request
+      constexpr int kCntReqs = 64 / kCntRowsPerReq;                    // 2 or 4 requests per brick
+      const int crow = lane / kCntDwordsPerRow;                        // row within a request
+      typedef const CountT __attribute__((address_space(1))) * gcnt_ptr;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if (((live >> (8 * j)) & 0xffull) == 0ull) continue;  // (uniform) no live view: neither read nor written
+        const int xb = x_seg + j * WX;
+#pragma unroll
+        for (int r = 0; r < BZ; ++r) {
+          const int zr = min(zl0 + r, g.nz_local - 1);
+          gfloat_ptr src = (gfloat_ptr)g.sdf + ((int64_t)zr * g.ny * g.nx + xb);
+          __builtin_amdgcn_global_load_lds(src + off_s, (lds_float*)(stage_s + (j * 64 + 8 * r) * WX), 4, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < kCntReqs; ++r) {
+          const int row = r * kCntRowsPerReq + crow;  // = ly | lz << 3 of the lane that carves it
+          const int yr = min(by * BY + (row & 7), g.ny - 1), zr = min(zl0 + (row >> 3), g.nz_local - 1);
+          gcnt_ptr src = (gcnt_ptr)cnt + (((int64_t)zr * g.ny + yr) * g.nx + xb + (lane % kCntDwordsPerRow) * kCntPerDword);
+          __builtin_amdgcn_global_load_lds((const uint32_t __attribute__((address_space(1)))*)src,
+                                           (lds_u32*)(uint32_t*)(stage_n + (j * 64 + r * kCntRowsPerReq) * WX), 4, 0, 0);
+        }
+      }
+    }
+  } else if (fresh) {  // a fresh slab is known to be untouched everywhere: nothing to read
 #pragma unroll
     for (int k = 0; k < WX; ++k) {
       s[k] = kInvalidSdf;
       n[k] = (NT)0;
     }
   } else if (vec_io) {
+    // (streaming LOADS of the state were measured too: 2.7 -> 5.3 ms per view, profiles/r06/nontemporal.txt)
     const float4 a = *(const float4*)(g.sdf + row0 + x_first), b4 = *(const float4*)(g.sdf + row0 + x_first + 4);
     const CountVec cv = *(const CountVec*)(cnt + row0 + x_first);
     prefetch_first_tile();  // (behind the state's requests, in front of their first use)
@@ -1261,16 +1395,17 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     for (int k = 1; k < WX; ++k) nmin = min(nmin, n[k]);
     all_touched = __all(nmin >= (NT)1);
   };
-  if (!fresh) refresh_all_touched();
+  if (!fresh && !kRows) refresh_all_touched();
   // No voxel of the brick touched yet?  (Wave-uniform; true for every brick of a fresh slab.)  The first `sure`
   // view of such a brick is a plain store of the samples (carve_view_fast<FIRST>).
   bool none_touched = fresh != 0;
-  if (!fresh && UPDATE == VCY_UPDATE_MAX && !all_touched) {
+  auto refresh_none_touched = [&]() {
     NT nmax = n[0];
 #pragma unroll
     for (int k = 1; k < WX; ++k) nmax = max(nmax, n[k]);
     none_touched = __all(nmax < (NT)1);
-  }
+  };
+  if (!kRows && !fresh && UPDATE == VCY_UPDATE_MAX && !all_touched) refresh_none_touched();
   // Weighted average: does every voxel of the brick carry the same update_num?  (Wave-uniform; true for a
   // fresh slab, and it stays true while every processed view updates every voxel -- the views whose tile
   // provably holds no sample below -1.)  Then the weights of the average, fn and 1 / (fn + 1), are the same
@@ -1278,9 +1413,11 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   // n[] is only brought up to date when the brick leaves this state, and at the write-back.
   bool uniform_cnt = false;
   float fnu = 0.0f;  // the common update_num (as a float, like n[])
-  if (UPDATE != VCY_UPDATE_MAX) {
+  auto refresh_uniform_cnt = [&]() {
+    if (UPDATE == VCY_UPDATE_MAX) return;
     if (fresh) {
       uniform_cnt = true;
+      fnu = 0.0f;
     } else {
       const float f0 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)n[0])));
       bool same = true;
@@ -1289,7 +1426,8 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
       uniform_cnt = __all(same);
       fnu = f0;
     }
-  }
+  };
+  if (!kRows) refresh_uniform_cnt();
   auto leave_uniform = [&]() {
     if (!uniform_cnt) return;
     uniform_cnt = false;
@@ -1297,6 +1435,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     for (int k = 0; k < WX; ++k) n[k] = (NT)fnu;
   };
   // views that may still change something, as a wave-uniform bit mask
+  int jc = -1;  // NB > 1: the brick of the segment whose state is in registers
   auto live_views = [&]() -> unsigned long long {
     bool drop = false;
     if (want_bound) {
@@ -1309,20 +1448,78 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
         drop = drop || ub_lane <= smin;
       }
     }
+    if constexpr (kRows) {  // (the bounds of the other bricks' pairs stand as they are)
+      const unsigned long long cur_bits = 0xffull << (8 * jc);
+      return (live & ~cur_bits) | (__ballot(!drop) & view_mask & cur_bits);
+    }
     return __ballot(!drop) & view_mask;
   };
+  const int vi_end = kRows ? 64 : nviews;  // "no further view / pair"
   auto next_view = [&](unsigned long long live, int after) -> int {
     const unsigned long long rest = (after >= 63) ? 0ull : (live & ~((2ull << after) - 1ull));
-    return rest ? (__ffsll((long long)rest) - 1) : nviews;
+    return rest ? (__ffsll((long long)rest) - 1) : vi_end;
   };
 
   // Lanes whose voxels changed (update_num grows with every change), accumulated over the views: what the write-back
   // stores.  (Round 3 re-read update_num from memory and compared: a dependent round trip in every wave's chain.  It
   // turned out not to be what bounds a single-view launch -- see DESIGN section 8 -- but there is no reason to keep it.)
   unsigned long long changed_lanes = 0ull;
-  unsigned long long live = live_views();
-  int vi = live ? (__ffsll((long long)live) - 1) : nviews;
-  if (kRaw && vi < nviews && vi != vi_pre) raw_prefetch(views[vi].v, tinfo[vi], lane, raw_buf(0));
+  if (!kRows) live = live_views();
+  int vi = live ? (__ffsll((long long)live) - 1) : vi_end;
+  if (kRaw && vi < vi_end && vi != vi_pre) raw_prefetch(views[kRows ? (vi & 7) : vi].v, tinfo[vi], lane, raw_buf(0));
+  // NB > 1: the brick whose turn it is takes its state from the staging area (the LDS-direct requests above have
+  // landed once the wave has waited for its first tile) and leaves it there again when the next brick begins
+  typedef CountT CountVecR __attribute__((ext_vector_type(WX)));
+  typedef CountVecR __attribute__((address_space(3))) lds_countvec_r;
+  auto finish_brick = [&]() {
+    if constexpr (kRows) {
+      leave_uniform();
+      if (brick_min != nullptr && implied) {
+        float m = s[0];
+#pragma unroll
+        for (int k = 1; k < WX; ++k) m = fminf(m, s[k]);
+        const float smin = wave_min(m);
+        if (lane == 0) brick_min[brick_lin] = smin;
+      }
+      lds_float4* rs = (lds_float4*)(float4*)(stage_s + (jc * 64 + lane) * WX);
+      rs[0] = f4{s[0], s[1], s[2], s[3]};
+      rs[1] = f4{s[4], s[5], s[6], s[7]};
+      CountVecR cv;
+#pragma unroll
+      for (int k = 0; k < WX; ++k) cv[k] = (CountT)n[k];
+      *(lds_countvec_r*)(CountVecR*)(stage_n + (jc * 64 + lane) * WX) = cv;
+      if (lane == 0) stage_mask[jc] = fresh ? ~0ull : changed_lanes;
+    }
+  };
+  auto begin_brick = [&](int j) {
+    if constexpr (kRows) {
+      jc = j;
+      x_first = x_seg + j * WX;
+      brick_lin = brick_seg + j;
+      changed_lanes = 0ull;
+      if (fresh) {
+#pragma unroll
+        for (int k = 0; k < WX; ++k) {
+          s[k] = kInvalidSdf;
+          n[k] = (NT)0;
+        }
+      } else {
+        const lds_float4* rs = (const lds_float4*)(float4*)(stage_s + (j * 64 + lane) * WX);
+        const f4 a = rs[0], b4 = rs[1];
+        const CountVecR cv = *(const lds_countvec_r*)(CountVecR*)(stage_n + (j * 64 + lane) * WX);
+        s[0] = a.x, s[1] = a.y, s[2] = a.z, s[3] = a.w, s[4] = b4.x, s[5] = b4.y, s[6] = b4.z, s[7] = b4.w;
+#pragma unroll
+        for (int k = 0; k < WX; ++k) n[k] = (NT)cv[k];
+      }
+      all_touched = false;
+      none_touched = fresh != 0;
+      if (!fresh) {
+        refresh_all_touched();
+        if (UPDATE == VCY_UPDATE_MAX && !all_touched) refresh_none_touched();
+      }
+      refresh_uniform_cnt();
+    }
+  };
   VCY_PT(0);
   VCY_PT_COUNT(10);
 
@@ -1334,11 +1531,27 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
 #endif
   // ---- views ------------------------------------------------------------------------------
   int n_processed = 0;  // (wave-uniform: an SGPR; only read with "paircount" on)
-  while (vi < nviews) {
-    ++n_processed;
-    const ViewParams& v = views[vi].v;
+  while (vi < vi_end) {
+    if constexpr (kRows) {
+      if ((vi >> 3) != jc) {  // (uniform) the next pair belongs to another brick of the segment
+        raw_tile_wait();      // everything requested so far has landed: the state of every brick, this pair's tile
+        wave_lds_fence();
+        if (jc >= 0) finish_brick();
+        begin_brick(vi >> 3);
+        // the bounds of this brick's pairs against its state as it really is (the kept minima may be invalid or absent)
+        live = live_views();
+        if (((live >> vi) & 1ull) == 0ull) {
+          vi = next_view(live, vi);
+          // (the dropped pair's pixels may still be arriving in that buffer: loads complete in order)
+          if (vi < vi_end) raw_prefetch(views[vi & 7].v, tinfo[vi], lane, raw_buf(cur));
+          continue;
+        }
+      }
+    }
+    const int vv = kRows ? (vi & 7) : vi;  // the view of pair vi
+    const ViewParams& v = views[vv].v;
     // this view's record of the wave brick's x products: (x, y) pairs at [2 k], z at [16 + k]
-    cfloat_ptr c0 = (cfloat_ptr)(c0_all + ((size_t)vi * (nxp / WX) + (x_first / WX)) * kC0Stride);
+    cfloat_ptr c0 = (cfloat_ptr)(c0_all + ((size_t)vv * (nxp / WX) + (x_first / WX)) * kC0Stride);
     // stage this view's tile (wave-private: program order is enough)
     VCY_SETPRIO(3);
     wave_lds_fence();
@@ -1350,7 +1563,8 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
     wave_lds_fence();
     // the next live view's tile is fetched while this one is computed
     int vnext = next_view(live, vi);
-    if (kRaw && vnext < nviews) raw_prefetch(views[vnext].v, tinfo[vnext], lane, raw_buf(cur ^ 1));
+    if (kRaw && vnext < vi_end) raw_prefetch(views[kRows ? (vnext & 7) : vnext].v, tinfo[vnext], lane, raw_buf(cur ^ 1));
+    ++n_processed;
     const float pitchf = tinfo[vi].pitchf;
     const int base = tinfo[vi].base;
     const int big_pitch = kRaw ? 16 : (int)pitchf;  // pixels per row of the big tile
@@ -1621,7 +1835,7 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
       if (v2 != vnext) {
         vnext = v2;
         // (the dropped view's pixels may still be arriving in that buffer: loads complete in order)
-        if (kRaw && vnext < nviews) raw_prefetch(views[vnext].v, tinfo[vnext], lane, raw_buf(cur ^ 1));
+        if (kRaw && vnext < vi_end) raw_prefetch(views[kRows ? (vnext & 7) : vnext].v, tinfo[vnext], lane, raw_buf(cur ^ 1));
       }
     }
     vi = vnext;
@@ -1630,6 +1844,40 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
   }
 
   // ---- write back what changed (update_num grows with every change) ----------------------------
+  if constexpr (kRows) {
+    if (jc >= 0) finish_brick();
+    wave_lds_fence();
+    if (pair_count != nullptr && lane == 0) atomicAdd(&pair_count[bz], (unsigned long long)n_processed);
+    // Whole row segments: request i writes z slice i of the segment -- lane L the 16-byte chunk L & 7 of voxel row
+    // 8 i + (L >> 3), so 8 lanes store the 128 contiguous bytes the segment has in that row (NB = 4) -- for the rows
+    // whose carving lane changed (stage_mask of the chunk's brick; every row of a fresh slab).
+    {
+      const int yw = by * BY + (lane >> 3), c16 = lane & 7, jw = c16 >> 1;
+      const unsigned long long mw = jw < NB ? stage_mask[jw] : 0ull;
+      const bool col_ok = jw < NB && yw < g.ny && x_seg + 4 * c16 < g.nx;
+#pragma unroll
+      for (int i = 0; i < BZ; ++i) {
+        const int row = 8 * i + (lane >> 3);
+        if (zl0 + i < g.nz_local && col_ok && ((mw >> row) & 1ull) != 0ull) {
+          const f4 q = *(const lds_float4*)(float4*)(stage_s + (jw * 64 + row) * WX + (c16 & 1) * 4);
+          *(float4*)(g.sdf + (((int64_t)(zl0 + i) * g.ny + yw) * g.nx + x_seg + 4 * c16)) = make_float4(q.x, q.y, q.z, q.w);
+        }
+      }
+      // counters: lane L the 8 (u8) / 16 (u16) bytes brick L & 3 has in voxel row 16 i + (L >> 2)
+      const int jn = lane & 3;
+      const unsigned long long mn = jn < NB ? stage_mask[jn] : 0ull;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 16 * i + (lane >> 2);
+        const int yn = by * BY + (row & 7), zn = zl0 + (row >> 3);
+        if (jn < NB && yn < g.ny && zn < g.nz_local && x_seg + WX * jn < g.nx && ((mn >> row) & 1ull) != 0ull) {
+          const CountVecR cv = *(const lds_countvec_r*)(CountVecR*)(stage_n + (jn * 64 + row) * WX);
+          *(CountVecR*)(cnt + (((int64_t)zn * g.ny + yn) * g.nx + x_seg + WX * jn)) = cv;
+        }
+      }
+    }
+    return;
+  }
   leave_uniform();
   // Where this lane's run lies is worked out again from the thread id (opaque to the compiler): kept from the prologue
   // it occupies three registers through every view, and the weighted-average kernels are short of exactly those --
@@ -1697,7 +1945,10 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
         const f4 v = *(lds_float4*)(float4*)(coop_s + r * kCoopSdfPitch + ch * 4);
         const int64_t rowg = ((int64_t)(zl0 + (r >> 3)) * g.ny + (by * BY + (r & 7))) * g.nx;
 #ifndef VCY_DEV_SKIP_SDF_STORE  // (development builds: which of the two arrays the written bytes belong to)
-        *(float4*)(g.sdf + rowg + xb + ch * 4) = make_float4(v.x, v.y, v.z, v.w);
+        // (whole 128-byte row segments: as streaming stores when the launch asks for it -- state_flags bit 4, the first
+        // view on a fresh grid, where nothing written is read again by this launch; launch_carve_fused)
+        if (nt_store) __builtin_nontemporal_store(v, (f4*)(g.sdf + rowg + xb + ch * 4));
+        else *(float4*)(g.sdf + rowg + xb + ch * 4) = make_float4(v.x, v.y, v.z, v.w);
 #else
         if (v.x == 1.2345e-30f) g.sdf[0] = v.y;
 #endif
@@ -1711,7 +1962,8 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
         const CountVec8 cv = *(lds_countvec*)(CountVec8*)(coop_n + r * coop_cnt_pitch<CountT>() + ch * WX);
         const int64_t rowg = ((int64_t)(zl0 + (r >> 3)) * g.ny + (by * BY + (r & 7))) * g.nx;
 #ifndef VCY_DEV_SKIP_CNT_STORE
-        *(CountVec8*)(cnt + rowg + xb + ch * WX) = cv;
+        if (nt_store) __builtin_nontemporal_store(cv, (CountVec8*)(cnt + rowg + xb + ch * WX));
+        else *(CountVec8*)(cnt + rowg + xb + ch * WX) = cv;
 #else
         if (cv[0] == (CountT)12345) cnt[0] = cv[1];
 #endif
@@ -1768,8 +2020,32 @@ __attribute__((amdgpu_waves_per_eu((!GEN && !CHECKMAX && TQ == kTileRaw && UPDAT
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF>
 void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const GridParams& g, const FusedView* dv,
                     const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh,
-                    const FootprintRecord* recs, int64_t nbricks, float* bmin, const int* wgl, unsigned long long* pcnt) {
+                    const FootprintRecord* recs, int64_t nbricks, float* bmin, const int* wgl, unsigned long long* pcnt,
+                    int row_units) {
   const bool gen = m.ortho != 0 || m.interp == VCY_INTERP_NN;
+  if (row_units > 0) {
+    // the few-view flavour: `grid` workgroups of kRowWaves waves, a segment of kRowBricks bricks per wave; `nbx` =
+    // segments per brick row, `row_units` = segments of the launch (what the block decode deals to the XCDs)
+    const BlockDecode bd = make_block_decode((unsigned)row_units, nbx, nby);
+    const size_t lds = (size_t)kRowWaves * row_lds_bytes_per_wave<CountT, kRowBricks>();
+#define VCY_ROWS(GEN_, DIV_)                                                                                         \
+  hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, false, kTileRaw, GEN_, DIV_, kRowBricks>), grid, \
+                     dim3(64 * kRowWaves), lds, s, g, dv, c2, nv, m, nbx, nby, bd, cull, fresh, recs, nbricks, bmin, wgl, pcnt)
+#ifdef VCY_DEV_BENCH_KERNELS_ONLY
+    if (gen || m.div_level != 2 || !SAMEF || sizeof(CountT) != 1 || UPDATE == VCY_UPDATE_WEIGHTED_AVERAGE) {
+      fprintf(stderr, "VCY_DEV_BENCH_KERNELS_ONLY: kernel variant not built\n");
+      abort();
+    }
+    if constexpr (SAMEF && sizeof(CountT) == 1 && UPDATE != VCY_UPDATE_WEIGHTED_AVERAGE) VCY_ROWS(false, 2);
+#else
+    if (gen) VCY_ROWS(true, 0);
+    else if (m.div_level == 2) VCY_ROWS(false, 2);
+    else if (m.div_level == 1) VCY_ROWS(false, 1);
+    else VCY_ROWS(false, 0);
+#endif
+#undef VCY_ROWS
+    return;
+  }
 #define VCY_FUSED(CM, TQ_, GEN_, DIV_)                                                                           \
   hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, CM, TQ_, GEN_, DIV_>), grid, dim3(64 * kWgWaves),  \
                      (size_t)kWgWaves * tile_f4_per_wave<TQ_>() * sizeof(float4) + (size_t)kWgWaves * nv * sizeof(TileInfo) + \
@@ -1806,26 +2082,28 @@ void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const Gri
 template <typename CountT, int UPDATE>
 void launch_fused_2(bool big, bool trunc, bool samef, bool checkmax, dim3 grid, hipStream_t s, const GridParams& g,
                     const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh,
-                    const FootprintRecord* recs, int64_t nbricks, float* bmin, const int* wgl, unsigned long long* pcnt) {
+                    const FootprintRecord* recs, int64_t nbricks, float* bmin, const int* wgl, unsigned long long* pcnt,
+                    int row_units) {
   if (trunc) {
-    if (samef) launch_fused_4<CountT, UPDATE, true, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt);
-    else launch_fused_4<CountT, UPDATE, true, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt);
+    if (samef) launch_fused_4<CountT, UPDATE, true, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt, row_units);
+    else launch_fused_4<CountT, UPDATE, true, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt, row_units);
   } else {
-    if (samef) launch_fused_4<CountT, UPDATE, false, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt);
-    else launch_fused_4<CountT, UPDATE, false, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt);
+    if (samef) launch_fused_4<CountT, UPDATE, false, true>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt, row_units);
+    else launch_fused_4<CountT, UPDATE, false, false>(big, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt, row_units);
   }
 }
 
 template <typename CountT>
 void launch_fused_1(bool big, int update, bool trunc, bool samef, bool checkmax, dim3 grid, hipStream_t s,
                     const GridParams& g, const FusedView* dv, const float* c2, int nv, const ModeParams& m, int nbx, int nby, int cull, int fresh,
-                    const FootprintRecord* recs, int64_t nbricks, float* bmin, const int* wgl, unsigned long long* pcnt) {
+                    const FootprintRecord* recs, int64_t nbricks, float* bmin, const int* wgl, unsigned long long* pcnt,
+                    int row_units) {
   if (update == VCY_UPDATE_MAX)
-    launch_fused_2<CountT, VCY_UPDATE_MAX>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt);
+    launch_fused_2<CountT, VCY_UPDATE_MAX>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt, row_units);
   else if (g.weight == 1.0f)
-    launch_fused_2<CountT, kUpdateWaUnitWeight>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt);
+    launch_fused_2<CountT, kUpdateWaUnitWeight>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt, row_units);
   else
-    launch_fused_2<CountT, VCY_UPDATE_WEIGHTED_AVERAGE>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt);
+    launch_fused_2<CountT, VCY_UPDATE_WEIGHTED_AVERAGE>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt, row_units);
 }
 
 // Exhaustive check of the short division sequences for ONE numerator: every significand of the
@@ -2192,11 +2470,20 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   // of views and the barrier costs 3 - 4 %, profiles/r04/coop_store_batches.txt; weighted average: up to 8 views, 0 ... +2 %;
   // a fresh grid: single-view launches in either mode -- the fused 32-view launch gained nothing from whole-segment
   // stores in round 3)
-  const bool coop_ok = (kWgWaves == 4 || kWgWaves == 8) && (c->nx & (WX - 1)) == 0 && !big;
+  // The few-view flavour (kRowBricks: a wave walks the bricks of a row segment): launches of up to kRowMaxViews views with
+  // raw tiles and records from the pre-pass, over rows of whole bricks, no update limit in reach.  "rowkernel" -1 that
+  // rule, 0 never (the NB = 1 kernel with its cooperative write-back), n > 0: launches of up to min(n, 8) views.
+  const int row_views = c->row_kernel < 0 ? kRowMaxViews : std::min(c->row_kernel, kRowMaxViews);
+  const bool rows = !big && !checkmax && (c->nx & (WX - 1)) == 0 && n_views <= row_views && c->prologue_mode != 1;
+  const int nseg = (nbw + kRowBricks - 1) / kRowBricks;  // segments per brick row
+  const bool coop_ok = (kWgWaves == 4 || kWgWaves == 8) && (c->nx & (WX - 1)) == 0 && !big && !rows;
   const int coop_views = c->fresh ? 1 : (u.voxel_update == VCY_UPDATE_MAX ? 1 : kLiveListMaxViews);
   const bool coop = coop_ok && (c->coop_store > 0 || (c->coop_store < 0 && n_views <= coop_views));
+  // "ntstore": streaming stores whenever the cooperative write-back runs (0: never) -- whole 128-byte segments that this
+  // launch does not read again: 0.5 - 1.5 % on single-view launches (profiles/r06/nontemporal.txt)
+  const bool nt = coop && c->nt_store != 0;
   const int state_flags = (c->fresh ? 1 : 0) | (c->cnt_implied ? 2 : 0) | (c->brick_min_valid && !c->fresh ? 4 : 0) |
-                          (coop ? 8 : 0);
+                          (coop ? 8 : 0) | (nt ? 16 : 0);
   // Raw tiles: the footprint records of every (wave brick, view) pair come from a pre-pass (footprint_records_kernel),
   // 8 bytes per pair.  The slab is carved in chunks of whole brick layers so that the records of a chunk stay
   // below kRecordBytesMax (1024^3 x 32 views: 0.5 GiB, one chunk; 2048^3 x 64: nine).
@@ -2267,8 +2554,15 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
 #undef VCY_PREPASS
       VCY_HIP_CHECK(hipGetLastError());
     }
-    const dim3 grid((unsigned)((int64_t)nbx * nby * layers));
-    dim3 launch_grid = grid;
+    // units of the launch: workgroup blocks of kWgWaves bricks, or the segments of the few-view flavour (one per wave)
+    const int unit_bricks = rows ? kRowBricks : kWgWaves;
+    const int units_x = rows ? nseg : nbx;
+    const dim3 grid((unsigned)((int64_t)units_x * nby * layers));
+    auto groups_of = [&](unsigned units) {  // workgroups that hold `units` listed units
+      return rows ? dim3((units + kRowWaves - 1) / kRowWaves) : dim3(units);
+    };
+    // (unlisted launch of the few-view flavour: unit (g mod 8) + 8 (kRowWaves (g / 8) + wave) of workgroup g)
+    dim3 launch_grid = rows ? dim3(8u * ((grid.x + 8u * kRowWaves - 1) / (8u * kRowWaves))) : grid;
     // few views over a carved grid: only the workgroups with a live (brick, view) pair (live_workgroups_kernel)
     const int* wgl = nullptr;
     const bool have_min = u.voxel_update == VCY_UPDATE_MAX && (state_flags & 4) != 0 && bmin != nullptr;
@@ -2293,7 +2587,8 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
       }
       VCY_HIP_CHECK(hipMemsetAsync(c->d_wg_list, 0, sizeof(int), c->stream));
       hipLaunchKernelGGL(live_workgroups_kernel, dim3((unsigned)((nwg + kLiveThreads - 1) / kLiveThreads)), dim3(kLiveThreads), 0, c->stream, recs, nbricks,
-                         n_views, have_min ? bmin : nullptr, m.trunc, nbx, nby, nbw, nwg, c->d_wg_list);
+                         n_views, have_min ? bmin : nullptr, m.trunc, units_x, nby, nbw, nwg, c->d_wg_list, unit_bricks);
+      launch_grid = groups_of((unsigned)nwg);  // (every unit started unless the count below arrives)
       VCY_HIP_CHECK(hipGetLastError());
       wgl = c->d_wg_list;
       if (!c->h_live_hint && hipHostMalloc((void**)&c->h_live_hint, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
@@ -2309,7 +2604,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
         // (profiles/tools/per_view_floor.py), a sixth of a single-view launch.  ("livesync" 0: the full grid, no wait.)
         if (c->live_sync && hipStreamSynchronize(c->stream) == hipSuccess) {
           const int live = c->h_live_hint[0];
-          if (live >= 0 && live <= nwg) launch_grid = dim3((unsigned)live);
+          if (live >= 0 && live <= nwg) launch_grid = groups_of((unsigned)live);
         } else {
           (void)hipGetLastError();
         }
@@ -2320,10 +2615,12 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
       // (no workgroup is live: nothing to launch)
     } else if (c->cnt_bytes == 1)
       launch_fused_1<uint8_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, launch_grid, c->stream, gc, d_views,
-                              d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin, wgl, pcnt);
+                              d_c2, n_views, m, units_x, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin, wgl, pcnt,
+                              rows ? (int)grid.x : 0);
     else
       launch_fused_1<uint16_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, launch_grid, c->stream, gc, d_views,
-                               d_c2, n_views, m, nbx, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin, wgl, pcnt);
+                               d_c2, n_views, m, units_x, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin, wgl, pcnt,
+                               rows ? (int)grid.x : 0);
     VCY_HIP_CHECK(hipGetLastError());
     if (stamp >= 0) VCY_HIP_CHECK(hipEventRecord(c->carve_log[stamp].ev[2], c->stream));
   }

@@ -30,6 +30,8 @@
 //
 // Memory-bound, no MFMA: 4 B (sdf) per cell algorithmic; real traffic = one read of sdf +
 // update_num, everything else is 1 bit per voxel/cell, plus 12 B per vertex/triangle out.
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <utility>
@@ -1163,10 +1165,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCY_EMIT_WA
                                                       const u64* __restrict__ block_offs,
                                                       const u64* __restrict__ grand_total_dev, int64_t verts_capacity,
                                                       int64_t faces_capacity, float* __restrict__ verts,
-                                                      long long* __restrict__ keys, int* __restrict__ faces) {
+                                                      long long* __restrict__ keys, int* __restrict__ faces,
+                                                      const u64* __restrict__ ghost_cells_dev, u64* __restrict__ report) {
   const int64_t ncells = min((int64_t)*ncells_dev, capacity);
-  if ((int64_t)*ncells_dev > capacity) return;  // the host sees the same totals and runs again with room
   const u64 grand_total = *grand_total_dev;
+  // The counts the host needs, written by the LAST kernel of the chain straight into page-locked host memory (`report`):
+  // active cells, how many of them are ghost cells, (vertices << 32 | triangles), and the vertices owned by ghost cells
+  // = the vertex prefix of list entry `nghost`.  The host used to fetch these with three 8-byte copies into pageable
+  // memory plus two more for the ghost prefix -- each a blocking round trip -- in the middle of every extraction.
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const u64 nc = *ncells_dev, ng = *ghost_cells_dev;
+    u64 foreign = 0;
+    if ((int64_t)nc <= capacity && ng > 0) {
+      if (ng >= nc) foreign = grand_total >> 32;
+      else foreign = (block_offs[ng >> 8] >> 32) + (info[ng] >> 20);
+    }
+    report[0] = nc;
+    report[1] = ng;
+    report[2] = grand_total;
+    report[3] = foreign;
+  }
+  if ((int64_t)*ncells_dev > capacity) return;  // the host sees the same totals and runs again with room
   if ((int64_t)(grand_total >> 32) > verts_capacity || (int64_t)(grand_total & 0xFFFFFFFFull) > faces_capacity) return;
   __shared__ int sm[4];
   __shared__ float sv[3 * kEmitMaxVerts];
@@ -1692,62 +1711,107 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
     const ChainedScanSlot sl = scan_slot(1);
     return exclusive_scan_u64(b.counts, b.blocks, b.total, b.scan, s, &sl);
   };
-  // output staging, cached in the context and grown on demand; then the emit pass
+  // The counts come back through 64 bytes of page-locked memory that mc_emit writes itself (see the kernel).
+  if (!c->h_mc_report) {
+    MC_TRY(hipHostMalloc((void**)&c->h_mc_report, 64, hipHostMallocDefault));
+    std::memset((void*)c->h_mc_report, 0, 64);
+  }
+  volatile u64* report = (volatile u64*)c->h_mc_report;
+  const bool timing = c->mc_timing != 0;
+  double t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto now_us = []() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  };
+  const double t_begin = timing ? now_us() : 0.0;
+  // Output arrays.  A mesh of up to "mcdirect" bytes (default 8 MiB) is written by mc_emit STRAIGHT into the page-locked
+  // host arrays the caller receives (whole rows of dwords over PCIe while other blocks still compute): the call is then
+  // one enqueue and one wait.  Larger meshes are staged in device memory and copied with exact sizes after the counts
+  // are known (over-copying the guess's headroom would cost more than the second wait).
+  bool direct = false;
+  auto release_host = [&]() {
+    mesh_host_free(out->vertices);
+    mesh_host_free(out->faces);
+    mesh_host_free(out->edge_keys);
+    out->vertices = nullptr, out->faces = nullptr, out->edge_keys = nullptr;
+  };
   auto enqueue_emit = [&](const CellBuffers& b, int64_t cap_cells, int64_t cap_v, int64_t cap_f) -> int {
     const size_t sz_v = align(sizeof(float) * 3 * (size_t)std::max<int64_t>(cap_v, 1));
     const size_t sz_k = align(sizeof(long long) * 2 * (size_t)std::max<int64_t>(cap_v, 1));
     const size_t sz_f = align(sizeof(int) * 3 * (size_t)std::max<int64_t>(cap_f, 1));
-    if (c->mc_out_bytes < sz_v + sz_k + sz_f) {
-      MC_TRY(hipStreamSynchronize(s));
-      if (c->d_mc_out) MC_TRY(hipFree(c->d_mc_out));
-      c->d_mc_out = nullptr;
-      c->mc_out_bytes = 0;
-      MC_TRY(hipMalloc(&c->d_mc_out, sz_v + sz_k + sz_f));
-      c->mc_out_bytes = sz_v + sz_k + sz_f;
+    direct = false;
+    if ((int64_t)(sz_v + sz_f + (c->mesh_keys ? sz_k : 0)) <= c->mc_direct_bytes) {
+      bool pinned = true, pk = true, pf = true;
+      out->vertices = (float*)mesh_host_alloc(sz_v, &pinned);
+      out->faces = (int32_t*)mesh_host_alloc(sz_f, &pf);
+      if (c->mesh_keys) out->edge_keys = (int64_t*)mesh_host_alloc(sz_k, &pk);
+      direct = out->vertices && out->faces && (!c->mesh_keys || out->edge_keys) && pinned && pf && pk;
+      if (!direct) release_host();
     }
-    d_verts = (float*)c->d_mc_out;
-    d_keys = c->mesh_keys ? (long long*)((char*)c->d_mc_out + sz_v) : nullptr;
-    d_faces = (int*)((char*)c->d_mc_out + sz_v + sz_k);
+    if (direct) {
+      d_verts = out->vertices;
+      d_keys = c->mesh_keys ? (long long*)out->edge_keys : nullptr;
+      d_faces = (int*)out->faces;
+    } else {
+      if (c->mc_out_bytes < sz_v + sz_k + sz_f) {
+        MC_TRY(hipStreamSynchronize(s));
+        if (c->d_mc_out) MC_TRY(hipFree(c->d_mc_out));
+        c->d_mc_out = nullptr;
+        c->mc_out_bytes = 0;
+        MC_TRY(hipMalloc(&c->d_mc_out, sz_v + sz_k + sz_f));
+        c->mc_out_bytes = sz_v + sz_k + sz_f;
+      }
+      d_verts = (float*)c->d_mc_out;
+      d_keys = c->mesh_keys ? (long long*)((char*)c->d_mc_out + sz_v) : nullptr;
+      d_faces = (int*)((char*)c->d_mc_out + sz_v + sz_k);
+    }
     hipLaunchKernelGGL(mc_emit_kernel, dim3(b.blocks), dim3(256), 0, s, p, T, d_act, b.list, d_total, cap_cells, d_woff,
-                       d_wcounts, b.info, b.nact, b.counts, b.total, cap_v, cap_f, d_verts, d_keys, d_faces);
+                       d_wcounts, b.info, b.nact, b.counts, b.total, cap_v, cap_f, d_verts, d_keys, d_faces,
+                       d_wcounts + p.G / kWordsPerBlock, (u64*)c->h_mc_report);
     MC_TRY(hipGetLastError());
     return VCY_OK;
   };
   // number of active cells, and how many of them are ghost cells (words below G)
-  u64 h_cells[2] = {0, 0}, h_tot = 0;
-  int64_t ncells = 0, nghost = 0, nv = 0, nf = 0;
+  int64_t ncells = 0, nghost = 0, nv = 0, nf = 0, nforeign = 0;
   CellBuffers cb{};
   bool done = false, end_recorded = false;
   auto with_headroom = [](int64_t v) { return v + v / 4 + 4096; };  // the next view's mesh is a little different
+  auto read_report = [&]() {
+    ncells = (int64_t)report[0];
+    nghost = (int64_t)report[1];
+    nv = (int64_t)(report[2] >> 32);
+    nf = (int64_t)(report[2] & 0xFFFFFFFFull);
+    nforeign = (int64_t)report[3];
+  };
+  if (timing) t_ph[0] = now_us();
   if (c->mc_hint_cells > 0) {
     const int64_t cap_cells = with_headroom(c->mc_hint_cells);
     const int64_t cap_v = with_headroom(c->mc_hint_verts), cap_f = with_headroom(c->mc_hint_faces);
     rc = cell_buffers(cap_cells, &cb);
     if (rc == VCY_OK) rc = enqueue_owners(cb, cap_cells);
     if (rc == VCY_OK) rc = enqueue_emit(cb, cap_cells, cap_v, cap_f);
-    if (rc != VCY_OK) return rc;
-    // (the end of the kernels: what follows is three 8-byte copies and the host's wait for them, which
-    // last_extract_device_ms -- "kernels only" -- used to include: 40 - 80 us of a 0.3 ms extraction at 512^3)
+    if (rc != VCY_OK) {
+      release_host();
+      return rc;
+    }
+    // (the end of the kernels: last_extract_device_ms is "kernels only")
     MC_TRY(hipEventRecord(c->ev_mc_end, s));
     end_recorded = true;
-    MC_TRY(hipMemcpyAsync(&h_cells[0], d_total, sizeof(u64), hipMemcpyDeviceToHost, s));
-    MC_TRY(hipMemcpyAsync(&h_cells[1], d_wcounts + p.G / kWordsPerBlock, sizeof(u64), hipMemcpyDeviceToHost, s));
-    MC_TRY(hipMemcpyAsync(&h_tot, cb.total, sizeof(u64), hipMemcpyDeviceToHost, s));
-    MC_TRY(hipStreamSynchronize(s));
-    ncells = (int64_t)h_cells[0];
-    nghost = (int64_t)h_cells[1];
-    nv = (int64_t)(h_tot >> 32);
-    nf = (int64_t)(h_tot & 0xFFFFFFFFull);
+    if (timing) t_ph[1] = now_us();
+    MC_TRY(hipStreamSynchronize(s));  // the ONE wait of an extraction whose mesh went straight to host memory
+    if (timing) t_ph[2] = now_us();
+    read_report();
     done = ncells <= cap_cells && nv <= cap_v && nf <= cap_f;
     if (ncells == 0) nv = nf = 0;
+    if (!done) release_host();
   }
   if (!done) {
-    MC_TRY(hipMemcpyAsync(&h_cells[0], d_total, sizeof(u64), hipMemcpyDeviceToHost, s));
-    MC_TRY(hipMemcpyAsync(&h_cells[1], d_wcounts + p.G / kWordsPerBlock, sizeof(u64), hipMemcpyDeviceToHost, s));
+    // first extraction of a context, or a guess that was too small: the counts first, then buffers of the right size
+    MC_TRY(hipMemcpyAsync((void*)&report[0], d_total, sizeof(u64), hipMemcpyDeviceToHost, s));
+    MC_TRY(hipMemcpyAsync((void*)&report[1], d_wcounts + p.G / kWordsPerBlock, sizeof(u64), hipMemcpyDeviceToHost, s));
     MC_TRY(hipStreamSynchronize(s));
-    ncells = (int64_t)h_cells[0];
-    nghost = (int64_t)h_cells[1];
-    nv = nf = 0;
+    ncells = (int64_t)report[0];
+    nghost = (int64_t)report[1];
+    nv = nf = nforeign = 0;
     if (ncells > 0xFFFFFFFFLL) {
       set_error("too many surface cells");
       return VCY_ERR_TOO_MANY_VOXELS;
@@ -1758,54 +1822,72 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
       rc = cell_buffers(cap_cells, &cb);
       if (rc == VCY_OK) rc = enqueue_owners(cb, cap_cells);
       if (rc != VCY_OK) return rc;
-      MC_TRY(hipMemcpyAsync(&h_tot, cb.total, sizeof(u64), hipMemcpyDeviceToHost, s));
+      MC_TRY(hipMemcpyAsync((void*)&report[2], cb.total, sizeof(u64), hipMemcpyDeviceToHost, s));
       MC_TRY(hipStreamSynchronize(s));
-      nv = (int64_t)(h_tot >> 32);
-      nf = (int64_t)(h_tot & 0xFFFFFFFFull);
+      nv = (int64_t)(report[2] >> 32);
+      nf = (int64_t)(report[2] & 0xFFFFFFFFull);
       rc = enqueue_emit(cb, cap_cells, with_headroom(nv), with_headroom(nf));
-      if (rc != VCY_OK) return rc;
-    }
-    end_recorded = false;  // (this path ran kernels after the first end mark, if there was one)
-  }
-  if (ncells > 0) {
-    // vertices owned by ghost cells = vertex prefix of list entry `nghost`
-    if (nghost >= ncells) {
-      out->n_foreign_vertices = nv;
-    } else if (nghost > 0) {
-      u64 h_goff = 0;
-      uint32_t h_ginfo = 0;
-      MC_TRY(hipMemcpyAsync(&h_goff, cb.counts + (nghost >> 8), sizeof(u64), hipMemcpyDeviceToHost, s));
-      MC_TRY(hipMemcpyAsync(&h_ginfo, cb.info + nghost, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      if (rc != VCY_OK) {
+        release_host();
+        return rc;
+      }
+      MC_TRY(hipEventRecord(c->ev_mc_end, s));
+      end_recorded = true;
       MC_TRY(hipStreamSynchronize(s));
-      out->n_foreign_vertices = (int64_t)(h_goff >> 32) + (h_ginfo >> 20);
+      read_report();
+    } else {
+      end_recorded = false;
     }
   }
+  if (ncells > 0) out->n_foreign_vertices = nforeign;
   c->mc_hint_cells = ncells;
   c->mc_hint_verts = nv;
   c->mc_hint_faces = nf;
   if (!end_recorded) MC_TRY(hipEventRecord(c->ev_mc_end, s));
   MC_TRY(hipEventSynchronize(c->ev_mc_end));
   MC_TRY(hipEventElapsedTime(&c->last_extract_device_ms, c->ev_mc_begin, c->ev_mc_end));
+  if (timing) t_ph[3] = now_us();
 
-  // the mesh arrays: page-locked host buffers, three DMAs in flight on the context's stream
-  if (nv > 0) {
-    out->vertices = (float*)mesh_host_alloc(sizeof(float) * 3 * (size_t)nv);
-    if (c->mesh_keys) out->edge_keys = (int64_t*)mesh_host_alloc(sizeof(int64_t) * 2 * (size_t)nv);
+  if (direct && ncells > 0 && (nv > 0 || nf > 0)) {
+    // the arrays are already where the caller reads them; an empty side has no array
+    if (nv == 0) {
+      mesh_host_free(out->vertices);
+      mesh_host_free(out->edge_keys);
+      out->vertices = nullptr, out->edge_keys = nullptr;
+    }
+    if (nf == 0) {
+      mesh_host_free(out->faces);
+      out->faces = nullptr;
+    }
+  } else {
+    if (direct) release_host();  // (an empty mesh)
+    // the mesh arrays: page-locked host buffers, three DMAs in flight on the context's stream
+    if (nv > 0) {
+      out->vertices = (float*)mesh_host_alloc(sizeof(float) * 3 * (size_t)nv);
+      if (c->mesh_keys) out->edge_keys = (int64_t*)mesh_host_alloc(sizeof(int64_t) * 2 * (size_t)nv);
+    }
+    if (nf > 0) out->faces = (int32_t*)mesh_host_alloc(sizeof(int32_t) * 3 * (size_t)nf);
+    if ((nv > 0 && (!out->vertices || (c->mesh_keys && !out->edge_keys))) || (nf > 0 && !out->faces)) {
+      set_error("out of host memory for the mesh");
+      return VCY_ERR_INTERNAL;
+    }
+    if (nv > 0) {
+      MC_TRY(hipMemcpyAsync(out->vertices, d_verts, sizeof(float) * 3 * (size_t)nv, hipMemcpyDeviceToHost, s));
+      if (c->mesh_keys)
+        MC_TRY(hipMemcpyAsync(out->edge_keys, d_keys, sizeof(long long) * 2 * (size_t)nv, hipMemcpyDeviceToHost, s));
+    }
+    if (nf > 0) MC_TRY(hipMemcpyAsync(out->faces, d_faces, sizeof(int) * 3 * (size_t)nf, hipMemcpyDeviceToHost, s));
+    if (nv > 0 || nf > 0) MC_TRY(hipStreamSynchronize(s));
   }
-  if (nf > 0) out->faces = (int32_t*)mesh_host_alloc(sizeof(int32_t) * 3 * (size_t)nf);
-  if ((nv > 0 && (!out->vertices || (c->mesh_keys && !out->edge_keys))) || (nf > 0 && !out->faces)) {
-    set_error("out of host memory for the mesh");
-    return VCY_ERR_INTERNAL;
-  }
-  if (nv > 0) {
-    MC_TRY(hipMemcpyAsync(out->vertices, d_verts, sizeof(float) * 3 * (size_t)nv, hipMemcpyDeviceToHost, s));
-    if (c->mesh_keys)
-      MC_TRY(hipMemcpyAsync(out->edge_keys, d_keys, sizeof(long long) * 2 * (size_t)nv, hipMemcpyDeviceToHost, s));
-  }
-  if (nf > 0) MC_TRY(hipMemcpyAsync(out->faces, d_faces, sizeof(int) * 3 * (size_t)nf, hipMemcpyDeviceToHost, s));
-  MC_TRY(hipStreamSynchronize(s));
   out->n_vertices = nv;
   out->n_faces = nf;
+  if (timing) {
+    t_ph[4] = now_us();
+    fprintf(stderr, "[vcy mc timing] setup %.1f us | enqueue %.1f | wait %.1f | events %.1f | mesh to host %.1f | total %.1f "
+                    "(direct %d, %lld cells, %lld v, %lld f, kernels %.1f us)\n",
+            t_ph[0] - t_begin, t_ph[1] - t_ph[0], t_ph[2] - t_ph[1], t_ph[3] - t_ph[2], t_ph[4] - t_ph[3], t_ph[4] - t_begin,
+            direct ? 1 : 0, (long long)ncells, (long long)nv, (long long)nf, c->last_extract_device_ms * 1e3);
+  }
 #undef MC_TRY
   cleanup();
   return VCY_OK;

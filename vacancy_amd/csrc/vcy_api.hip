@@ -37,7 +37,8 @@ std::vector<HostBuf> g_mesh_live, g_mesh_idle;
 constexpr size_t kMeshIdleCap = (size_t)3 << 30;  // idle bytes kept for reuse
 }  // namespace
 
-void* mesh_host_alloc(size_t bytes) {
+void* mesh_host_alloc(size_t bytes, bool* pinned_out) {
+  if (pinned_out) *pinned_out = false;
   if (bytes == 0) bytes = 16;
   std::lock_guard<std::mutex> lock(g_mesh_mutex);
   size_t best = g_mesh_idle.size();
@@ -60,6 +61,7 @@ void* mesh_host_alloc(size_t bytes) {
     }
   }
   g_mesh_live.push_back(b);
+  if (pinned_out) *pinned_out = b.pinned;  // (page-locked: kernels can write it directly, mc_emit)
   return b.p;
 }
 
@@ -412,6 +414,10 @@ int vcy_create(const vcy_carver_option* o, int device_id, int z_begin, int z_end
   const int64_t max_cnt = (int64_t)u.voxel_max_update_num + 1;
   c->cnt_bytes_wire = max_cnt <= 255 ? 1 : (max_cnt <= 65535 ? 2 : 4);
   c->cnt_bytes = 1;  // widened when the views applied (or uploaded counts) need it, ensure_count_width
+  {
+    const char* e = std::getenv("VCY_MC_TIMING");  // development aid: host-side phases of every extraction on stderr
+    if (e && e[0] == '1') c->mc_timing = 1;
+  }
 
   auto fail = [&](int code) {
     vcy_destroy(c);
@@ -498,6 +504,7 @@ void vcy_destroy(vcy_ctx* c) {
   }
   (void)hipFree(c->d_mc_out);
   (void)hipFree(c->d_mc_flags);
+  if (c->h_mc_report) (void)hipHostFree(c->h_mc_report);
   (void)hipFree(c->d_mc_cells);
   (void)hipFree(c->d_fused_scratch);
   for (int q = 0; q < 2; ++q) {
@@ -616,12 +623,28 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
     c->coop_store = value < 0 ? -1 : (value != 0 ? 1 : 0);
     return VCY_OK;
   }
+  if (std::strcmp(name, "ntstore") == 0) {
+    c->nt_store = value < 0 ? -1 : (value != 0 ? 1 : 0);
+    return VCY_OK;
+  }
+  if (std::strcmp(name, "rowkernel") == 0) {
+    c->row_kernel = value < 0 ? -1 : value;
+    return VCY_OK;
+  }
   if (std::strcmp(name, "mcskip") == 0) {
     c->mc_skip = value <= 0 ? 0 : (value >= 2 ? 2 : 1);
     return VCY_OK;
   }
   if (std::strcmp(name, "meshkeys") == 0) {
     c->mesh_keys = value != 0;
+    return VCY_OK;
+  }
+  if (std::strcmp(name, "mcdirect") == 0) {  // bytes (of the guessed mesh) up to which mc_emit writes host memory directly
+    c->mc_direct_bytes = value < 0 ? 0 : (int64_t)value;
+    return VCY_OK;
+  }
+  if (std::strcmp(name, "mctiming") == 0) {
+    c->mc_timing = value != 0 ? 1 : 0;
     return VCY_OK;
   }
   if (std::strcmp(name, "lazycount") == 0) {  // 0: counters at their final width from now on (round 4's layout)
@@ -644,6 +667,9 @@ int vcy_get_param(vcy_ctx* c, const char* name, int* value) {
   else if (std::strcmp(name, "div_level") == 0) *value = c->last_div_level;
   else if (std::strcmp(name, "mcsweep") == 0) *value = c->mc_sweep ? 1 : 0;
   else if (std::strcmp(name, "mcskip") == 0) *value = c->mc_skip;
+  else if (std::strcmp(name, "rowkernel") == 0) *value = c->row_kernel;
+  else if (std::strcmp(name, "ntstore") == 0) *value = c->nt_store;
+  else if (std::strcmp(name, "mcdirect") == 0) *value = (int)std::min<int64_t>(c->mc_direct_bytes, 0x7fffffff);
   else if (std::strcmp(name, "livelist") == 0) *value = c->use_live_list ? 1 : 0;
   else if (std::strcmp(name, "prologue") == 0) *value = c->prologue_mode;
   else if (std::strcmp(name, "coopstore") == 0) *value = c->coop_store;

@@ -81,6 +81,8 @@ struct vcy_ctx {
   float* d_pz = nullptr;
 
   bool mesh_keys = true;              // vcy_extract_iso also returns the edge key of every vertex (vcy_set_param "meshkeys")
+  int nt_store = -1;                  // "ntstore": streaming stores in the cooperative write-back (-1 / 1: whenever it runs -- 0.5 - 1.5 % on single-view launches; 0 never)
+  int row_kernel = 0;                 // "rowkernel": launches of up to this many views take the few-view flavour of the fused kernel (a wave walks the bricks of a row segment); -1 = up to 8, 0 = never (the default: measured slower, carve_fused.hip kRowBricks)
   int mc_skip = 1;                    // marching cubes: bricks whose kept minimum is above the iso level are not read (vcy_set_param "mcskip": 0 never, 1 where it pays -- rows of 1024 voxels and more --, 2 wherever possible)
   bool mc_sweep = false;              // marching cubes: cell search in one sweep with the bit planes in LDS where the row shape allows (vcy_set_param "mcsweep")
   int tile_mode = 0;                  // 0 auto, 1 the 16 x 16 pixel tile, 2 the 2048-pixel tile filled in place (vcy_set_param "tile")
@@ -167,6 +169,9 @@ struct vcy_ctx {
   size_t mc_scratch_bytes = 0;
   void* d_mc_flags = nullptr;         // publication flags of the chained scans (mc_kernels.hip, scan_chained_kernel)
   uint32_t mc_scan_epoch = 0;         // ... and the epoch of the last scan (flags never hold a later one)
+  void* h_mc_report = nullptr;        // 64 page-locked bytes mc_emit reports an extraction's counts in (extract_iso)
+  int64_t mc_direct_bytes = (int64_t)8 << 20;  // "mcdirect": meshes guessed up to this size are written by mc_emit straight into host memory
+  int mc_timing = 0;                  // "mctiming" 1 (or VCY_MC_TIMING=1): host-side phases of every extraction on stderr
   uint32_t mc_scan_tickets[2] = {0, 0};  // chunk tickets drawn so far from the two scan slots' counters (scan_chained_kernel)
   void* d_mc_cells = nullptr;         // per-active-cell arrays of the extraction
   size_t mc_cells_bytes = 0;
@@ -220,7 +225,7 @@ int device_make_sdf_batch(hipStream_t stream, int n, const uint8_t* const* masks
                           bool normalize, bool truncate, float band, char* scratch, size_t scratch_stride,
                           float* const* sdf_dev);
 // host arrays of returned meshes (page-locked pool, vcy_api.hip); released by vcy_mesh_free
-void* mesh_host_alloc(size_t bytes);
+void* mesh_host_alloc(size_t bytes, bool* pinned_out = nullptr);
 void mesh_host_free(void* p);
 // utility kernels (vcy_api.hip)
 int ensure_count_width(vcy_ctx* ctx, int64_t max_count);  // d_cnt wide enough for counts up to max_count (vcy_api.hip)
