@@ -353,6 +353,12 @@ int vcy_reset(vcy_ctx* ctx);
  * bricks through LDS and store whole 128-byte row segments; 0: every wave stores its own 16-byte pieces; -1: the first
  * for single-view launches (over a carved grid in the weighted-average modes: up to 8 views), the second otherwise.
  * Results are identical.
+ * "rowkernel" (default 0): n > 0 or -1 (= 8) sends fused launches of up to n views through the few-view flavour of the
+ * carve kernel -- a WAVE walks the four bricks of a row segment, their state requested up front with LDS-direct loads,
+ * whole 128-byte row segments stored, no barrier -- instead of a workgroup of four waves with the cooperative write-back.
+ * Results identical; measured slower (3.17 against 2.63 ms per weighted-average view at 1024^3: its staging area leaves
+ * 2.7 waves per SIMD), so it is off by default and serves as the second implementation the tests compare with.
+ * "ntstore" (default -1 = 1): the cooperative write-back stores its whole row segments as streaming stores (0: ordinary).
  * "recordbytes" (default 0 = 2 GiB): bytes of footprint records one carve launch may take; a launch whose records would
  * be larger is cut into chunks of whole brick layers (2048^3 x 64 views: 8.6 GB of records, four chunks) -- small values
  * let tests run the chunking on small grids.
@@ -368,7 +374,7 @@ int vcy_reset(vcy_ctx* ctx);
  * "inject_carve_failure" (test hook, default 0): the next `value` applications of views fail with
  * VCY_ERR_INTERNAL before anything is launched -- how the tests exercise the error contract of vcy_carve. */
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
-/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep", "mcskip", "livelist", "livesync", "coopstore", "meshkeys",
+/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep", "mcskip", "mcdirect", "rowkernel", "ntstore", "livelist", "livesync", "coopstore", "meshkeys",
  * "lazycount", "carvetimer"), "count_bytes" / "count_bytes_final" / "carvelog_dropped" (see above), "div_level": the
  * division sequence the last fused launch was instantiated with (2: 4 instructions, 1: 6, 0: full IEEE expansion), or
  * "brick_min_valid": 1 while the brick minima describe the state (every write since the fill went through the fused kernel). */

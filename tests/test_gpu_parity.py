@@ -1021,6 +1021,9 @@ def test_single_view_launches_with_brick_minima(kw, livelist, recordbytes, coops
     # inside the grid, the other three leave before the barrier)
     dev.set_param("coopstore", coopstore)
     dev.set_param("rowkernel", rowkernel)
+    # single-view launches take the kernel instance compiled for ONE view (footprint record in registers, flags from the
+    # kept brick minimum); the cases that also cut their launches into chunks run the general instance ("oneview" 0)
+    dev.set_param("oneview", 0 if recordbytes else 1)
     orc = O.OracleGrid(opt)
     base = O.make_sdf(masks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
     for i in range(nv):

@@ -277,7 +277,6 @@ __device__ __forceinline__ float load_u32_index(gfloat_ptr base, unsigned idx) {
   return *(gfloat_ptr)((gchar_ptr)base + (idx << 2));
 }
 typedef const float __attribute__((address_space(4))) * cfloat_ptr;  // read-only: scalar loads
-
 // Generic sample for a voxel the staged tile does not cover (rare): global-memory taps and the
 // full ROI / outside-image semantics of carve_common.h.  Kept out of line so that the hot loop
 // stays small.
@@ -1037,7 +1036,7 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : ((!GEN && !CHECKMAX && TQ == kTi
                                        : VCY_WAVES_CHECKED)))) void carve_fused_kernel(GridParams g,
                                                           const FusedView* __restrict__ views,
                                                           const float* __restrict__ c0_all,
-                                                          int nviews, ModeParams mode, int nbx,
+                                                          int nviews_arg, ModeParams mode, int nbx,
                                                           int nby, BlockDecode bd, int cull_enabled, int state_flags,
                                                           const FootprintRecord* __restrict__ records,
                                                           int64_t nbricks, float* __restrict__ brick_min,
@@ -1052,9 +1051,20 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : ((!GEN && !CHECKMAX && TQ == kTi
   // state_flags: bit 0 = the slab is fresh (known sdf = lowest(), update_num = 0, never written);
   //              bit 1 = update_num == 0 implies sdf == lowest() (no vcy_upload since the fill)
   //              bit 3 = cooperative write-back through LDS (below)
+  // NB == 0: a launch of ONE view with the NB = 1 structure (a brick per wave, cooperative write-back).  The reference's
+  // own loop (examples.cc:117-149) makes every view such a launch; with the view count a compile-time 1 the footprint
+  // record is a scalar load unpacked into registers (no TileInfo in LDS, no read-backs), and the view loop, its
+  // next-view search, the second tile buffer's bookkeeping and the re-bounding after the view fold away.
+  constexpr bool kOne = NB == 0;
+#ifdef VCY_ONE_LDS  // development build: the one-view instance keeps its TileInfo in LDS like the general one
+  constexpr bool kOneRegs = false;
+#else
+  constexpr bool kOneRegs = kOne;
+#endif
+  const int nviews = kOne ? 1 : nviews_arg;
   const int fresh = state_flags & 1;
   const bool implied = (state_flags & 2) != 0;
-  const bool coop = NB == 1 && (kWgWaves == 4 || kWgWaves == 8) && (state_flags & 8) != 0;
+  const bool coop = NB <= 1 && (kWgWaves == 4 || kWgWaves == 8) && (state_flags & 8) != 0;
   const bool nt_store = (state_flags & 16) != 0;  // cooperative write-back with streaming stores
   constexpr bool kRows = NB > 1;  // the few-view flavour: this WAVE walks NB bricks of a row (kRowBricks)
   static_assert(!kRows || (TQ == kTileRaw && !CHECKMAX), "the few-view flavour: raw tiles, no update limit in reach");
@@ -1110,6 +1120,11 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : ((!GEN && !CHECKMAX && TQ == kTi
       if (lane == 0) coop_mask[wave] = 0ull, coop_mask[kWgWaves + wave] = 0ull;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
+  };
+  TileInfo ti_one;  // NB == 0: the one view's tile, in registers
+  auto tile_of = [&](int p) -> const TileInfo& {
+    if constexpr (kOneRegs) return ti_one;
+    else return tinfo[p];
   };
   int cur = 0;  // raw tiles: which of the wave's buffers holds the view being carved
   auto raw_buf = [&](int b) -> float* { return (float*)tile + 256 * b; };
@@ -1215,6 +1230,17 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : ((!GEN && !CHECKMAX && TQ == kTi
       store_tile_info((lds_u32*)tinfo, lane, ti);
       ub_lane = ti.ub;
     }
+  } else if constexpr (kOneRegs) {
+    // one view: the record of (view 0, this brick) is wave-uniform.  Fetched with a VECTOR load all lanes share and made
+    // uniform afterwards: the records are streamed once, and as scalar loads they evicted the view record and the x
+    // tables -- which every wave re-reads -- from the scalar cache (2.72 -> 3.38 ms per weighted-average view).
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef const u32x2 __attribute__((address_space(1))) * grec_ptr;
+    const u32x2 raw = ((grec_ptr)records)[brick_lin];
+    FootprintRecord rec;
+    rec.w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.x), rec.w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.y);
+    ti_one = unpack_footprint(rec);
+    ub_lane = ti_one.ub;
   } else if (kRaw && records != nullptr) {
     // raw tiles: the footprints come from the pre-pass (footprint_records_kernel), 8 bytes per view
     ub_lane = INFINITY;
@@ -1314,7 +1340,7 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : ((!GEN && !CHECKMAX && TQ == kTi
       }
       const unsigned long long lp = __ballot(!drop) & view_mask;
       vi_pre = lp ? (__ffsll((long long)lp) - 1) : nviews;
-      if (vi_pre < nviews) raw_prefetch(views[vi_pre].v, tinfo[vi_pre], lane, raw_buf(0));
+      if (vi_pre < nviews) raw_prefetch(views[vi_pre].v, tile_of(vi_pre), lane, raw_buf(0));
     }
   };
   // rows are whole bricks when nx % 8 == 0: the run is one 32-byte (sdf) and one 8/16-byte (update_num) vector
@@ -1466,7 +1492,7 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : ((!GEN && !CHECKMAX && TQ == kTi
   unsigned long long changed_lanes = 0ull;
   if (!kRows) live = live_views();
   int vi = live ? (__ffsll((long long)live) - 1) : vi_end;
-  if (kRaw && vi < vi_end && vi != vi_pre) raw_prefetch(views[kRows ? (vi & 7) : vi].v, tinfo[vi], lane, raw_buf(0));
+  if (kRaw && vi < vi_end && vi != vi_pre) raw_prefetch(views[kRows ? (vi & 7) : vi].v, tile_of(vi), lane, raw_buf(0));
   // NB > 1: the brick whose turn it is takes its state from the staging area (the LDS-direct requests above have
   // landed once the wave has waited for its first tile) and leaves it there again when the next brick begins
   typedef CountT CountVecR __attribute__((ext_vector_type(WX)));
@@ -1543,7 +1569,7 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : ((!GEN && !CHECKMAX && TQ == kTi
         if (((live >> vi) & 1ull) == 0ull) {
           vi = next_view(live, vi);
           // (the dropped pair's pixels may still be arriving in that buffer: loads complete in order)
-          if (vi < vi_end) raw_prefetch(views[vi & 7].v, tinfo[vi], lane, raw_buf(cur));
+          if (vi < vi_end) raw_prefetch(views[vi & 7].v, tile_of(vi), lane, raw_buf(cur));
           continue;
         }
       }
@@ -1558,15 +1584,15 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : ((!GEN && !CHECKMAX && TQ == kTi
     if (kRaw) {
       raw_tile_wait();  // this view's pixels have landed in raw_buf(cur)
     } else {
-      tile_fill(v, tinfo[vi], lane, (float*)tile);
+      tile_fill(v, tile_of(vi), lane, (float*)tile);
     }
     wave_lds_fence();
     // the next live view's tile is fetched while this one is computed
     int vnext = next_view(live, vi);
-    if (kRaw && vnext < vi_end) raw_prefetch(views[kRows ? (vnext & 7) : vnext].v, tinfo[vnext], lane, raw_buf(cur ^ 1));
+    if (kRaw && vnext < vi_end) raw_prefetch(views[kRows ? (vnext & 7) : vnext].v, tile_of(vnext), lane, raw_buf(cur ^ 1));
     ++n_processed;
-    const float pitchf = tinfo[vi].pitchf;
-    const int base = tinfo[vi].base;
+    const float pitchf = tile_of(vi).pitchf;
+    const int base = tile_of(vi).base;
     const int big_pitch = kRaw ? 16 : (int)pitchf;  // pixels per row of the big tile
     // the four taps of the sample whose upper left pixel is tile element idx
     const lds_float* rawcur = (const lds_float*)raw_buf(cur);
@@ -1581,8 +1607,8 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : ((!GEN && !CHECKMAX && TQ == kTi
       }
     };
 
-    const float lo_x = tinfo[vi].lo_x, hi_x = tinfo[vi].hi_x;
-    const float lo_y = tinfo[vi].lo_y, hi_y = tinfo[vi].hi_y;
+    const float lo_x = tile_of(vi).lo_x, hi_x = tile_of(vi).hi_x;
+    const float lo_y = tile_of(vi).lo_y, hi_y = tile_of(vi).hi_y;
     const bool is_ortho = GEN && mode.ortho != 0, is_nn = GEN && mode.interp == VCY_INTERP_NN;
     // c1 + c2 of this lane's (y, z): the inner sum of pc = t + (c0 + (c1 + c2)) (voxel_carver.cc:453)
     const float h12x = v.r[0][1] * py + v.r[0][2] * pz, h12y = v.r[1][1] * py + v.r[1][2] * pz;
@@ -1775,7 +1801,7 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : ((!GEN && !CHECKMAX && TQ == kTi
       return (kFastMax && !FIRST) ? took != 0ull : true;
     };
     bool brick_moved;
-    const int sure_bits = __builtin_amdgcn_readfirstlane(tinfo[vi].sure);
+    const int sure_bits = __builtin_amdgcn_readfirstlane(tile_of(vi).sure);
     const bool sure = (sure_bits & 1) != 0, never_truncated = (sure_bits & 2) != 0;
     // (Branch weights: the checked loops below are the rare ones in the kernels that have a select-free loop;
     // the register allocator then spills there, if anywhere, and not in the loops that do the work.)
@@ -1825,17 +1851,17 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : ((!GEN && !CHECKMAX && TQ == kTi
     VCY_SETPRIO(3);
     if (brick_moved) VCY_PT_COUNT(11);
     none_touched = false;  // (a checked view may have touched only some voxels)
-    refresh_all_touched();
+    if (!kOne) refresh_all_touched();  // (only the views that follow ask)
 
     // state moved: some of the remaining views may have become droppable (min(sdf) only grows)
     // (an unchanged brick leaves every bound comparison as it was)
-    if (want_bound && UPDATE == VCY_UPDATE_MAX && brick_moved) {
+    if (!kOne && want_bound && UPDATE == VCY_UPDATE_MAX && brick_moved) {
       live = live_views();
       const int v2 = next_view(live, vi);
       if (v2 != vnext) {
         vnext = v2;
         // (the dropped view's pixels may still be arriving in that buffer: loads complete in order)
-        if (kRaw && vnext < vi_end) raw_prefetch(views[kRows ? (vnext & 7) : vnext].v, tinfo[vnext], lane, raw_buf(cur ^ 1));
+        if (kRaw && vnext < vi_end) raw_prefetch(views[kRows ? (vnext & 7) : vnext].v, tile_of(vnext), lane, raw_buf(cur ^ 1));
       }
     }
     vi = vnext;
@@ -1945,8 +1971,9 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : ((!GEN && !CHECKMAX && TQ == kTi
         const f4 v = *(lds_float4*)(float4*)(coop_s + r * kCoopSdfPitch + ch * 4);
         const int64_t rowg = ((int64_t)(zl0 + (r >> 3)) * g.ny + (by * BY + (r & 7))) * g.nx;
 #ifndef VCY_DEV_SKIP_SDF_STORE  // (development builds: which of the two arrays the written bytes belong to)
-        // (whole 128-byte row segments: as streaming stores when the launch asks for it -- state_flags bit 4, the first
-        // view on a fresh grid, where nothing written is read again by this launch; launch_carve_fused)
+        // (whole 128-byte row segments: as streaming stores when the launch asks for it -- state_flags bit 4.  A scalar
+        // base with 32-bit offsets instead of these 64-bit row addresses was measured in round 6: 23 vector instructions
+        // fewer per wave, 18 scalar ones more, +1 % in time -- profiles/r06/one_view.txt)
         if (nt_store) __builtin_nontemporal_store(v, (f4*)(g.sdf + rowg + xb + ch * 4));
         else *(float4*)(g.sdf + rowg + xb + ch * 4) = make_float4(v.x, v.y, v.z, v.w);
 #else
@@ -2023,6 +2050,29 @@ void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const Gri
                     const FootprintRecord* recs, int64_t nbricks, float* bmin, const int* wgl, unsigned long long* pcnt,
                     int row_units) {
   const bool gen = m.ortho != 0 || m.interp == VCY_INTERP_NN;
+  if (row_units < 0) {
+    // a launch of ONE view (NB == 0): the NB = 1 launch shape, the view count a compile-time constant
+#define VCY_ONE(GEN_, DIV_)                                                                                          \
+  hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, false, kTileRaw, GEN_, DIV_, 0>), grid,         \
+                     dim3(64 * kWgWaves),                                                                            \
+                     (size_t)kWgWaves * tile_f4_per_wave<kTileRaw>() * sizeof(float4) + (size_t)kWgWaves * sizeof(TileInfo) + \
+                         ((fresh & 8) ? coop_lds_bytes<CountT>() : 0), s,                                            \
+                     g, dv, c2, 1, m, nbx, nby, make_block_decode(grid.x, nbx, nby), cull, fresh, recs, nbricks, bmin, wgl, pcnt)
+#ifdef VCY_DEV_BENCH_KERNELS_ONLY
+    if (gen || m.div_level != 2 || !SAMEF || sizeof(CountT) != 1 || UPDATE == VCY_UPDATE_WEIGHTED_AVERAGE) {
+      fprintf(stderr, "VCY_DEV_BENCH_KERNELS_ONLY: kernel variant not built\n");
+      abort();
+    }
+    if constexpr (SAMEF && sizeof(CountT) == 1 && UPDATE != VCY_UPDATE_WEIGHTED_AVERAGE) VCY_ONE(false, 2);
+#else
+    if (gen) VCY_ONE(true, 0);
+    else if (m.div_level == 2) VCY_ONE(false, 2);
+    else if (m.div_level == 1) VCY_ONE(false, 1);
+    else VCY_ONE(false, 0);
+#endif
+#undef VCY_ONE
+    return;
+  }
   if (row_units > 0) {
     // the few-view flavour: `grid` workgroups of kRowWaves waves, a segment of kRowBricks bricks per wave; `nbx` =
     // segments per brick row, `row_units` = segments of the launch (what the block decode deals to the XCDs)
@@ -2476,6 +2526,8 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   const int row_views = c->row_kernel < 0 ? kRowMaxViews : std::min(c->row_kernel, kRowMaxViews);
   const bool rows = !big && !checkmax && (c->nx & (WX - 1)) == 0 && n_views <= row_views && c->prologue_mode != 1;
   const int nseg = (nbw + kRowBricks - 1) / kRowBricks;  // segments per brick row
+  // a launch of ONE view through the kernel instance that knows it ("oneview" 0: the general instance)
+  const bool one_view = c->one_view && n_views == 1 && !rows && !big && !checkmax && c->prologue_mode != 1;
   const bool coop_ok = (kWgWaves == 4 || kWgWaves == 8) && (c->nx & (WX - 1)) == 0 && !big && !rows;
   const int coop_views = c->fresh ? 1 : (u.voxel_update == VCY_UPDATE_MAX ? 1 : kLiveListMaxViews);
   const bool coop = coop_ok && (c->coop_store > 0 || (c->coop_store < 0 && n_views <= coop_views));
@@ -2616,11 +2668,11 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     } else if (c->cnt_bytes == 1)
       launch_fused_1<uint8_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, launch_grid, c->stream, gc, d_views,
                               d_c2, n_views, m, units_x, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin, wgl, pcnt,
-                              rows ? (int)grid.x : 0);
+                              rows ? (int)grid.x : (one_view ? -1 : 0));
     else
       launch_fused_1<uint16_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, launch_grid, c->stream, gc, d_views,
                                d_c2, n_views, m, units_x, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin, wgl, pcnt,
-                               rows ? (int)grid.x : 0);
+                               rows ? (int)grid.x : (one_view ? -1 : 0));
     VCY_HIP_CHECK(hipGetLastError());
     if (stamp >= 0) VCY_HIP_CHECK(hipEventRecord(c->carve_log[stamp].ev[2], c->stream));
   }
