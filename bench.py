@@ -189,6 +189,47 @@ def cpu_baseline(args, views, sdfs, budget_s):
         del g1
     finally:
         lib.orc_set_num_threads(usable)
+    # The same loop at the FULL grid size when the box can hold the reference's 40-byte AoS grid (1024^3: 43 GB) well
+    # inside both its free memory and its cgroup limit -- one or two views, not extrapolated.  (Never attempted without
+    # that headroom: a box driven out of memory is lost.)
+    full = None
+    try:
+        need = 40.0 * float(args.grid) ** 3
+        avail = 0.0
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = float(ln.split()[1]) * 1024.0
+        limit = float("inf")
+        for pth in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+            try:
+                t = open(pth).read().strip()
+                if t != "max":
+                    limit = min(limit, float(t))
+            except OSError:
+                pass
+        used = 0.0
+        try:
+            used = float(open("/sys/fs/cgroup/memory.current").read().strip())
+        except (OSError, ValueError):
+            pass
+        if n_cpu != args.grid and os.environ.get("VCY_CPU_FULL_SIZE", "1") != "0" and avail > 2.0 * need and limit - used > 2.0 * need:
+            t_alloc = time.perf_counter()
+            gf = O.OracleGrid(synth.sphere_option(args.grid, uo))
+            t_alloc = time.perf_counter() - t_alloc
+            tf, nf_ = 0.0, 0
+            for i in range(min(2, len(views))):
+                tf += gf.carve(views[i], sdfs[i]) / 1e3
+                nf_ += 1
+                if tf > budget_s:
+                    break
+            full = {"value": round(gf.n * nf_ / tf / 1e6, 2), "views": nf_, "grid": args.grid, "seconds": round(tf, 2),
+                    "grid_bytes": need, "init_seconds": round(t_alloc, 2)}
+            del gf
+        else:
+            full = {"skipped": "needs %.0f GB twice over: MemAvailable %.0f GB, cgroup headroom %s GB"
+                               % (need / 1e9, avail / 1e9, "unlimited" if limit == float("inf") else "%.0f" % ((limit - used) / 1e9))}
+    except Exception as e:  # the sample above stands on its own
+        full = {"error": "%s: %s" % (type(e).__name__, e)}
     mesh = g.marching_cubes(0.0, True)
     mc_s = mesh["ms"] / 1e3
     cells = (g.dims[0] - 1) * (g.dims[1] - 1) * (g.dims[2] - 1)
@@ -201,6 +242,7 @@ def cpu_baseline(args, views, sdfs, budget_s):
         "kind": "port",
         "extrapolated": extrapolated,
         "single_thread_value": single,
+        "full_size": full,
         "sample": "%soracle (OpenMP over z, %d threads = usable host cores of %d visible) on a %d^3 grid over the "
                   "same scene (the rate per voxel*view is what is reported; the %d^3 AoS grid of the reference "
                   "needs %.1f GB), %d of %d views at %dx%d; times the Carve main loop only (reference "

@@ -358,6 +358,11 @@ int vcy_reset(vcy_ctx* ctx);
  * whole 128-byte row segments stored, no barrier -- instead of a workgroup of four waves with the cooperative write-back.
  * Results identical; measured slower (3.17 against 2.63 ms per weighted-average view at 1024^3: its staging area leaves
  * 2.7 waves per SIMD), so it is off by default and serves as the second implementation the tests compare with.
+ * "oneview" (default 1): a fused launch of exactly ONE view -- what every call of the reference's per-view API becomes
+ * when an extraction separates the views, examples.cc:117-149 -- takes a kernel instance compiled for one view (the
+ * footprint record unpacked into registers, no view loop, no second tile buffer): 15 % fewer vector and 27 % fewer
+ * scalar instructions per wave, 2.72 -> 2.43-2.53 ms per weighted-average view at 1024^3, the first view on a fresh grid
+ * 1.73-1.92 -> 1.37-1.58, kMax 0.60 -> 0.53; 0: the general instance.  Results identical.
  * "ntstore" (default -1 = 1): the cooperative write-back stores its whole row segments as streaming stores (0: ordinary).
  * "recordbytes" (default 0 = 2 GiB): bytes of footprint records one carve launch may take; a launch whose records would
  * be larger is cut into chunks of whole brick layers (2048^3 x 64 views: 8.6 GB of records, four chunks) -- small values
@@ -374,7 +379,7 @@ int vcy_reset(vcy_ctx* ctx);
  * "inject_carve_failure" (test hook, default 0): the next `value` applications of views fail with
  * VCY_ERR_INTERNAL before anything is launched -- how the tests exercise the error contract of vcy_carve. */
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
-/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep", "mcskip", "mcdirect", "rowkernel", "ntstore", "livelist", "livesync", "coopstore", "meshkeys",
+/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep", "mcskip", "mcdirect", "rowkernel", "oneview", "ntstore", "livelist", "livesync", "coopstore", "meshkeys",
  * "lazycount", "carvetimer"), "count_bytes" / "count_bytes_final" / "carvelog_dropped" (see above), "div_level": the
  * division sequence the last fused launch was instantiated with (2: 4 instructions, 1: 6, 0: full IEEE expansion), or
  * "brick_min_valid": 1 while the brick minima describe the state (every write since the fill went through the fused kernel). */

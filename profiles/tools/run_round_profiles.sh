@@ -72,6 +72,13 @@ timeout 1200 python profiles/tools/streamed_emulation.py > "$O/streamed_emulatio
 timeout 1200 python profiles/tools/slab_emulation.py > "$O/slab_emulation.txt" 2>&1; echo "slab emulation rc=$?" >> "$O/status.txt"
 VCY_XV_TIMING=1 timeout 300 python profiles/tools/xv_timing.py > "$O/extract_voxel_phases.txt" 2>&1
 for m in default tsdf; do timeout 300 python profiles/tools/first_view.py 1024 $m; done > "$O/first_view.txt" 2>&1
+# round 6: single-view launches through the instance compiled for one view against the general one, and the few-view
+# flavour (a wave walks the bricks of a row segment) against both; what a marching-cubes CALL costs (wall) per size
+PARAM=oneview VALUES=0,1 timeout 300 python profiles/tools/row_kernel.py 1024 tsdf default > "$O/one_view_final.txt" 2>&1
+PARAM=rowkernel VALUES=0,-1 timeout 300 python profiles/tools/row_kernel.py 1024 tsdf default > "$O/row_kernel_final.txt" 2>&1
+for m in tsdf default; do PARAM=oneview bash profiles/tools/pmc_rows.sh "gpurun_out/$RND/pmc_one_view" $m 1; PARAM=oneview bash profiles/tools/pmc_rows.sh "gpurun_out/$RND/pmc_one_view" $m 0; done 2>&1 | grep knob > "$O/one_view_pmc_final.txt"
+VCY_MC_TIMING_ONCE=1 timeout 300 python profiles/tools/mc_wall.py > "$O/mc_wall.txt" 2>&1
+N=512 NV=16 MODE=tsdf bash profiles/tools/mc_kernel_times.sh prod > "$O/mc_kernels_512_tsdf.txt" 2>&1
 timeout 300 python profiles/tools/write_ceiling.py > "$O/write_ceiling.txt" 2>&1
 # the summaries profiles/rNN/ keeps of the traced runs
 for w in default cull0 tsdf; do cp "$O/$w/trace_kernel_stats.csv" "$O/kernel_stats_1024x32_$w.csv"; done
