@@ -169,6 +169,44 @@ def test_orthographic_views_in_the_select_free_loops(kw):
         assert np.array_equal(ds.view(np.uint32), os_.view(np.uint32)), (kw, cull, tile)
 
 
+@pytest.mark.parametrize("kw,ortho,lazy", [(dict(sdf_interp=0), False, 1), (dict(), True, 1),
+                                            (dict(voxel_update=1, use_truncation=True, sdf_interp=0), True, 1),
+                                            (dict(voxel_update=1, voxel_update_weight=0.5, use_truncation=True), False, 1),
+                                            (dict(voxel_update=1, use_truncation=True, truncation_band=0.1), False, 0),
+                                            (dict(update_outside=1), False, 0)])
+@pytest.mark.parametrize("oneview", [1, 0])
+def test_one_view_instance_in_every_flavour(kw, ortho, lazy, oneview):
+    """The kernel instance compiled for ONE view ("oneview" 1: footprint record in registers, no view loop) and the general
+    instance, one launch per view ("defer" 0), in the flavours the benchmark modes do not reach: nearest-neighbour taps
+    and orthographic cameras (the GEN instances), general weights, two-byte counters from the start ("lazycount" 0),
+    `update_outside = kMax`; state against the oracle after every view, mesh at the end.  Images of 160 x 120: raw tiles,
+    footprint records, brick minima, live list and cooperative write-back all take part."""
+    n, nv, w, h = 72, 9, 160, 120
+    uo = UpdateOption(**kw)
+    opt = synth.sphere_option(n, uo)
+    views, masks = synth.sphere_views(n, nv, w, h)
+    if ortho:
+        for v in views:
+            v.is_ortho = 1
+            v.w2c[3] += np.float32(w / 2)
+            v.w2c[7] += np.float32(h / 2)
+    base = O.make_sdf(masks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
+    rng = np.random.RandomState(3)
+    noisy = (base + rng.uniform(-0.04, 0.04, base.shape)).astype(np.float32)
+    dev = vc.VoxelCarver(opt)
+    assert dev.Init(), vc.last_error()
+    dev.set_param("lazycount", lazy)
+    dev.set_param("defer", 0)
+    dev.set_param("oneview", oneview)
+    orc = O.OracleGrid(opt)
+    for i in range(nv):
+        img = noisy if i % 3 == 2 else base
+        assert dev.Carve(views[i], img), vc.last_error()
+        orc.carve(views[i], img)
+        assert_state_equal(dev, orc, "%s ortho %s oneview %d view %d" % (kw, ortho, oneview, i))
+    assert_mesh_equal(dev.ExtractIsoSurface(0.0, True), orc.marching_cubes(0.0, True), "%s oneview %d" % (kw, oneview))
+
+
 def test_camera_inside_grid_and_behind():
     """voxels behind the camera (pc.z < 0), at pc.z == 0 and right at the camera."""
     n = 32
