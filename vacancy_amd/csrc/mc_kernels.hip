@@ -1713,7 +1713,7 @@ int extract_iso(vcy_ctx* c, double iso, int linear_interp, vcy_mesh* out) {
   };
   // The counts come back through 64 bytes of page-locked memory that mc_emit writes itself (see the kernel).
   if (!c->h_mc_report) {
-    MC_TRY(hipHostMalloc((void**)&c->h_mc_report, 64, hipHostMallocDefault));
+    MC_TRY(hipHostMalloc((void**)&c->h_mc_report, 64, hipHostMallocPortable | hipHostMallocMapped));
     std::memset((void*)c->h_mc_report, 0, 64);
   }
   volatile u64* report = (volatile u64*)c->h_mc_report;

@@ -53,7 +53,9 @@ void* mesh_host_alloc(size_t bytes, bool* pinned_out) {
   } else {
     b.bytes = bytes + bytes / 8 + 4096;  // headroom: the next view's mesh is usually a little different
     b.p = nullptr;
-    b.pinned = hipHostMalloc(&b.p, b.bytes, hipHostMallocDefault) == hipSuccess && b.p != nullptr;
+    // (portable + mapped: the pool is shared by the contexts of every device of the process, and mc_emit writes small
+    // meshes into these arrays from whichever device extracts -- "mcdirect")
+    b.pinned = hipHostMalloc(&b.p, b.bytes, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess && b.p != nullptr;
     if (!b.pinned) {
       (void)hipGetLastError();
       b.p = std::malloc(b.bytes);
