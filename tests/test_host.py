@@ -326,6 +326,47 @@ def test_voxel_cubes_without_a_gpu_equals_the_oracle():
         assert np.array_equal(np.unique(v[:, 2]), np.unique(np.array([lo_t[2] + pos[t][2], hi_t[2] + pos[t][2]], np.float32)))
 
 
+def test_voxel_cubes_speculative_chunks_are_checked_and_redone():
+    """vcy_voxel_cubes runs the serial cube chain in chunks on host threads, each from a GUESSED incoming state, and checks
+    afterwards that every guess equals what the predecessor really left.  (1) a resolution whose half is not a dyadic
+    number, so that the cube really drifts from voxel to voxel; (2) in a subprocess with the test hook that makes every
+    guess wrong by one ulp: the check must catch it, the chunks are done again, and the mesh still equals the oracle's."""
+    import subprocess
+    import sys
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import bunny_data as B, oracle_lib as O
+from vacancy_amd import carver
+opt = B.bunny_option(2.3)
+g = O.OracleGrid(opt)
+rng = np.random.RandomState(3)
+sdf = rng.uniform(-1, 1, g.n).astype(np.float32)
+g.upload(sdf, np.ones(g.n, np.int32))
+ids = np.nonzero(sdf <= 0)[0].astype(np.int64)
+assert len(ids) > 200000
+want = g.extract_voxel(False)
+got = carver.voxel_cubes(opt, ids)
+assert np.array_equal(got["faces"], want["faces"])
+assert np.array_equal(got["vertices"].view(np.uint32), want["vertices"].view(np.uint32))
+h = np.float32(2.3) / np.float32(2)
+v = got["vertices"].reshape(-1, 24, 3)
+width = v[:, :, 0].max(1) - v[:, :, 0].min(1)
+print("DRIFT", int((width != width[0]).sum()))
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    for hook in (False, True):
+        env = dict(os.environ, VCY_XV_TIMING="1")
+        if hook:
+            env["VCY_TEST_XV_BAD_GUESS"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        redone = [int(x) for x in re.findall(r"check \+ (\d+) chunks done again", r.stderr)]
+        assert redone, r.stderr[-500:]
+        assert (max(redone) > 0) == hook, (hook, redone)
+        assert int(re.search(r"DRIFT (\d+)", r.stdout).group(1)) > 0   # the cube's width is not constant: it does drift
+
+
 def _png_decode_filter0(path):
     """An independent decoder for what WritePng8 emits (8-bit, non-interlaced, every row filter 0): chunk walk with CRC
     check, zlib inflate.  Returns (width, height, channels, pixels)."""
