@@ -5,7 +5,7 @@
 # must be 0: the x-table records belong in scalar loads), s_waitcnt and SGPR spills through lanes.  Caught the -15 %
 # regression of round 3 (a uniform value first computed in a divergent branch).
 mkdir -p /tmp/vcy_asm; cd "$(dirname "$0")/../../vacancy_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize -DVCY_DEV_BENCH_KERNELS_ONLY "$@" -I../../include -I. -S --cuda-device-only -o /tmp/vcy_asm/fused_dev.s ${SRC:-carve_fused.hip} 2>&1 | grep -v hip-link
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize -DVCY_DEV_BENCH_KERNELS_ONLY "$@" -I../../include -I. -S --cuda-device-only -o /tmp/vcy_asm/fused_dev.s ${SRC:-carve_fused_u8.hip} 2>&1 | grep -v hip-link
 cd /tmp/vcy_asm
 grep -E "^\s+\.(vgpr_count|sgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size|name):" fused_dev.s | paste - - - - - - | grep -E "carve_fused" | sed 's/ \+/ /g;s/_ZN3vcy12_GLOBAL__N_1//;s/EEvNS.*//;s/.private_segment_fixed_size/priv/;s/.name: 18carve_fused_kernel//'
 python3 - <<'P'

@@ -36,7 +36,7 @@ def main():
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
                         "-I" + os.path.join(ROOT, "include"), "-I" + src, "-fno-slp-vectorize",
-                        "-DVCY_DEV_BENCH_KERNELS_ONLY", "--cuda-device-only", "-S", os.path.join(src, "carve_fused.hip"),
+                        "-DVCY_DEV_BENCH_KERNELS_ONLY", "--cuda-device-only", "-S", os.path.join(src, "carve_fused_u8.hip"),
                         "-o", out], check=True, stderr=subprocess.DEVNULL)
         lines = open(out).read().splitlines()
     tag = "carve_fused_kernelItLi%sELb%sELb1ELb0ELi16ELb0ELi2EEEv" % (mode, trunc)

@@ -207,7 +207,7 @@ def test_run_loops_of_the_fused_kernel_fetch_their_tables_through_scalar_loads()
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                             "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
                             "-fno-slp-vectorize", "-DVCY_DEV_BENCH_KERNELS_ONLY", "-I", os.path.join(root, "include"),
-                            "-I", src, "-S", "--cuda-device-only", "-o", out, os.path.join(src, "carve_fused.hip")],
+                            "-I", src, "-S", "--cuda-device-only", "-o", out, os.path.join(src, "carve_fused_u8.hip")],
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         txt = open(out).read()

@@ -36,6 +36,20 @@
 
 namespace vcy {
 
+// The instances of carve_fused_kernel are compiled in TWO translation units of their own -- carve_fused_u8.hip (update_num
+// in one byte) and carve_fused_u16.hip (two bytes), each `#define VCY_FUSED_PART` + `#include "carve_fused.hip"`: the
+// kernel, its helpers and the launch_fused_* dispatch below up to launch_fused_1, then one exported function -- so that
+// the 960 instantiations build in parallel halves (4.4 min in one unit).  This file compiled by itself is the host side
+// and the small kernels; it instantiates no carve kernel.  (Pointers to types of the anonymous namespace cross as void*.)
+void launch_fused_counts8(bool big, int update, bool trunc, bool samef, bool checkmax, unsigned grid_x, hipStream_t s,
+                          const GridParams& g, const void* views, const float* c2, int nv, const ModeParams& m, int nbx, int nby,
+                          int cull, int state_flags, const void* records, int64_t nbricks, float* bmin, const int* wgl,
+                          unsigned long long* pcnt, int row_units);
+void launch_fused_counts16(bool big, int update, bool trunc, bool samef, bool checkmax, unsigned grid_x, hipStream_t s,
+                           const GridParams& g, const void* views, const float* c2, int nv, const ModeParams& m, int nbx, int nby,
+                           int cull, int state_flags, const void* records, int64_t nbricks, float* bmin, const int* wgl,
+                           unsigned long long* pcnt, int row_units);
+
 namespace {
 
 // Wave priority: everything but the runs over the voxels is short and ends in a memory request (view records,
@@ -2156,6 +2170,41 @@ void launch_fused_1(bool big, int update, bool trunc, bool samef, bool checkmax,
     launch_fused_2<CountT, VCY_UPDATE_WEIGHTED_AVERAGE>(big, trunc, samef, checkmax, grid, s, g, dv, c2, nv, m, nbx, nby, cull, fresh, recs, nbricks, bmin, wgl, pcnt, row_units);
 }
 
+#ifdef VCY_FUSED_PART
+}  // namespace
+
+// (carve_fused_u8.hip / carve_fused_u16.hip) this unit's half of the kernel instances behind its one exported function
+void VCY_FUSED_PART_FN(bool big, int update, bool trunc, bool samef, bool checkmax, unsigned grid_x, hipStream_t s,
+                       const GridParams& g, const void* views, const float* c2, int nv, const ModeParams& m, int nbx, int nby,
+                       int cull, int state_flags, const void* records, int64_t nbricks, float* bmin, const int* wgl,
+                       unsigned long long* pcnt, int row_units) {
+  launch_fused_1<VCY_FUSED_PART_TYPE>(big, update, trunc, samef, checkmax, dim3(grid_x), s, g, (const FusedView*)views, c2, nv, m,
+                                      nbx, nby, cull, state_flags, (const FootprintRecord*)records, nbricks, bmin, wgl, pcnt,
+                                      row_units);
+}
+
+}  // namespace vcy
+
+#if defined(VCY_PHASE_TIMING) && VCY_FUSED_PART == 8
+// development build only (the benchmark's kernels are the one-byte ones): reads (and optionally clears) the phase counters
+// of the fused kernel -- in THIS unit, whose copy of g_phase_ticks its kernels write
+extern "C" int vcy_debug_phase_ticks(unsigned long long* out12, int reset) {
+  unsigned long long h[256][16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(vcy::g_phase_ticks), sizeof(h)) != hipSuccess) return -1;
+  for (int q = 0; q < 16; ++q) {
+    out12[q] = 0;
+    for (int b = 0; b < 256; ++b) out12[q] += h[b][q];
+  }
+  if (reset) {
+    std::memset(h, 0, sizeof(h));
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vcy::g_phase_ticks), h, sizeof(h)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
+
+#else  // !VCY_FUSED_PART: the host side and the small kernels
+
 // Exhaustive check of the short division sequences for ONE numerator: every significand of the
 // denominator (blockIdx.x * 256 + threadIdx.x) in every binade 2^-60 .. 2^60 (blockIdx.y) the fast path
 // admits (in_fast_div_range), against the IEEE quotient.  bad[0]: DIV 2 differs somewhere, bad[1]: DIV 1.
@@ -2666,13 +2715,13 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     if (launch_grid.x == 0) {
       // (no workgroup is live: nothing to launch)
     } else if (c->cnt_bytes == 1)
-      launch_fused_1<uint8_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, launch_grid, c->stream, gc, d_views,
-                              d_c2, n_views, m, units_x, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin, wgl, pcnt,
-                              rows ? (int)grid.x : (one_view ? -1 : 0));
+      launch_fused_counts8(big, u.voxel_update, m.trunc != 0, samef, checkmax, launch_grid.x, c->stream, gc, d_views,
+                           d_c2, n_views, m, units_x, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin, wgl, pcnt,
+                           rows ? (int)grid.x : (one_view ? -1 : 0));
     else
-      launch_fused_1<uint16_t>(big, u.voxel_update, m.trunc != 0, samef, checkmax, launch_grid, c->stream, gc, d_views,
-                               d_c2, n_views, m, units_x, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin, wgl, pcnt,
-                               rows ? (int)grid.x : (one_view ? -1 : 0));
+      launch_fused_counts16(big, u.voxel_update, m.trunc != 0, samef, checkmax, launch_grid.x, c->stream, gc, d_views,
+                            d_c2, n_views, m, units_x, nby, c->use_cull ? 1 : 0, state_flags, recs, nbricks, bmin, wgl, pcnt,
+                            rows ? (int)grid.x : (one_view ? -1 : 0));
     VCY_HIP_CHECK(hipGetLastError());
     if (stamp >= 0) VCY_HIP_CHECK(hipEventRecord(c->carve_log[stamp].ev[2], c->stream));
   }
@@ -2791,24 +2840,6 @@ int plan_layer_pairs(vcy_ctx* c, int n_views, const ViewParams* vp, int stride, 
   return VCY_OK;
 }
 
-#ifdef VCY_PHASE_TIMING
-}  // namespace vcy
-// development build only: reads (and optionally clears) the phase counters of the fused kernel
-extern "C" int vcy_debug_phase_ticks(unsigned long long* out12, int reset) {
-  unsigned long long h[256][16];
-  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(vcy::g_phase_ticks), sizeof(h)) != hipSuccess) return -1;
-  for (int q = 0; q < 16; ++q) {
-    out12[q] = 0;
-    for (int b = 0; b < 256; ++b) out12[q] += h[b][q];
-  }
-  if (reset) {
-    std::memset(h, 0, sizeof(h));
-    if (hipMemcpyToSymbol(HIP_SYMBOL(vcy::g_phase_ticks), h, sizeof(h)) != hipSuccess) return -1;
-  }
-  return 0;
-}
-namespace vcy {
-#endif
 
 namespace {
 __global__ void selftest_rcp_count_kernel(int* n_bad) {
@@ -2842,3 +2873,5 @@ int selftest_fused(hipStream_t stream) {
 }
 
 }  // namespace vcy
+
+#endif  // VCY_FUSED_PART
