@@ -41,7 +41,8 @@ for mode in modes:
             print(("%-7s " + PARAM + " %2d rep %d: total %.2f ms | first view %.3f (kernel %.3f) | others avg %.3f (kernel %.3f, min %.3f max %.3f) -> %.0f Mvoxel*views/s")
                   % (mode, rk, rep, tot, pre[0] + ker[0], ker[0], (tot - pre[0] - ker[0]) / (nv - 1), sum(ker[1:]) / (nv - 1),
                      min(ker[1:]), max(ker[1:]), float(n) ** 3 * nv / tot / 1e3))
-    print("%-7s voxels differing between the two kernels after %d views: %d" % (mode, nv, cs[0][1].state_diff(cs[1][1])))
+    if len(cs) > 1:
+        print("%-7s voxels differing between the two kernels after %d views: %d" % (mode, nv, cs[0][1].state_diff(cs[1][1])))
     for _, c, d in cs:
         c.free_device(d)
         c.close()

@@ -164,6 +164,16 @@ constexpr int64_t kRecordBytesMax = (int64_t)2 << 30;  // footprint records of o
 #ifndef VCY_WAVES_WA
 #define VCY_WAVES_WA 6
 #endif
+// The one-view instances (NB == 0) have no view loop to keep registers for: the unit-weight average fits 7 waves (first
+// view on a fresh grid 1.61 -> 1.47 ms, later views 2.53 -> 2.50; 5 waves: 1.81 / 2.65 -- profiles/r06/one_view_waves.txt)
+#ifndef VCY_WAVES_WA_ONE
+#define VCY_WAVES_WA_ONE 7
+#endif
+// ... and kMax 8, which its one tile buffer makes room for in LDS (first view 1.38 -> 1.32 ms, later views 0.537 -> 0.520;
+// the unit-weight average at 8: 2.50 -> 2.82, spills)
+#ifndef VCY_WAVES_ONE
+#define VCY_WAVES_ONE 8
+#endif
 
 
 // Development build only (-DVCY_PHASE_TIMING, profiles/tools/phase_timing.py): s_memtime ticks of every wave,
@@ -1039,15 +1049,18 @@ __global__ __launch_bounds__(kLiveThreads) void live_workgroups_kernel(const Foo
 // (compiled out of the default bilinear + pinhole kernels, where the extra branches cost 16 %).
 // NB: bricks per wave -- 1: a workgroup of kWgWaves waves, a brick each (fused launches of many views); kRowBricks: the
 // few-view flavour described at kRowBricks above (raw tiles, records from the pre-pass, rows of whole bricks).
+template <int UPDATE, bool CHECKMAX, int TQ, bool GEN, int NB>
+constexpr int carve_waves_per_simd() {
+  // (the few-view flavour is bounded by its LDS: 3 - 5 waves per SIMD, registers to spare)
+  if (NB > 1) return NB > 2 ? 4 : 5;
+  if (GEN || CHECKMAX || TQ != kTileRaw || UPDATE == VCY_UPDATE_WEIGHTED_AVERAGE) return VCY_WAVES_CHECKED;
+  if (UPDATE == kUpdateWaUnitWeight) return NB == 0 ? VCY_WAVES_WA_ONE : VCY_WAVES_WA;
+  return NB == 0 ? VCY_WAVES_ONE : VCY_WAVES;
+}
 template <typename CountT, int UPDATE, bool TRUNC, bool SAMEF, bool CHECKMAX, int TQ, bool GEN, int DIV, int NB = 1>
 __global__ __launch_bounds__(64 * (NB > 1 ? kRowWaves : kWgWaves))
-__attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : ((!GEN && !CHECKMAX && TQ == kTileRaw && UPDATE != VCY_UPDATE_WEIGHTED_AVERAGE)
-                                       ? (UPDATE == kUpdateWaUnitWeight ? VCY_WAVES_WA : VCY_WAVES)
-                                       : VCY_WAVES_CHECKED),
-                                   // (the few-view flavour is bounded by its LDS: 3 - 5 waves per SIMD, registers to spare)
-                                   NB > 1 ? (NB > 2 ? 4 : 5) : ((!GEN && !CHECKMAX && TQ == kTileRaw && UPDATE != VCY_UPDATE_WEIGHTED_AVERAGE)
-                                       ? (UPDATE == kUpdateWaUnitWeight ? VCY_WAVES_WA : VCY_WAVES)
-                                       : VCY_WAVES_CHECKED)))) void carve_fused_kernel(GridParams g,
+__attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : carve_waves_per_simd<UPDATE, CHECKMAX, TQ, GEN, NB>(),
+                                   carve_waves_per_simd<UPDATE, CHECKMAX, TQ, GEN, NB>()))) void carve_fused_kernel(GridParams g,
                                                           const FusedView* __restrict__ views,
                                                           const float* __restrict__ c0_all,
                                                           int nviews_arg, ModeParams mode, int nbx,
@@ -1086,7 +1099,9 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : ((!GEN && !CHECKMAX && TQ == kTi
   // cooperative write-back
   extern __shared__ float4 fused_lds[];
   constexpr bool kRaw = TQ == kTileRaw;                  // raw-pixel tiles, loaded straight into LDS
-  constexpr int kTileF4 = tile_f4_per_wave<TQ>();
+  // (NB == 0: ONE tile buffer -- there is no next view to fetch ahead -- and no TileInfo: 18.4 KB per workgroup with the
+  // cooperative write-back's staging instead of 22.5, i.e. eight workgroups per CU where seven fit)
+  constexpr int kTileF4 = NB == 0 ? 64 : tile_f4_per_wave<TQ>();
   // A view can be dropped for a whole wave brick when no voxel of the brick can change:
   //   - use_truncation and every sample is provably < -1 (voxel_carver.cc:478), or
   //   - kMax, every voxel already touched, and every sample is provably <= min(sdf) of the
@@ -1123,7 +1138,8 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : ((!GEN && !CHECKMAX && TQ == kTi
   typedef CountT CountVec8 __attribute__((ext_vector_type(WX)));
   typedef CountVec8 __attribute__((address_space(3))) lds_countvec;
   typedef unsigned long long __attribute__((address_space(3))) lds_u64;
-  float* coop_s = (float*)((TileInfo*)(fused_lds + kWgWaves * kTileF4) + kWgWaves * nviews);
+  float* coop_s = NB == 0 ? (float*)(fused_lds + kWgWaves * kTileF4)
+                          : (float*)((TileInfo*)(fused_lds + kWgWaves * kTileF4) + kWgWaves * nviews);
   CountT* coop_n = (CountT*)(coop_s + 64 * kCoopSdfPitch);
   lds_u64* coop_mask = (lds_u64*)(unsigned long long*)(coop_n + 64 * coop_cnt_pitch<CountT>());
   // A wave that leaves early tells the others that none of its rows is to be stored and that it will not be there to
@@ -2069,8 +2085,7 @@ void launch_fused_4(bool big, bool checkmax, dim3 grid, hipStream_t s, const Gri
 #define VCY_ONE(GEN_, DIV_)                                                                                          \
   hipLaunchKernelGGL((carve_fused_kernel<CountT, UPDATE, TRUNC, SAMEF, false, kTileRaw, GEN_, DIV_, 0>), grid,         \
                      dim3(64 * kWgWaves),                                                                            \
-                     (size_t)kWgWaves * tile_f4_per_wave<kTileRaw>() * sizeof(float4) + (size_t)kWgWaves * sizeof(TileInfo) + \
-                         ((fresh & 8) ? coop_lds_bytes<CountT>() : 0), s,                                            \
+                     (size_t)kWgWaves * 64 * sizeof(float4) + ((fresh & 8) ? coop_lds_bytes<CountT>() : 0), s,          \
                      g, dv, c2, 1, m, nbx, nby, make_block_decode(grid.x, nbx, nby), cull, fresh, recs, nbricks, bmin, wgl, pcnt)
 #ifdef VCY_DEV_BENCH_KERNELS_ONLY
     if (gen || m.div_level != 2 || !SAMEF || sizeof(CountT) != 1 || UPDATE == VCY_UPDATE_WEIGHTED_AVERAGE) {
