@@ -363,6 +363,11 @@ int vcy_reset(vcy_ctx* ctx);
  * footprint record unpacked into registers, no view loop, no second tile buffer): 15 % fewer vector and 27 % fewer
  * scalar instructions per wave, 2.72 -> 2.43-2.53 ms per weighted-average view at 1024^3, the first view on a fresh grid
  * 1.73-1.92 -> 1.37-1.58, kMax 0.60 -> 0.53; 0: the general instance.  Results identical.
+ * "eagerstate" (default -1): launches of up to 8 views over a carved grid request a brick's state next to its footprint
+ * record, before the test that lets a wave leave without it, when nearly every started workgroup will need it: listed
+ * launches (only live workgroups are started) and launches that skipped their list because the last one held most
+ * workgroups; 0 never, 1 every such launch.  One memory round trip less per wave: 2.51 -> 2.35-2.46 ms per
+ * weighted-average view at 1024^3, kMax 0.52 -> 0.49 (profiles/r06/eager_state.txt).  Results identical.
  * "ntstore" (default -1 = 1): the cooperative write-back stores its whole row segments as streaming stores (0: ordinary).
  * "recordbytes" (default 0 = 2 GiB): bytes of footprint records one carve launch may take; a launch whose records would
  * be larger is cut into chunks of whole brick layers (2048^3 x 64 views: 8.6 GB of records, four chunks) -- small values
@@ -379,7 +384,7 @@ int vcy_reset(vcy_ctx* ctx);
  * "inject_carve_failure" (test hook, default 0): the next `value` applications of views fail with
  * VCY_ERR_INTERNAL before anything is launched -- how the tests exercise the error contract of vcy_carve. */
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
-/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep", "mcskip", "mcdirect", "rowkernel", "oneview", "ntstore", "livelist", "livesync", "coopstore", "meshkeys",
+/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep", "mcskip", "mcdirect", "rowkernel", "oneview", "eagerstate", "ntstore", "livelist", "livesync", "coopstore", "meshkeys",
  * "lazycount", "carvetimer"), "count_bytes" / "count_bytes_final" / "carvelog_dropped" (see above), "div_level": the
  * division sequence the last fused launch was instantiated with (2: 4 instructions, 1: 6, 0: full IEEE expansion), or
  * "brick_min_valid": 1 while the brick minima describe the state (every write since the fill went through the fused kernel). */

@@ -1062,6 +1062,10 @@ def test_single_view_launches_with_brick_minima(kw, livelist, recordbytes, coops
     # single-view launches take the kernel instance compiled for ONE view (footprint record in registers, flags from the
     # kept brick minimum); the cases that also cut their launches into chunks run the general instance ("oneview" 0)
     dev.set_param("oneview", 0 if recordbytes else 1)
+    # the state of a brick requested next to its footprint record, before the early-return test ("eagerstate"): by the
+    # library's rule (listed launches, or the last list held most workgroups), and forced on for the unlisted launches,
+    # where most waves then return early with the state in flight
+    dev.set_param("eagerstate", 1 if livelist == 0 else -1)
     orc = O.OracleGrid(opt)
     base = O.make_sdf(masks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
     for i in range(nv):
@@ -1271,6 +1275,7 @@ def test_cooperative_write_back_with_groups_of_views(kw, coopstore, rowkernel):
     # these launches -- a wave walks the four bricks of a row segment, pairs of several views per brick, bricks whose
     # every view is dropped neither read nor stored; 3: launches of up to three views only)
     dev.set_param("rowkernel", rowkernel)
+    dev.set_param("eagerstate", 1 if coopstore == 1 else -1)  # (1: every launch of up to 8 views requests the state early)
     orc = O.OracleGrid(opt)
     d_base = dev.upload_sdf(base)
     noisy = (base + rng.uniform(-0.03, 0.03, base.shape)).astype(np.float32)

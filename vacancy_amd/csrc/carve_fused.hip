@@ -1236,6 +1236,21 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : carve_waves_per_simd<UPDATE, CHE
   // c0 records that shares `nxp / WX` with it: the scalar loads of the run loops had become vector loads (-15 %).
   int brick_lin = (bz * nby + by) * (nxp / WX) + (x_first / WX);
   const int x_seg = x_first, brick_seg = brick_lin;  // (NB > 1: the segment's first brick)
+  // "Eager" launches (state_flags bit 5; launch_carve_fused sets it for few-view launches whose workgroups are nearly all
+  // live -- listed ones, or a weighted-average view that changes nearly every brick): the brick's state is requested HERE,
+  // next to the footprint record, instead of behind the early-return test that needs the record first -- one memory round
+  // trip less in the life of a wave that consists of little else.  (A wave that then returns early has read 2.5 KB for
+  // nothing; y and zl are clamped and x_first < nx, so the addresses are inside the slab.)
+  typedef CountT CountVecE __attribute__((ext_vector_type(WX)));
+  f4 eager_a = f4{0.f, 0.f, 0.f, 0.f}, eager_b = eager_a;
+  CountVecE eager_c = CountVecE{};
+  const bool eager = NB <= 1 && (state_flags & 32) != 0 && (state_flags & 1) == 0 && (g.nx & (WX - 1)) == 0;
+  if (eager) {
+    const int64_t row_e = ((int64_t)zl * g.ny + y) * g.nx + x_first;
+    eager_a = *(const f4*)(g.sdf + row_e);
+    eager_b = *(const f4*)(g.sdf + row_e + 4);
+    eager_c = *(const CountVecE*)((const CountT*)g.cnt + row_e);
+  }
   // ---- prologue: lane vi bounds the footprint of the wave brick in view vi (brick_footprints) -------
   float ub_lane;
 #ifdef VCY_PHASE_TIMING
@@ -1425,8 +1440,15 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : carve_waves_per_simd<UPDATE, CHE
     }
   } else if (vec_io) {
     // (streaming LOADS of the state were measured too: 2.7 -> 5.3 ms per view, profiles/r06/nontemporal.txt)
-    const float4 a = *(const float4*)(g.sdf + row0 + x_first), b4 = *(const float4*)(g.sdf + row0 + x_first + 4);
-    const CountVec cv = *(const CountVec*)(cnt + row0 + x_first);
+    float4 a, b4;
+    CountVec cv;
+    if (eager) {  // (uniform) requested before the footprint record was looked at
+      a = make_float4(eager_a.x, eager_a.y, eager_a.z, eager_a.w), b4 = make_float4(eager_b.x, eager_b.y, eager_b.z, eager_b.w);
+      cv = eager_c;
+    } else {
+      a = *(const float4*)(g.sdf + row0 + x_first), b4 = *(const float4*)(g.sdf + row0 + x_first + 4);
+      cv = *(const CountVec*)(cnt + row0 + x_first);
+    }
     prefetch_first_tile();  // (behind the state's requests, in front of their first use)
     s[0] = a.x, s[1] = a.y, s[2] = a.z, s[3] = a.w, s[4] = b4.x, s[5] = b4.y, s[6] = b4.z, s[7] = b4.w;
 #pragma unroll
@@ -2598,8 +2620,9 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
   // "ntstore": streaming stores whenever the cooperative write-back runs (0: never) -- whole 128-byte segments that this
   // launch does not read again: 0.5 - 1.5 % on single-view launches (profiles/r06/nontemporal.txt)
   const bool nt = coop && c->nt_store != 0;
-  const int state_flags = (c->fresh ? 1 : 0) | (c->cnt_implied ? 2 : 0) | (c->brick_min_valid && !c->fresh ? 4 : 0) |
-                          (coop ? 8 : 0) | (nt ? 16 : 0);
+  // (bit 5, "eager" state requests, is decided per chunk below: it depends on whether the launch is a listed one)
+  const int state_flags_base = (c->fresh ? 1 : 0) | (c->cnt_implied ? 2 : 0) | (c->brick_min_valid && !c->fresh ? 4 : 0) |
+                               (coop ? 8 : 0) | (nt ? 16 : 0);
   // Raw tiles: the footprint records of every (wave brick, view) pair come from a pre-pass (footprint_records_kernel),
   // 8 bytes per pair.  The slab is carved in chunks of whole brick layers so that the records of a chunk stay
   // below kRecordBytesMax (1024^3 x 32 views: 0.5 GiB, one chunk; 2048^3 x 64: nine).
@@ -2681,7 +2704,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     dim3 launch_grid = rows ? dim3(8u * ((grid.x + 8u * kRowWaves - 1) / (8u * kRowWaves))) : grid;
     // few views over a carved grid: only the workgroups with a live (brick, view) pair (live_workgroups_kernel)
     const int* wgl = nullptr;
-    const bool have_min = u.voxel_update == VCY_UPDATE_MAX && (state_flags & 4) != 0 && bmin != nullptr;
+    const bool have_min = u.voxel_update == VCY_UPDATE_MAX && (state_flags_base & 4) != 0 && bmin != nullptr;
     // (not when the list of the previous such launch held most workgroups anyway -- a weighted-average carve touches
     // nearly every brick with every view, and the list pass is then 4 % on top; the count arrives by an asynchronous
     // copy into page-locked memory and is only a hint: reading an older value is harmless)
@@ -2726,6 +2749,14 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
         }
       }
     }
+    // "eagerstate": the workgroups of a few-view launch over a carved grid request their bricks' state next to the
+    // footprint records when nearly all of them will need it: a listed launch (only live workgroups are started), or one
+    // that skipped its list because the last one held most workgroups (-1 that rule, 0 never, 1 every few-view launch).
+    // 1024^3, one view per launch: weighted average 2.51 -> 2.46 ms, kMax 0.521 -> 0.487 (profiles/r06/eager_state.txt).
+    const bool nearly_all_live = wgl != nullptr ? launch_grid.x < grid.x || !list_pays : !list_pays;
+    const bool eager_state = !c->fresh && !rows && !big && n_views <= kLiveListMaxViews &&
+                             (c->eager_state > 0 || (c->eager_state < 0 && nearly_all_live));
+    const int state_flags = state_flags_base | (eager_state ? 32 : 0);
     if (stamp >= 0) VCY_HIP_CHECK(hipEventRecord(c->carve_log[stamp].ev[1], c->stream));
     if (launch_grid.x == 0) {
       // (no workgroup is live: nothing to launch)

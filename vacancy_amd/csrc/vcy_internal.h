@@ -81,6 +81,7 @@ struct vcy_ctx {
   float* d_pz = nullptr;
 
   bool mesh_keys = true;              // vcy_extract_iso also returns the edge key of every vertex (vcy_set_param "meshkeys")
+  int eager_state = -1;               // "eagerstate": few-view launches request a brick's state next to its footprint record instead of behind the early-return test (-1: when most workgroups were live last time, 0 never, 1 always)
   int one_view = 1;                   // "oneview": single-view launches take the kernel instance compiled for one view (carve_fused_kernel NB == 0)
   int nt_store = -1;                  // "ntstore": streaming stores in the cooperative write-back (-1 / 1: whenever it runs -- 0.5 - 1.5 % on single-view launches; 0 never)
   int row_kernel = 0;                 // "rowkernel": launches of up to this many views take the few-view flavour of the fused kernel (a wave walks the bricks of a row segment); -1 = up to 8, 0 = never (the default: measured slower, carve_fused.hip kRowBricks)
