@@ -363,7 +363,7 @@ int vcy_reset(vcy_ctx* ctx);
  * footprint record unpacked into registers, no view loop, no second tile buffer): 15 % fewer vector and 27 % fewer
  * scalar instructions per wave, 2.72 -> 2.43-2.53 ms per weighted-average view at 1024^3, the first view on a fresh grid
  * 1.73-1.92 -> 1.37-1.58, kMax 0.60 -> 0.53; 0: the general instance.  Results identical.
- * "eagerstate" (default -1): launches of up to 8 views over a carved grid request a brick's state next to its footprint
+ * "eagerstate" (default -1): launches of ONE view ("oneview" 1) over a carved grid request a brick's state next to its footprint
  * record, before the test that lets a wave leave without it, when nearly every started workgroup will need it: listed
  * launches (only live workgroups are started) and launches that skipped their list because the last one held most
  * workgroups; 0 never, 1 every such launch.  One memory round trip less per wave: 2.51 -> 2.35-2.46 ms per

@@ -1275,7 +1275,7 @@ def test_cooperative_write_back_with_groups_of_views(kw, coopstore, rowkernel):
     # these launches -- a wave walks the four bricks of a row segment, pairs of several views per brick, bricks whose
     # every view is dropped neither read nor stored; 3: launches of up to three views only)
     dev.set_param("rowkernel", rowkernel)
-    dev.set_param("eagerstate", 1 if coopstore == 1 else -1)  # (1: every launch of up to 8 views requests the state early)
+    dev.set_param("eagerstate", 1 if coopstore == 1 else -1)  # (1: the launches of ONE view request the state early whether listed or not)
     orc = O.OracleGrid(opt)
     d_base = dev.upload_sdf(base)
     noisy = (base + rng.uniform(-0.03, 0.03, base.shape)).astype(np.float32)

@@ -1241,15 +1241,19 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : carve_waves_per_simd<UPDATE, CHE
   // next to the footprint record, instead of behind the early-return test that needs the record first -- one memory round
   // trip less in the life of a wave that consists of little else.  (A wave that then returns early has read 2.5 KB for
   // nothing; y and zl are clamped and x_first < nx, so the addresses are inside the slab.)
+  // Only in the instance compiled for ONE view: in the general one the ten registers, live across the prologue, put
+  // lane spills into the run loops of the 32-view launch that never takes this path.
   typedef CountT CountVecE __attribute__((ext_vector_type(WX)));
   f4 eager_a = f4{0.f, 0.f, 0.f, 0.f}, eager_b = eager_a;
   CountVecE eager_c = CountVecE{};
-  const bool eager = NB <= 1 && (state_flags & 32) != 0 && (state_flags & 1) == 0 && (g.nx & (WX - 1)) == 0;
-  if (eager) {
-    const int64_t row_e = ((int64_t)zl * g.ny + y) * g.nx + x_first;
-    eager_a = *(const f4*)(g.sdf + row_e);
-    eager_b = *(const f4*)(g.sdf + row_e + 4);
-    eager_c = *(const CountVecE*)((const CountT*)g.cnt + row_e);
+  const bool eager = kOne && (state_flags & 32) != 0 && (state_flags & 1) == 0 && (g.nx & (WX - 1)) == 0;
+  if constexpr (kOne) {
+    if (eager) {
+      const int64_t row_e = ((int64_t)zl * g.ny + y) * g.nx + x_first;
+      eager_a = *(const f4*)(g.sdf + row_e);
+      eager_b = *(const f4*)(g.sdf + row_e + 4);
+      eager_c = *(const CountVecE*)((const CountT*)g.cnt + row_e);
+    }
   }
   // ---- prologue: lane vi bounds the footprint of the wave brick in view vi (brick_footprints) -------
   float ub_lane;
@@ -1442,7 +1446,7 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : carve_waves_per_simd<UPDATE, CHE
     // (streaming LOADS of the state were measured too: 2.7 -> 5.3 ms per view, profiles/r06/nontemporal.txt)
     float4 a, b4;
     CountVec cv;
-    if (eager) {  // (uniform) requested before the footprint record was looked at
+    if (kOne && eager) {  // (uniform) requested before the footprint record was looked at
       a = make_float4(eager_a.x, eager_a.y, eager_a.z, eager_a.w), b4 = make_float4(eager_b.x, eager_b.y, eager_b.z, eager_b.w);
       cv = eager_c;
     } else {
@@ -2749,12 +2753,12 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
         }
       }
     }
-    // "eagerstate": the workgroups of a few-view launch over a carved grid request their bricks' state next to the
+    // "eagerstate": the workgroups of a one-view launch over a carved grid request their bricks' state next to the
     // footprint records when nearly all of them will need it: a listed launch (only live workgroups are started), or one
-    // that skipped its list because the last one held most workgroups (-1 that rule, 0 never, 1 every few-view launch).
+    // that skipped its list because the last one held most workgroups (-1 that rule, 0 never, 1 every one-view launch).
     // 1024^3, one view per launch: weighted average 2.51 -> 2.46 ms, kMax 0.521 -> 0.487 (profiles/r06/eager_state.txt).
     const bool nearly_all_live = wgl != nullptr ? launch_grid.x < grid.x || !list_pays : !list_pays;
-    const bool eager_state = !c->fresh && !rows && !big && n_views <= kLiveListMaxViews &&
+    const bool eager_state = !c->fresh && one_view &&
                              (c->eager_state > 0 || (c->eager_state < 0 && nearly_all_live));
     const int state_flags = state_flags_base | (eager_state ? 32 : 0);
     if (stamp >= 0) VCY_HIP_CHECK(hipEventRecord(c->carve_log[stamp].ev[1], c->stream));
