@@ -338,7 +338,7 @@ int vcy_reset(vcy_ctx* ctx);
  * carve kernel -- lies above the iso level (they are outside the surface whatever they hold exactly); 0 reads every
  * brick; 1 skips them where that is the faster pass (voxel rows of 1024 and more: at 512^3 the dense pass wins by 7 - 14 %);
  * 2 skips them on any size (what the parity tests ask for).
- * "mcdirect" (default 8388608): vcy_extract_iso lets its last kernel write a mesh whose GUESSED size (the previous
+ * "mcdirect" (default 33554432): vcy_extract_iso lets its last kernel write a mesh whose GUESSED size (the previous
  * extraction's counts + 25 %) is at most this many bytes straight into the page-locked host arrays it returns -- one
  * enqueue, one wait per call; larger meshes are staged in device memory and copied with their exact sizes.  0: always
  * staged.  Results identical.  "mctiming" 1 (or VCY_MC_TIMING=1 in the environment): the host-side phases of every
@@ -363,6 +363,10 @@ int vcy_reset(vcy_ctx* ctx);
  * footprint record unpacked into registers, no view loop, no second tile buffer): 15 % fewer vector and 27 % fewer
  * scalar instructions per wave, 2.72 -> 2.43-2.53 ms per weighted-average view at 1024^3, the first view on a fresh grid
  * 1.73-1.92 -> 1.37-1.58, kMax 0.60 -> 0.53; 0: the general instance.  Results identical.
+ * "listrecords" (default 1): the live list of a launch of ONE view holds, per listed workgroup, its id, which of its
+ * waves are live and their four footprint records (40 bytes instead of 4): a wave learns its record with its id instead
+ * of one memory round trip later, and needs no brick minimum for a test the list pass has made (kMax at 1024^3:
+ * 0.506 -> 0.496 ms per view).  0: ids only.  Results identical.
  * "eagerstate" (default -1): launches of ONE view ("oneview" 1) over a carved grid request a brick's state next to its footprint
  * record, before the test that lets a wave leave without it, when nearly every started workgroup will need it: listed
  * launches (only live workgroups are started) and launches that skipped their list because the last one held most
@@ -384,7 +388,7 @@ int vcy_reset(vcy_ctx* ctx);
  * "inject_carve_failure" (test hook, default 0): the next `value` applications of views fail with
  * VCY_ERR_INTERNAL before anything is launched -- how the tests exercise the error contract of vcy_carve. */
 int vcy_set_param(vcy_ctx* ctx, const char* name, int value);
-/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep", "mcskip", "mcdirect", "rowkernel", "oneview", "eagerstate", "ntstore", "livelist", "livesync", "coopstore", "meshkeys",
+/* Reads a knob back ("fused", "cull", "tile", "defer", "shortdiv", "mcsweep", "mcskip", "mcdirect", "rowkernel", "oneview", "eagerstate", "listrecords", "ntstore", "livelist", "livesync", "coopstore", "meshkeys",
  * "lazycount", "carvetimer"), "count_bytes" / "count_bytes_final" / "carvelog_dropped" (see above), "div_level": the
  * division sequence the last fused launch was instantiated with (2: 4 instructions, 1: 6, 0: full IEEE expansion), or
  * "brick_min_valid": 1 while the brick minima describe the state (every write since the fill went through the fused kernel). */

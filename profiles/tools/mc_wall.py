@@ -37,7 +37,7 @@ for a in args:
     c, label = bunny(2.5) if a == "bunny" else sphere(int(a))
     c.set_param("meshkeys", 0)
     c.sync()
-    for direct in (0, 8 << 20, 64 << 20, 0, 8 << 20):
+    for direct in (0, 32 << 20, 256 << 20, 0, 32 << 20):
         c.set_param("mcdirect", direct)
         c.ExtractIsoSurface(0.0, True)
         runs = [c.ExtractIsoSurface(0.0, True) for _ in range(9)]
@@ -49,7 +49,7 @@ for a in args:
               % (label, direct, wall[len(wall) // 2], wall[0], dev[len(dev) // 2], dev[0], mb, len(m["vertices"]), len(m["faces"])))
     if os.environ.get("VCY_MC_TIMING_ONCE"):
         c.set_param("mctiming", 1)
-        for direct in (0, 8 << 20):
+        for direct in (0, 32 << 20):
             c.set_param("mcdirect", direct)
             for _ in range(3):
                 c.ExtractIsoSurface(0.0, True)

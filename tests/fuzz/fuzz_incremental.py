@@ -91,6 +91,7 @@ for seed in range(lo, hi):
         # (round 6) the few-view flavour of the fused kernel (a wave walks the bricks of a row segment): its rule, never,
         # launches of up to 2 views only -- drawn from a stream of its own so that the scenes of earlier rounds' seeds stay
         dev.set_param("rowkernel", int(np.random.RandomState(61000 + seed).choice([-1, 0, 0, 2])))
+        dev.set_param("listrecords", int(np.random.RandomState(64000 + seed).choice([1, 1, 0])))  # live-list entries with / without the records
         dev.set_param("eagerstate", int(np.random.RandomState(63000 + seed).choice([-1, -1, 0, 1])))  # state requested next to the footprint record
         dev.set_param("oneview", int(np.random.RandomState(62000 + seed).choice([1, 1, 0])))  # the instance compiled for ONE view, or the general one
         dev.set_param("defer", int(rng.randint(0, 2)))

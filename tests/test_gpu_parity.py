@@ -1066,6 +1066,9 @@ def test_single_view_launches_with_brick_minima(kw, livelist, recordbytes, coops
     # library's rule (listed launches, or the last list held most workgroups), and forced on for the unlisted launches,
     # where most waves then return early with the state in flight
     dev.set_param("eagerstate", 1 if livelist == 0 else -1)
+    # the live list of a one-view launch with the footprint records and per-wave live bits in its entries (the default),
+    # and with workgroup ids only in the cases that force the cooperative write-back
+    dev.set_param("listrecords", 0 if coopstore == 1 else 1)
     orc = O.OracleGrid(opt)
     base = O.make_sdf(masks[0], use_truncation=bool(uo.use_truncation), band=uo.truncation_band)
     for i in range(nv):

@@ -1002,29 +1002,43 @@ __global__ __launch_bounds__(256) void footprint_records_kernel(GridParams g, co
 // most workgroups would only start, load 8 bytes and leave; 2 M such waves cost more than the bricks that do
 // change.  This pass lists the workgroups with a live pair, list[0] = their number, list[1 ...] = their linear
 // ids (any order); the carve kernel is launched over the full range and workgroups beyond list[0] leave at once.
+// Entries WITH RECORDS (launches of one view, `entry_words` = kLiveEntryWords): list[0] = count, list[1] unused, then per
+// listed workgroup {id, bit j = the brick of wave j is live, the kWgWaves footprint records} -- what a wave of the listed
+// launch otherwise fetches AFTER it has learnt its workgroup id from the list: its record (a second round trip in a wave
+// that lasts a handful) and the brick minimum for a test whose outcome is known here.
 constexpr int kLiveThreads = 1024;
+constexpr int kLiveEntryWords = 2 + 2 * kWgWaves;
 __global__ __launch_bounds__(kLiveThreads) void live_workgroups_kernel(const FootprintRecord* __restrict__ recs, int64_t nbricks,
                                                                        int nviews, const float* __restrict__ bmin, int trunc,
                                                                        int nbx, int nby, int nbw, int nwg, int* __restrict__ list,
-                                                                       int unit_bricks) {
+                                                                       int unit_bricks, int entry_words) {
   // (one atomic per block of 1024 workgroups: one per WAVE -- 8192 of them on one counter at 1024^3 -- took 78 us of a
   // 0.8 ms single-view launch, the serialised atomics, not the 25 MB it reads)
   __shared__ int wave_count[kLiveThreads / 64];
   __shared__ int block_base;
   const int wg = blockIdx.x * kLiveThreads + threadIdx.x;
   bool live = false;
+  unsigned live_bricks = 0u;        // bit j: brick j of the unit has a live view
+  FootprintRecord rec0[kWgWaves];   // (entries with records: view 0 of the workgroup's bricks)
+  for (int j = 0; j < kWgWaves; ++j) rec0[j].w0 = 0u, rec0[j].w1 = 0u;
   if (wg < nwg) {
     const int bx = wg % nbx, r = wg / nbx;
     const int by = r % nby, bz = r / nby;
-    for (int j = 0; j < unit_bricks; ++j) {  // (kWgWaves bricks of a workgroup, or the segment of a wave: kRowBricks)
+    constexpr int kUnitMax = kWgWaves > VCY_ROW_BRICKS ? kWgWaves : VCY_ROW_BRICKS;
+#pragma unroll
+    for (int j = 0; j < kUnitMax; ++j) {  // (kWgWaves bricks of a workgroup, or the segment of a wave: kRowBricks)
+      if (j >= unit_bricks) break;
       const int bxw = bx * unit_bricks + j;
       if (bxw >= nbw) break;
       const int64_t brick = ((int64_t)bz * nby + by) * nbw + bxw;
       const float smin = bmin ? bmin[brick] : 0.0f;
       for (int v = 0; v < nviews; ++v) {
-        const float ub = __uint_as_float(recs[(int64_t)v * nbricks + brick].w0 & ~63u);
+        const FootprintRecord rec = recs[(int64_t)v * nbricks + brick];
+        const float ub = __uint_as_float(rec.w0 & ~63u);
         const bool drop = (trunc && ub < -1.0f) || (bmin != nullptr && ub <= smin);
         live = live || !drop;
+        if (!drop) live_bricks |= 1u << j;
+        if (v == 0 && j < kWgWaves) rec0[j] = rec;
       }
     }
   }
@@ -1042,7 +1056,16 @@ __global__ __launch_bounds__(kLiveThreads) void live_workgroups_kernel(const Foo
     block_base = total ? atomicAdd(&list[0], total) : 0;
   }
   __syncthreads();
-  if (live) list[1 + block_base + wave_count[wave] + __popcll(m & ((1ull << lane) - 1ull))] = wg;
+  if (live) {
+    const int slot = block_base + wave_count[wave] + __popcll(m & ((1ull << lane) - 1ull));
+    if (entry_words == 0) {
+      list[1 + slot] = wg;
+    } else {  // (8-byte aligned: the list is, and entry_words is even)
+      int* e = list + 2 + (int64_t)slot * kLiveEntryWords;
+      e[0] = wg, e[1] = (int)live_bricks;
+      for (int j = 0; j < kWgWaves; ++j) e[2 + 2 * j] = (int)rec0[j].w0, e[3 + 2 * j] = (int)rec0[j].w1;
+    }
+  }
 }
 
 // GEN: nearest-neighbour sampling and/or an orthographic camera, selected at run time from `mode`
@@ -1166,10 +1189,27 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : carve_waves_per_simd<UPDATE, CHE
   // NB > 1: the unit of the launch is a SEGMENT (NB bricks of a row) and every wave takes one -- the waves of a
   // workgroup consecutive units of the same XCD's share (b mod 8 = blockIdx mod 8, the XCD the workgroup runs on)
   int b = kRows ? ((int)(blockIdx.x & 7u) + 8 * (kRowWaves * (int)(blockIdx.x >> 3) + wave)) : (int)blockIdx.x;
+  const int* list_entry = nullptr;  // NB == 0, listed launch whose entries hold {id, live waves, records}: this workgroup's
+  int list_live = 0;
+  FootprintRecord list_rec;
+  list_rec.w0 = 0u, list_rec.w1 = 0u;
   if (wg_list != nullptr) {  // only the workgroups live_workgroups_kernel listed (wg_list[0] of them)
     if (kRows) b = (int)blockIdx.x * kRowWaves + wave;
     if (b >= wg_list[0]) return;
-    b = wg_list[1 + b];
+    if (kOne && (state_flags & 64) != 0) {  // entries with records (live_workgroups_kernel)
+      // (VECTOR loads that all lanes share, made uniform afterwards: 40 bytes per workgroup streamed through the scalar
+      // cache evict the view record and the axis tables that every wave re-reads -- measured, like the records before)
+      list_entry = wg_list + 2 + (int64_t)b * kLiveEntryWords;
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      typedef const u32x2 __attribute__((address_space(1))) * gent_ptr;
+      const u32x2 head = ((gent_ptr)list_entry)[0], mine = ((gent_ptr)list_entry)[1 + wave];
+      b = __builtin_amdgcn_readfirstlane((int)head.x);
+      list_live = __builtin_amdgcn_readfirstlane((int)head.y);
+      list_rec.w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine.x);
+      list_rec.w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine.y);
+    } else {
+      b = wg_list[1 + b];
+    }
   } else {
     if (kRows && b >= bd.total) return;
 #if !defined(VCY_XCD_LAYERS) && !defined(VCY_XCD_CONTIGUOUS)
@@ -1220,6 +1260,13 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : carve_waves_per_simd<UPDATE, CHE
   if (x_first >= g.nx) {                    // (a wave may leave alone: see coop_leave)
     coop_leave();
     return;
+  }
+  if constexpr (kOne) {
+    // (the early return below, decided by the list pass on the same record and the same brick minimum)
+    if (list_entry != nullptr && ((list_live >> wave) & 1) == 0) {
+      coop_leave();
+      return;
+    }
   }
   const int zl0 = bz * BZ;
   const int y_raw = by * BY + ly, zl_raw = zl0 + lz;
@@ -1285,9 +1332,13 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : carve_waves_per_simd<UPDATE, CHE
     // tables -- which every wave re-reads -- from the scalar cache (2.72 -> 3.38 ms per weighted-average view).
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef const u32x2 __attribute__((address_space(1))) * grec_ptr;
-    const u32x2 raw = ((grec_ptr)records)[brick_lin];
     FootprintRecord rec;
-    rec.w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.x), rec.w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.y);
+    if (list_entry != nullptr) {  // (arrived with the workgroup id)
+      rec = list_rec;
+    } else {
+      const u32x2 raw = ((grec_ptr)records)[brick_lin];
+      rec.w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.x), rec.w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.y);
+    }
     ti_one = unpack_footprint(rec);
     ub_lane = ti_one.ub;
   } else if (kRaw && records != nullptr) {
@@ -1327,7 +1378,7 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : carve_waves_per_simd<UPDATE, CHE
   // Views that cannot change this brick whatever its voxels hold now: every sample below the truncation limit, or
   // (kMax) not above the brick's minimum as the previous launch left it.  All of them: nothing to read or write.
 #ifndef VCY_NO_EARLY_EXIT
-  if (want_bound && !fresh) {
+  if (want_bound && !fresh && !(kOne && list_entry != nullptr)) {
     const bool have_min = UPDATE == VCY_UPDATE_MAX && (state_flags & 4) != 0 && brick_min != nullptr;
     if (TRUNC || have_min) {
       bool drop0 = TRUNC && ub_lane < -1.0f;
@@ -1376,10 +1427,11 @@ __attribute__((amdgpu_waves_per_eu(NB > 1 ? 1 : carve_waves_per_simd<UPDATE, CHE
   int vi_pre = -1;
   auto prefetch_first_tile = [&]() {
     if constexpr (kRaw) {
+      const bool listed_live = kOne && list_entry != nullptr;  // (the list pass has decided: the one view is live)
       const bool have_min = UPDATE == VCY_UPDATE_MAX && !fresh && (state_flags & 4) != 0 && brick_min != nullptr;
-      if (!(fresh || UPDATE != VCY_UPDATE_MAX || !want_bound || have_min)) return;
+      if (!(fresh || UPDATE != VCY_UPDATE_MAX || !want_bound || have_min || listed_live)) return;
       bool drop = false;
-      if (want_bound) {
+      if (want_bound && !listed_live) {
         if (TRUNC) drop = ub_lane < -1.0f;
         if (have_min) {
           const float smin0 = ((cfloat_ptr)brick_min)[brick_lin];
@@ -2708,6 +2760,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     dim3 launch_grid = rows ? dim3(8u * ((grid.x + 8u * kRowWaves - 1) / (8u * kRowWaves))) : grid;
     // few views over a carved grid: only the workgroups with a live (brick, view) pair (live_workgroups_kernel)
     const int* wgl = nullptr;
+    int list_entry_words = 0;
     const bool have_min = u.voxel_update == VCY_UPDATE_MAX && (state_flags_base & 4) != 0 && bmin != nullptr;
     // (not when the list of the previous such launch held most workgroups anyway -- a weighted-average carve touches
     // nearly every brick with every view, and the list pass is then 4 % on top; the count arrives by an asynchronous
@@ -2718,7 +2771,9 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     if (!big && recs != nullptr && c->use_live_list && need_bound && !c->fresh && n_views <= kLiveListMaxViews && (m.trunc != 0 || have_min) &&
         (list_pays || c->live_list_age % 16 == 0)) {  // (every 16th launch looks again)
       const int nwg = (int)grid.x;
-      const size_t need = sizeof(int) * ((size_t)nwg + 1);  // (the hint below: a race with its copy is benign, it only
+      // (a launch of ONE view: entries {id, live waves, the four records} -- "listrecords" 0: ids only)
+      list_entry_words = one_view && c->list_records != 0 ? kLiveEntryWords : 0;
+      const size_t need = list_entry_words ? sizeof(int) * (2 + (size_t)nwg * kLiveEntryWords) : sizeof(int) * ((size_t)nwg + 1);  // (the hint below: a race with its copy is benign, it only
       // decides whether the NEXT launch lists its workgroups; with several chunks it reflects the last one)
       if (c->wg_list_bytes < need) {
         VCY_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -2730,7 +2785,8 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
       }
       VCY_HIP_CHECK(hipMemsetAsync(c->d_wg_list, 0, sizeof(int), c->stream));
       hipLaunchKernelGGL(live_workgroups_kernel, dim3((unsigned)((nwg + kLiveThreads - 1) / kLiveThreads)), dim3(kLiveThreads), 0, c->stream, recs, nbricks,
-                         n_views, have_min ? bmin : nullptr, m.trunc, units_x, nby, nbw, nwg, c->d_wg_list, unit_bricks);
+                         n_views, have_min ? bmin : nullptr, m.trunc, units_x, nby, nbw, nwg, c->d_wg_list, unit_bricks,
+                         list_entry_words);
       launch_grid = groups_of((unsigned)nwg);  // (every unit started unless the count below arrives)
       VCY_HIP_CHECK(hipGetLastError());
       wgl = c->d_wg_list;
@@ -2760,7 +2816,7 @@ int launch_carve_fused(vcy_ctx* c, const GridParams& g, int n_views, const ViewP
     const bool nearly_all_live = wgl != nullptr ? launch_grid.x < grid.x || !list_pays : !list_pays;
     const bool eager_state = !c->fresh && one_view &&
                              (c->eager_state > 0 || (c->eager_state < 0 && nearly_all_live));
-    const int state_flags = state_flags_base | (eager_state ? 32 : 0);
+    const int state_flags = state_flags_base | (eager_state ? 32 : 0) | (wgl != nullptr && list_entry_words ? 64 : 0);
     if (stamp >= 0) VCY_HIP_CHECK(hipEventRecord(c->carve_log[stamp].ev[1], c->stream));
     if (launch_grid.x == 0) {
       // (no workgroup is live: nothing to launch)

@@ -625,6 +625,10 @@ int vcy_set_param(vcy_ctx* c, const char* name, int value) {
     c->coop_store = value < 0 ? -1 : (value != 0 ? 1 : 0);
     return VCY_OK;
   }
+  if (std::strcmp(name, "listrecords") == 0) {
+    c->list_records = value != 0;
+    return VCY_OK;
+  }
   if (std::strcmp(name, "eagerstate") == 0) {
     c->eager_state = value < 0 ? -1 : (value != 0 ? 1 : 0);
     return VCY_OK;
@@ -681,6 +685,7 @@ int vcy_get_param(vcy_ctx* c, const char* name, int* value) {
   else if (std::strcmp(name, "ntstore") == 0) *value = c->nt_store;
   else if (std::strcmp(name, "oneview") == 0) *value = c->one_view;
   else if (std::strcmp(name, "eagerstate") == 0) *value = c->eager_state;
+  else if (std::strcmp(name, "listrecords") == 0) *value = c->list_records;
   else if (std::strcmp(name, "mcdirect") == 0) *value = (int)std::min<int64_t>(c->mc_direct_bytes, 0x7fffffff);
   else if (std::strcmp(name, "livelist") == 0) *value = c->use_live_list ? 1 : 0;
   else if (std::strcmp(name, "prologue") == 0) *value = c->prologue_mode;

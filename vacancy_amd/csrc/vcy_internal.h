@@ -81,6 +81,7 @@ struct vcy_ctx {
   float* d_pz = nullptr;
 
   bool mesh_keys = true;              // vcy_extract_iso also returns the edge key of every vertex (vcy_set_param "meshkeys")
+  int list_records = 1;               // "listrecords": the live list of a one-view launch carries the footprint records and per-wave live bits (0: workgroup ids only)
   int eager_state = -1;               // "eagerstate": few-view launches request a brick's state next to its footprint record instead of behind the early-return test (-1: when most workgroups were live last time, 0 never, 1 always)
   int one_view = 1;                   // "oneview": single-view launches take the kernel instance compiled for one view (carve_fused_kernel NB == 0)
   int nt_store = -1;                  // "ntstore": streaming stores in the cooperative write-back (-1 / 1: whenever it runs -- 0.5 - 1.5 % on single-view launches; 0 never)
@@ -172,7 +173,7 @@ struct vcy_ctx {
   void* d_mc_flags = nullptr;         // publication flags of the chained scans (mc_kernels.hip, scan_chained_kernel)
   uint32_t mc_scan_epoch = 0;         // ... and the epoch of the last scan (flags never hold a later one)
   void* h_mc_report = nullptr;        // 64 page-locked bytes mc_emit reports an extraction's counts in (extract_iso)
-  int64_t mc_direct_bytes = (int64_t)8 << 20;  // "mcdirect": meshes guessed up to this size are written by mc_emit straight into host memory
+  int64_t mc_direct_bytes = (int64_t)32 << 20;  // "mcdirect": meshes guessed up to this size are written by mc_emit straight into host memory
   int mc_timing = 0;                  // "mctiming" 1 (or VCY_MC_TIMING=1): host-side phases of every extraction on stderr
   uint32_t mc_scan_tickets[2] = {0, 0};  // chunk tickets drawn so far from the two scan slots' counters (scan_chained_kernel)
   void* d_mc_cells = nullptr;         // per-active-cell arrays of the extraction
