@@ -1036,6 +1036,7 @@ _TRUNC = dict(use_truncation=True, truncation_band=0.1)
                           (_TRUNC, 0, 2000, 1, (160, 120), -1),
                           (dict(), 1, 0, -1, (160, 120), 0), (_TSDF, 1, 0, -1, (160, 120), 0), (_TSDF, 1, 0, 0, (160, 120), 0),
                           (_TSDF, 0, 2000, 1, (160, 120), 0), (dict(), 1, 0, 1, (160, 120), 0), (_TRUNC, 0, 2000, 1, (160, 120), 0),
+                          (dict(), 1, 2000, -1, (160, 120), 0), (_TRUNC, 1, 2000, -1, (160, 120), 0),
                           (dict(), 1, 0, -1, (200, 150), -1), (_TSDF, 1, 0, -1, (200, 150), -1)])
 def test_single_view_launches_with_brick_minima(kw, livelist, recordbytes, coopstore, img, rowkernel):
     """The reference's call pattern (examples.cc:117-149): carve ONE view, extract, carve the next ... With
@@ -1060,8 +1061,9 @@ def test_single_view_launches_with_brick_minima(kw, livelist, recordbytes, coops
     dev.set_param("coopstore", coopstore)
     dev.set_param("rowkernel", rowkernel)
     # single-view launches take the kernel instance compiled for ONE view (footprint record in registers, flags from the
-    # kept brick minimum); the cases that also cut their launches into chunks run the general instance ("oneview" 0)
-    dev.set_param("oneview", 0 if recordbytes else 1)
+    # kept brick minimum); the unlisted cases that also cut their launches into chunks run the general instance
+    # ("oneview" 0), the listed ones the one-view instance with a list -- and its records -- per chunk
+    dev.set_param("oneview", 0 if recordbytes and not livelist else 1)
     # the state of a brick requested next to its footprint record, before the early-return test ("eagerstate"): by the
     # library's rule (listed launches, or the last list held most workgroups), and forced on for the unlisted launches,
     # where most waves then return early with the state in flight
