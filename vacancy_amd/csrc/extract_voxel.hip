@@ -22,6 +22,8 @@
 #include <thread>
 #include <vector>
 
+#include <emmintrin.h>  // the host half of ExtractVoxel fills its 800 MB mesh with streaming stores (SSE2: any x86-64)
+
 #include "vcy_internal.h"
 
 namespace vcy {
@@ -94,8 +96,37 @@ int device_exclusive_scan_u64(unsigned long long* d, int64_t n, unsigned long lo
 
 }  // namespace vcy
 
+// Kept voxel ids on the host: page-locked memory from the mesh pool (mesh_host_alloc) -- the copy from the device runs at
+// the link's rate and the pages are there already (a fresh std::vector cost 11 ms for the 36 MB of the bunny's first view:
+// zero-fill, page faults and a staged copy), and vcy_extract_voxel_ids hands the array to its caller as it is.
+struct HostIds {
+  int64_t* p = nullptr;
+  size_t n = 0;
+  HostIds() = default;
+  HostIds(const HostIds&) = delete;
+  HostIds& operator=(const HostIds&) = delete;
+  ~HostIds() { vcy::mesh_host_free(p); }
+  int64_t* release() {
+    int64_t* q = p;
+    p = nullptr, n = 0;
+    return q;
+  }
+};
+
+// (grow-only device scratch kept by the context: an extraction per view allocated and freed twice per call)
+static int xv_reserve(void** buf, size_t* cap, size_t need, hipStream_t s) {
+  using namespace vcy;
+  if (*cap >= need) return VCY_OK;
+  VCY_HIP_CHECK(hipStreamSynchronize(s));
+  if (*buf) (void)hipFree(*buf);
+  *buf = nullptr, *cap = 0;
+  VCY_HIP_CHECK(hipMalloc(buf, need + need / 8));
+  *cap = need + need / 8;
+  return VCY_OK;
+}
+
 // Kept voxel ids of this context's slab, GLOBAL ids in scan order (device predicate + compaction).
-static int kept_voxel_ids(vcy_ctx* c, int inside_empty, std::vector<int64_t>* out_ids) {
+static int kept_voxel_ids(vcy_ctx* c, int inside_empty, HostIds* out_ids) {
   using namespace vcy;
   VCY_HIP_CHECK(hipSetDevice(c->device));
   {
@@ -110,8 +141,8 @@ static int kept_voxel_ids(vcy_ctx* c, int inside_empty, std::vector<int64_t>* ou
   const int nx = c->nx, ny = c->ny, nz = c->nz_local();
   const int64_t n = (int64_t)nx * ny * nz;
   hipStream_t s = c->stream;
-  std::vector<int64_t>& ids = *out_ids;
-  ids.clear();
+  HostIds& ids = *out_ids;
+  vcy::mesh_host_free(ids.release());
   // ---- device: keep bits -> block counts -> scan -> kept voxel ids ---------------------------------
   if (!c->fresh) {  // a fresh grid is untouched everywhere: nothing is kept under either predicate
     const int64_t nblocks = (n + 255) / 256;
@@ -119,8 +150,11 @@ static int kept_voxel_ids(vcy_ctx* c, int inside_empty, std::vector<int64_t>* ou
     const size_t sz_bits = align(sizeof(u64) * (size_t)nblocks * 4);
     const size_t sz_counts = align(sizeof(u64) * ((size_t)nblocks + 1));
     const size_t sz_scan = align(sizeof(u64) * ((size_t)nblocks / 1024 + 64) * 2);
-    char* d_scratch = nullptr;
-    VCY_HIP_CHECK(hipMalloc((void**)&d_scratch, sz_bits + sz_counts + sz_scan + 256));
+    {
+      const int rcs = xv_reserve(&c->d_xv_scratch, &c->xv_scratch_bytes, sz_bits + sz_counts + sz_scan + 256, s);
+      if (rcs != VCY_OK) return rcs;
+    }
+    char* d_scratch = (char*)c->d_xv_scratch;
     u64* d_bits = (u64*)d_scratch;
     u64* d_counts = (u64*)(d_scratch + sz_bits);
     u64* d_scan = (u64*)(d_scratch + sz_bits + sz_counts);
@@ -159,23 +193,29 @@ static int kept_voxel_ids(vcy_ctx* c, int inside_empty, std::vector<int64_t>* ou
       rc = VCY_ERR_TOO_MANY_VOXELS;
     }
     if (rc == VCY_OK && kept > 0) {
-      XV_TRY(hipMalloc((void**)&d_ids, sizeof(int64_t) * (size_t)kept));
+      rc = xv_reserve(&c->d_xv_ids, &c->xv_ids_bytes, sizeof(int64_t) * (size_t)kept, s);
+      d_ids = (int64_t*)c->d_xv_ids;
       if (rc == VCY_OK) {
+        ids.p = (int64_t*)mesh_host_alloc(sizeof(int64_t) * (size_t)kept);
+        if (!ids.p) {
+          set_error("out of host memory for the kept voxel ids");
+          rc = VCY_ERR_INTERNAL;
+        }
+      }
+      if (rc == VCY_OK) {
+        ids.n = (size_t)kept;
         hipLaunchKernelGGL(xv_compact_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, d_bits, d_counts, d_ids);
         XV_TRY(hipGetLastError());
-        ids.resize((size_t)kept);
-        XV_TRY(hipMemcpyAsync(ids.data(), d_ids, sizeof(int64_t) * (size_t)kept, hipMemcpyDeviceToHost, s));
+        XV_TRY(hipMemcpyAsync(ids.p, d_ids, sizeof(int64_t) * (size_t)kept, hipMemcpyDeviceToHost, s));
         XV_TRY(hipStreamSynchronize(s));
       }
     }
 #undef XV_TRY
-    if (d_ids) (void)hipFree(d_ids);
-    (void)hipFree(d_scratch);
     if (rc != VCY_OK) return rc;
   }
   const int64_t first = (int64_t)c->z0 * c->slice;
   if (first)
-    for (int64_t& i : ids) i += first;
+    for (size_t t = 0; t < ids.n; ++t) ids.p[t] += first;
   return VCY_OK;
 }
 
@@ -257,16 +297,63 @@ static int cubes_from_ids(const float* px, const float* py, const float* pz, int
     }
     for (int k = 0; k < 3; ++k) state[k] = lo[k], state[3 + k] = hi[k];
   };
-  auto fill = [&](size_t t0, size_t t1, const float* cr) {
+  // A voxel's 72 vertex floats are 18 vectors of four: vector j starts at component j mod 3, so it is one of three
+  // rotations of (x, y, z, x) of the low corner blended with the same rotation of the high corner by a constant mask;
+  // its 36 indices are 9 constant vectors plus 24 t.  Written with STREAMING stores: the arrays are written once, front
+  // to back, and never read here -- ordinary stores made every line a read (for ownership) and a write-back, 1.6 GB of
+  // traffic for an 800 MB mesh, and 108 scalar stores per voxel (profiles/r06/extract_voxel_phases.txt).
+  // (16-byte alignment: both arrays start on a page or malloc boundary and a voxel is 288 / 144 bytes.)
+  struct FillTables {
+    __m128 sel_hi[18];
+    __m128i tri4[9];
+  };
+  static const FillTables tab = [] {
+    FillTables t;
+    for (int j = 0; j < 18; ++j) {
+      alignas(16) uint32_t m[4];
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * j + e;
+        m[e] = sgn[i / 3][i % 3] < 0 ? 0u : 0xffffffffu;
+      }
+      t.sel_hi[j] = _mm_castsi128_ps(_mm_load_si128((const __m128i*)m));
+    }
+    for (int j = 0; j < 9; ++j) {
+      alignas(16) int32_t q[4];
+      for (int e = 0; e < 4; ++e) q[e] = tri[(4 * j + e) / 3][(4 * j + e) % 3];
+      t.tri4[j] = _mm_load_si128((const __m128i*)q);
+    }
+    return t;
+  }();
+  // (VCY_XV_SCALAR_FILL in the environment: the scalar loop, for comparisons)
+  static const bool scalar_fill = std::getenv("VCY_XV_SCALAR_FILL") != nullptr;
+  const bool aligned16 = (((uintptr_t)out->vertices | (uintptr_t)out->faces) & 15) == 0 && !scalar_fill;
+  auto fill = [&](size_t t0, size_t t1, const float* cr) {  // (cr: readable up to cr[6 (t1 - t0)], one float past the end)
     float* v = out->vertices + 72 * t0;
     int32_t* f = out->faces + 36 * t0;
-    for (size_t t = t0; t < t1; ++t, cr += 6) {
-      for (int q = 0; q < 24; ++q)
-        for (int k = 0; k < 3; ++k) *v++ = cr[(sgn[q][k] < 0 ? 0 : 3) + k];
-      const int32_t base = (int32_t)(24 * t);
-      for (int q = 0; q < 12; ++q)
-        for (int k = 0; k < 3; ++k) *f++ = tri[q][k] + base;
+    if (!aligned16) {  // (never with the library's own arrays; kept for a caller's)
+      for (size_t t = t0; t < t1; ++t, cr += 6) {
+        for (int q = 0; q < 24; ++q)
+          for (int k = 0; k < 3; ++k) *v++ = cr[(sgn[q][k] < 0 ? 0 : 3) + k];
+        const int32_t base = (int32_t)(24 * t);
+        for (int q = 0; q < 12; ++q)
+          for (int k = 0; k < 3; ++k) *f++ = tri[q][k] + base;
+      }
+      return;
     }
+    for (size_t t = t0; t < t1; ++t, cr += 6, v += 72, f += 36) {
+      const __m128 lo = _mm_loadu_ps(cr), hi = _mm_loadu_ps(cr + 3);  // (x, y, z, -)
+      const __m128 L[3] = {_mm_shuffle_ps(lo, lo, _MM_SHUFFLE(0, 2, 1, 0)), _mm_shuffle_ps(lo, lo, _MM_SHUFFLE(1, 0, 2, 1)),
+                           _mm_shuffle_ps(lo, lo, _MM_SHUFFLE(2, 1, 0, 2))};
+      const __m128 H[3] = {_mm_shuffle_ps(hi, hi, _MM_SHUFFLE(0, 2, 1, 0)), _mm_shuffle_ps(hi, hi, _MM_SHUFFLE(1, 0, 2, 1)),
+                           _mm_shuffle_ps(hi, hi, _MM_SHUFFLE(2, 1, 0, 2))};
+      for (int j = 0; j < 18; ++j) {
+        const __m128 m = tab.sel_hi[j];
+        _mm_stream_ps(v + 4 * j, _mm_or_ps(_mm_and_ps(m, H[j % 3]), _mm_andnot_ps(m, L[j % 3])));
+      }
+      const __m128i base = _mm_set1_epi32((int32_t)(24 * t));
+      for (int j = 0; j < 9; ++j) _mm_stream_si128((__m128i*)(f + 4 * j), _mm_add_epi32(tab.tri4[j], base));
+    }
+    _mm_sfence();  // (the stores above are weakly ordered: visible before this thread is joined)
   };
   // (at most 16 threads: hardware_concurrency() counts the cores of the machine, not what a container's quota allows)
   const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
@@ -302,7 +389,8 @@ static int cubes_from_ids(const float* px, const float* py, const float* pz, int
       if (bad_guess) st[0] = std::nextafterf(st[0], 0.0f);
     }
     std::memcpy(c.assumed, st, sizeof(st));
-    float piece[6 * kPiece];
+    float piece[6 * kPiece + 4];  // (+ the float fill()'s last vector load reads past the corners)
+    piece[6 * kPiece] = 0.0f;
     for (size_t t = c.t0; t < c.t1; t += kPiece) {
       const size_t te = std::min(c.t1, t + kPiece);
       run_chain(t, te, st, piece);
@@ -344,18 +432,12 @@ extern "C" int vcy_extract_voxel_ids(vcy_ctx* c, int inside_empty, int64_t** ids
   }
   *ids_out = nullptr;
   *n_out = 0;
-  std::vector<int64_t> ids;
+  HostIds ids;
   const int rc = kept_voxel_ids(c, inside_empty, &ids);
   if (rc != VCY_OK) return rc;
-  if (ids.empty()) return VCY_OK;
-  int64_t* p = (int64_t*)mesh_host_alloc(sizeof(int64_t) * ids.size());
-  if (!p) {
-    set_error("out of host memory");
-    return VCY_ERR_INTERNAL;
-  }
-  std::memcpy(p, ids.data(), sizeof(int64_t) * ids.size());
-  *ids_out = p;
-  *n_out = (int64_t)ids.size();
+  if (ids.n == 0) return VCY_OK;
+  *n_out = (int64_t)ids.n;
+  *ids_out = ids.release();  // (freed by vcy_ids_free: back to the pool)
   return VCY_OK;
 }
 
@@ -404,12 +486,12 @@ extern "C" int vcy_extract_voxel(vcy_ctx* c, int inside_empty, vcy_mesh* out) {
     set_error("vcy_extract_voxel needs the whole grid in one context; for z-slabs: vcy_extract_voxel_ids per slab, then vcy_voxel_cubes");
     return VCY_ERR_UNSUPPORTED;
   }
-  std::vector<int64_t> ids;
+  HostIds ids;
   const double t_a = xv_now();
   const int rc = kept_voxel_ids(c, inside_empty, &ids);
   if (rc != VCY_OK) return rc;
   if (xv_timing()) std::fprintf(stderr, "vcy xv: kept voxel ids (device predicate + compaction + D2H) %.2f ms\n", xv_now() - t_a);
   std::vector<float> py((size_t)c->ny);
   VCY_HIP_CHECK(hipMemcpy(py.data(), c->d_py, sizeof(float) * (size_t)c->ny, hipMemcpyDeviceToHost));
-  return cubes_from_ids(c->h_px, py.data(), c->h_pz, c->nx, c->ny, c->opt.resolution, ids.data(), ids.size(), out);
+  return cubes_from_ids(c->h_px, py.data(), c->h_pz, c->nx, c->ny, c->opt.resolution, ids.p, ids.n, out);
 }

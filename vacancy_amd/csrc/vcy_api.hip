@@ -491,6 +491,8 @@ void vcy_destroy(vcy_ctx* c) {
   (void)hipFree(c->d_cnt);
   (void)hipFree(c->d_cnt_spare);
   (void)hipFree(c->d_halo_tmp);
+  (void)hipFree(c->d_xv_scratch);
+  (void)hipFree(c->d_xv_ids);
   (void)hipFree(c->d_px);
   (void)hipFree(c->d_py);
   (void)hipFree(c->d_pz);

@@ -74,6 +74,10 @@ struct vcy_ctx {
   void* d_cnt_spare = nullptr;        // the counter array of the OTHER width, kept once it exists (set_count_width): a
   size_t cnt_spare_cap = 0;           // reset / carve cycle across the 256th view then allocates and frees nothing
   size_t cnt_cap = 0;                 // bytes allocated behind d_cnt
+  void* d_xv_scratch = nullptr;       // ExtractVoxel: keep bits, block counts, scan scratch (grow-only)
+  size_t xv_scratch_bytes = 0;
+  void* d_xv_ids = nullptr;           // ExtractVoxel: the kept voxel ids before their copy to the host (grow-only)
+  size_t xv_ids_bytes = 0;
   void* d_halo_tmp = nullptr;         // two slices of a neighbour's counters at ITS width (vcy_halo_copy_from)
   size_t halo_tmp_bytes = 0;
   float* d_px = nullptr;
