@@ -1,6 +1,7 @@
 // CPU-only check of the facade's host utilities (no GPU calls): PNG decode of the bunny masks,
 // TUM pose -> w2c arithmetic.  Prints values that tests/test_host.py compares with fixtures.
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -53,6 +54,54 @@ int main(int argc, char* argv[]) {
     long long touched = 0;
     for (int k : n) touched += k > 0;
     std::printf("CUSTOMCAM %d %d %d %d %d %lld\n", a ? 1 : 0, b ? 1 : 0, c ? 1 : 0, d ? 1 : 0, e ? 1 : 0, touched);
+    return 0;
+  }
+  if (argc > 3 && std::string(argv[2]) == "xvtime") {
+    // needs a device: what the class API's extractions cost per call, Mesh included (a fresh Mesh per view, as
+    // examples.cc:117-149 has it).   host_selftest <data dir> xvtime <resolution>
+    std::vector<Eigen::Affine3d> poses;
+    {
+      std::FILE* fp = std::fopen((dir + "/tumpose.txt").c_str(), "r");
+      if (!fp) return 9;
+      int id;
+      double t[3], q[4];
+      while (std::fscanf(fp, "%d %lf %lf %lf %lf %lf %lf %lf", &id, &t[0], &t[1], &t[2], &q[0], &q[1], &q[2], &q[3]) == 8) {
+        Eigen::Translation3d tr;
+        tr.x() = t[0]; tr.y() = t[1]; tr.z() = t[2];
+        Eigen::Quaterniond qu;
+        qu.x() = q[0]; qu.y() = q[1]; qu.z() = q[2]; qu.w() = q[3];
+        poses.push_back(tr * qu);
+      }
+      std::fclose(fp);
+    }
+    vacancy::VoxelCarverOption option;
+    option.bb_min = Eigen::Vector3f(-270.000000f, -364.586151f, -149.982697f);
+    option.bb_max = Eigen::Vector3f(270.000000f, 170.542343f, 277.329224f);
+    option.resolution = (float)std::atof(argv[3]);
+    vacancy::VoxelCarver carver(option);
+    if (!carver.Init()) return 3;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    for (int rep = 0; rep < 2; ++rep) {
+      vacancy::VoxelCarver c2(option);
+      if (!c2.Init()) return 3;
+      for (size_t i = 0; i < 6 && i < poses.size(); ++i) {
+        vacancy::PinholeCamera cam(320, 240, poses[i], Eigen::Vector2f(159.3f, 127.65f), Eigen::Vector2f(258.65f, 258.25f));
+        vacancy::Image1b sil;
+        if (!sil.Load(dir + "/mask_" + vacancy::zfill(i) + ".png")) return 4;
+        vacancy::Image1f sdf;
+        if (!c2.Carve(cam, sil, &sdf)) return 5;
+        double t0 = now();
+        vacancy::Mesh voxels;
+        c2.ExtractVoxel(&voxels);
+        const double t_xv = now() - t0;
+        t0 = now();
+        vacancy::Mesh surface;
+        c2.ExtractIsoSurface(&surface, 0.0);
+        const double t_mc = now() - t0;
+        std::printf("XVTIME rep %d view %zu: ExtractVoxel %.2f ms (%zu vertices), ExtractIsoSurface %.3f ms (%zu vertices)\n", rep, i,
+                    t_xv, voxels.vertices().size(), t_mc, surface.vertices().size());
+      }
+    }
     return 0;
   }
   if (argc > 3 && std::string(argv[2]) == "io") {
