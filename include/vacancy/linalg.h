@@ -16,7 +16,10 @@ namespace Eigen {
 template <typename T, int N>
 struct Vec {
   T v[N];
-  Vec() { for (int i = 0; i < N; ++i) v[i] = T(0); }
+  // Like Eigen's fixed-size vectors: NOT initialised.  (std::vector<Vector3f>::resize(n) then touches nothing, and the
+  // facade fills an 800 MB voxel mesh from several threads instead of zeroing it first on one.)
+  Vec() {}
+  static Vec Zero() { Vec r; for (int i = 0; i < N; ++i) r.v[i] = T(0); return r; }
   Vec(T a, T b) { static_assert(N == 2, ""); v[0] = a; v[1] = b; }
   Vec(T a, T b, T c) { static_assert(N == 3, ""); v[0] = a; v[1] = b; v[2] = c; }
   T& operator[](int i) { return v[i]; }
@@ -100,7 +103,7 @@ template <typename T>
 struct Affine3 {
   Mat3<T> R;
   Vec<T, 3> t;
-  static Affine3 Identity() { Affine3 a; a.R = Mat3<T>::Identity(); return a; }
+  static Affine3 Identity() { Affine3 a; a.R = Mat3<T>::Identity(); a.t = Vec<T, 3>::Zero(); return a; }
   const Mat3<T>& linear() const { return R; }
   Mat3<T>& linear() { return R; }
   const Vec<T, 3>& translation() const { return t; }
@@ -136,7 +139,7 @@ struct Quaterniond {
 };
 
 struct Translation3d {
-  Vec<double, 3> p;
+  Vec<double, 3> p = Vec<double, 3>::Zero();
   double& x() { return p[0]; }
   double& y() { return p[1]; }
   double& z() { return p[2]; }

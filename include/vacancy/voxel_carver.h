@@ -32,8 +32,8 @@ struct VoxelUpdateOption {
 };
 
 struct VoxelCarverOption {
-  Eigen::Vector3f bb_max;
-  Eigen::Vector3f bb_min;
+  Eigen::Vector3f bb_max = Eigen::Vector3f(0.0f, 0.0f, 0.0f);  // (the reference leaves both uninitialised)
+  Eigen::Vector3f bb_min = Eigen::Vector3f(0.0f, 0.0f, 0.0f);
   float resolution{0.1f};
   bool sdf_minmax_normalize{true};
   VoxelUpdateOption update_option;

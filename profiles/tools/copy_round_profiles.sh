@@ -12,7 +12,7 @@ for f in bench_1024x32_default.json bench_512x16_tsdf_config1.json bench_2048x64
   one_view_final.txt one_view_pmc_final.txt row_kernel_final.txt per_view_launches.txt per_view_trace_default.txt \
   per_view_trace_tsdf.txt per_view_tsdf_pmc_final.txt phase_timing.json pmc_1024_marching_cubes.json pmc_1024x32_cull0.json \
   pmc_1024x32_default.json pmc_1024x32_tsdf.json pmc_2048x64_config4.json pmc_512x16_tsdf_config1.json slab_emulation.txt \
-  status.txt streamed_emulation.txt write_ceiling.txt pytest_gpu_final.txt; do
+  status.txt streamed_emulation.txt write_ceiling.txt pytest_gpu_final.txt class_api_extractions.txt; do
   cp $S/$f $D/ 2>/dev/null || echo "missing $f"
 done
 cp $S/bench_2ranks_one_device_rccl.err $D/bench_2ranks_one_device_rccl.err.txt

@@ -71,6 +71,8 @@ VCY_BENCH_FORCE_DEVICE=0 timeout 900 python bench.py --gpus 8 --launch inprocess
 timeout 1200 python profiles/tools/streamed_emulation.py > "$O/streamed_emulation.txt" 2>&1; echo "streamed emulation rc=$?" >> "$O/status.txt"
 timeout 1200 python profiles/tools/slab_emulation.py > "$O/slab_emulation.txt" 2>&1; echo "slab emulation rc=$?" >> "$O/status.txt"
 VCY_XV_TIMING=1 timeout 300 python profiles/tools/xv_timing.py > "$O/extract_voxel_phases.txt" 2>&1
+# the same extractions through the C++ class API, Mesh included (a fresh Mesh per view, as examples.cc has it)
+(timeout 300 vacancy_amd/host/host_selftest tests/golden/bunny xvtime 2.5 2>&1 | grep XVTIME) > "$O/class_api_extractions.txt"
 for m in default tsdf; do timeout 300 python profiles/tools/first_view.py 1024 $m; done > "$O/first_view.txt" 2>&1
 # round 6: single-view launches through the instance compiled for one view against the general one, and the few-view
 # flavour (a wave walks the bricks of a row segment) against both; what a marching-cubes CALL costs (wall) per size

@@ -8,6 +8,7 @@
 #include <unordered_map>
 
 #include "vacancy_hip.h"
+#include "mesh_copy.h"
 
 namespace vacancy {
 
@@ -269,10 +270,8 @@ void ShardedVoxelCarver::ExtractVoxel(Mesh* mesh, bool inside_empty) {
     if (vcy_voxel_cubes(&c, static_cast<int64_t>(all.size()), all.data(), &m) == VCY_OK) {
       std::vector<Eigen::Vector3f>* V = mesh->mutable_vertices();
       std::vector<Eigen::Vector3i>* F = mesh->mutable_vertex_indices();
-      V->resize(static_cast<size_t>(m.n_vertices));
-      F->resize(static_cast<size_t>(m.n_faces));
-      if (m.n_vertices) std::memcpy(static_cast<void*>(V->data()), m.vertices, sizeof(float) * 3 * m.n_vertices);
-      if (m.n_faces) std::memcpy(static_cast<void*>(F->data()), m.faces, sizeof(int) * 3 * m.n_faces);
+      detail::CopyTriples(V, m.vertices, static_cast<size_t>(m.n_vertices));
+      detail::CopyTriples(F, m.faces, static_cast<size_t>(m.n_faces));
     } else {
       LOGE("%s\n", vcy_last_error());
     }
@@ -320,8 +319,7 @@ void ShardedVoxelCarver::ExtractIsoSurface(Mesh* mesh, double iso_level, bool li
       }
       for (int64_t i = 0; i < nown; ++i) remap[nfo + i] = static_cast<int>(offset + i);
       const size_t v0 = V->size(), f0 = F->size();
-      V->resize(v0 + nown);
-      if (nown) std::memcpy(static_cast<void*>(V->data() + v0), m.vertices + 3 * nfo, sizeof(float) * 3 * nown);
+      detail::CopyTriples(V, m.vertices + 3 * nfo, static_cast<size_t>(nown), v0);
       F->resize(f0 + m.n_faces);
       for (int64_t i = 0; i < m.n_faces; ++i)
         (*F)[f0 + i] = Eigen::Vector3i(remap[m.faces[3 * i]], remap[m.faces[3 * i + 1]], remap[m.faces[3 * i + 2]]);

@@ -7,6 +7,7 @@
 #include <limits>
 
 #include "vacancy_hip.h"
+#include "mesh_copy.h"
 
 namespace vacancy {
 
@@ -285,10 +286,8 @@ void VoxelCarver::ExtractIsoSurface(Mesh* mesh, double iso_level, bool linear_in
   static_assert(sizeof(Eigen::Vector3i) == 3 * sizeof(int), "packed vector layout");
   std::vector<Eigen::Vector3f>* v = mesh->mutable_vertices();
   std::vector<Eigen::Vector3i>* f = mesh->mutable_vertex_indices();
-  v->resize(static_cast<size_t>(m.n_vertices));
-  f->resize(static_cast<size_t>(m.n_faces));
-  if (m.n_vertices) std::memcpy(static_cast<void*>(v->data()), m.vertices, sizeof(float) * 3 * m.n_vertices);
-  if (m.n_faces) std::memcpy(static_cast<void*>(f->data()), m.faces, sizeof(int) * 3 * m.n_faces);
+  detail::CopyTriples(v, m.vertices, static_cast<size_t>(m.n_vertices));
+  detail::CopyTriples(f, m.faces, static_cast<size_t>(m.n_faces));
   vcy_mesh_free(&m);
   LOGI("MarchingCubes %02f\n", NowMs() - t0);
 }
@@ -307,10 +306,8 @@ void VoxelCarver::ExtractVoxel(Mesh* mesh, bool inside_empty) {
   LogAppliedCarves(impl_->ctx, &impl_->carve_timer);
   std::vector<Eigen::Vector3f>* v = mesh->mutable_vertices();
   std::vector<Eigen::Vector3i>* f = mesh->mutable_vertex_indices();
-  v->resize(static_cast<size_t>(m.n_vertices));
-  f->resize(static_cast<size_t>(m.n_faces));
-  if (m.n_vertices) std::memcpy(static_cast<void*>(v->data()), m.vertices, sizeof(float) * 3 * m.n_vertices);
-  if (m.n_faces) std::memcpy(static_cast<void*>(f->data()), m.faces, sizeof(int) * 3 * m.n_faces);
+  detail::CopyTriples(v, m.vertices, static_cast<size_t>(m.n_vertices));
+  detail::CopyTriples(f, m.faces, static_cast<size_t>(m.n_faces));
   vcy_mesh_free(&m);
   LOGI("VoxelCarver::ExtractVoxel %02f\n", NowMs() - t0);
 }
