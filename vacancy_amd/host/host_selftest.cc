@@ -3,12 +3,15 @@
 #include <cmath>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "vacancy/camera.h"
 #include "vacancy/image.h"
 #include "vacancy/mesh.h"
+#include "vacancy/sharded_voxel_carver.h"
 #include "vacancy/voxel_carver.h"
 
 namespace {
@@ -81,9 +84,15 @@ int main(int argc, char* argv[]) {
     vacancy::VoxelCarver carver(option);
     if (!carver.Init()) return 3;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const int n_slabs = argc > 4 ? std::atoi(argv[4]) : 0;  // > 0: the same views through ShardedVoxelCarver (z-slabs on device 0)
     for (int rep = 0; rep < 2; ++rep) {
       vacancy::VoxelCarver c2(option);
       if (!c2.Init()) return 3;
+      std::unique_ptr<vacancy::ShardedVoxelCarver> sh;
+      if (n_slabs > 0) {
+        sh.reset(new vacancy::ShardedVoxelCarver(option, {0}, n_slabs));
+        if (!sh->Init()) return 6;
+      }
       for (size_t i = 0; i < 6 && i < poses.size(); ++i) {
         vacancy::PinholeCamera cam(320, 240, poses[i], Eigen::Vector2f(159.3f, 127.65f), Eigen::Vector2f(258.65f, 258.25f));
         vacancy::Image1b sil;
@@ -98,6 +107,20 @@ int main(int argc, char* argv[]) {
         vacancy::Mesh surface;
         c2.ExtractIsoSurface(&surface, 0.0);
         const double t_mc = now() - t0;
+        if (sh) {
+          if (!sh->Carve(cam, sil)) return 7;
+          t0 = now();
+          vacancy::Mesh sm;
+          sh->ExtractIsoSurface(&sm, 0.0);
+          const double t_s = now() - t0;
+          t0 = now();
+          vacancy::Mesh sv;
+          sh->ExtractVoxel(&sv);
+          std::printf("XVTIME rep %d view %zu: %d slabs: ExtractIsoSurface %.3f ms (%zu vertices, identical %d), ExtractVoxel %.2f ms (%zu vertices)\n", rep, i,
+                      sh->slab_count(), t_s, sm.vertices().size(),
+                      sm.vertices().size() == surface.vertices().size() && sm.vertex_indices().size() == surface.vertex_indices().size() ? 1 : 0,
+                      now() - t0, sv.vertices().size());
+        }
         std::printf("XVTIME rep %d view %zu: ExtractVoxel %.2f ms (%zu vertices), ExtractIsoSurface %.3f ms (%zu vertices)\n", rep, i,
                     t_xv, voxels.vertices().size(), t_mc, surface.vertices().size());
       }

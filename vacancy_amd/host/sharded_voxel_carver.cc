@@ -56,6 +56,7 @@ struct ShardedVoxelCarver::Impl {
   int per_device = 1;
   std::vector<int> wanted_bounds;  // PlanPartition / set_z_bounds; empty: equal thickness
   std::vector<int> bounds;         // of the slabs that exist
+  int64_t slice = 0;               // voxels per z slice of the grid (nx * ny)
   std::vector<vcy_ctx*> slabs;  // in z order
   bool peer_copy_halo = false;
   ~Impl() {
@@ -157,6 +158,7 @@ bool ShardedVoxelCarver::Init() {
     else if (!w.empty()) LOGW("ShardedVoxelCarver: the given z bounds do not fit %d slabs of this grid; equal thickness\n", count);
   }
   impl_->bounds = bounds;
+  impl_->slice = static_cast<int64_t>(dims[0]) * dims[1];
   for (int s = 0; s < count; ++s) {
     const int z0 = bounds[s], z1 = bounds[s + 1];
     vcy_ctx* ctx = nullptr;
@@ -304,6 +306,12 @@ void ShardedVoxelCarver::ExtractIsoSurface(Mesh* mesh, double iso_level, bool li
     std::vector<Eigen::Vector3i>* F = mesh->mutable_vertex_indices();
     std::unordered_map<std::pair<int64_t, int64_t>, int, KeyHash> prev;
     int64_t offset = 0;
+    {
+      size_t total_v = 0, total_f = 0;
+      for (const vcy_mesh& m : parts) total_v += static_cast<size_t>(m.n_vertices - m.n_foreign_vertices), total_f += static_cast<size_t>(m.n_faces);
+      V->reserve(total_v);
+      F->reserve(total_f);
+    }
     for (size_t s = 0; s < ns && ok; ++s) {
       const vcy_mesh& m = parts[s];
       const int64_t nfo = m.n_foreign_vertices, nown = m.n_vertices - nfo;
@@ -324,9 +332,16 @@ void ShardedVoxelCarver::ExtractIsoSurface(Mesh* mesh, double iso_level, bool li
       for (int64_t i = 0; i < m.n_faces; ++i)
         (*F)[f0 + i] = Eigen::Vector3i(remap[m.faces[3 * i]], remap[m.faces[3 * i + 1]], remap[m.faces[3 * i + 2]]);
       prev.clear();
-      if (s + 1 < ns)  // only vertices on this slab's top plane can be referenced from above
-        for (int64_t i = 0; i < nown; ++i)
-          prev[{m.edge_keys[2 * (nfo + i)], m.edge_keys[2 * (nfo + i) + 1]}] = static_cast<int>(offset + i);
+      if (s + 1 < ns) {
+        // Only vertices on this slab's top plane can be referenced from above: edges with both voxels in the slice below
+        // the next slab (vcy_mesh::n_foreign_vertices; keys are (lower, higher) GLOBAL voxel ids).  Entering every vertex
+        // made the merge 35 ms for a 600 K-vertex mesh in 8 slabs, where the extraction itself takes 2.
+        const int64_t lo = static_cast<int64_t>(impl_->bounds[s + 1] - 1) * impl_->slice, hi = lo + impl_->slice;
+        for (int64_t i = 0; i < nown; ++i) {
+          const int64_t k0 = m.edge_keys[2 * (nfo + i)], k1 = m.edge_keys[2 * (nfo + i) + 1];
+          if (k0 >= lo && k1 < hi) prev[{k0, k1}] = static_cast<int>(offset + i);
+        }
+      }
       offset += nown;
     }
   }
