@@ -98,8 +98,10 @@ int main(int argc, char* argv[]) {
         vacancy::Image1b sil;
         if (!sil.Load(dir + "/mask_" + vacancy::zfill(i) + ".png")) return 4;
         vacancy::Image1f sdf;
-        if (!c2.Carve(cam, sil, &sdf)) return 5;
         double t0 = now();
+        if (!c2.Carve(cam, sil, &sdf)) return 5;
+        const double t_carve = now() - t0;
+        t0 = now();
         vacancy::Mesh voxels;
         c2.ExtractVoxel(&voxels);
         const double t_xv = now() - t0;
@@ -121,8 +123,8 @@ int main(int argc, char* argv[]) {
                       sm.vertices().size() == surface.vertices().size() && sm.vertex_indices().size() == surface.vertex_indices().size() ? 1 : 0,
                       now() - t0, sv.vertices().size());
         }
-        std::printf("XVTIME rep %d view %zu: ExtractVoxel %.2f ms (%zu vertices), ExtractIsoSurface %.3f ms (%zu vertices)\n", rep, i,
-                    t_xv, voxels.vertices().size(), t_mc, surface.vertices().size());
+        std::printf("XVTIME rep %d view %zu: Carve(silhouette, &sdf) %.3f ms, ExtractVoxel %.2f ms (%zu vertices), ExtractIsoSurface %.3f ms (%zu vertices)\n", rep, i,
+                    t_carve, t_xv, voxels.vertices().size(), t_mc, surface.vertices().size());
       }
     }
     return 0;
