@@ -224,6 +224,15 @@ int vcy_extract_voxel(vcy_ctx* ctx, int inside_empty, vcy_mesh* out);
 int vcy_extract_voxel_ids(vcy_ctx* ctx, int inside_empty, int64_t** ids_out, int64_t* n_out);
 void vcy_ids_free(int64_t* ids);
 int vcy_voxel_cubes(const vcy_carver_option* option, int64_t n_ids, const int64_t* ids, vcy_mesh* out);
+/* The same two calls writing into arrays of the CALLER: once the sizes are known -- 24 vertices and 12 triangles per kept
+ * voxel -- `arrays` is called exactly once (not at all for an empty mesh; a non-zero return is passed on as
+ * VCY_ERR_INTERNAL) and returns where 3 * n_vertices floats and 3 * n_faces int32 go; the host threads that fill them are
+ * the first to touch them.  What a class API whose Mesh owns std::vectors wants (vacancy::VoxelCarver::ExtractVoxel: no
+ * library-owned copy of an 800 MB mesh in between).  16-byte aligned arrays are written with streaming stores. */
+typedef int (*vcy_mesh_arrays_fn)(void* user, int64_t n_vertices, int64_t n_faces, float** vertices, int32_t** faces);
+int vcy_extract_voxel_into(vcy_ctx* ctx, int inside_empty, vcy_mesh_arrays_fn arrays, void* user);
+int vcy_voxel_cubes_into(const vcy_carver_option* option, int64_t n_ids, const int64_t* ids, vcy_mesh_arrays_fn arrays,
+                         void* user);
 
 void vcy_mesh_free(vcy_mesh* mesh);
 /* Milliseconds the device kernels of the last vcy_extract_iso took (hipEvents on the

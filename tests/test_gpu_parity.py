@@ -463,6 +463,13 @@ def test_extract_voxel_predicates_on_adversarial_state():
             assert len(ov["faces"]) > 0
             assert np.array_equal(dv["faces"], ov["faces"]), (max_update, inside_empty)
             assert np.array_equal(dv["vertices"].view(np.uint32), ov["vertices"].view(np.uint32)), (max_update, inside_empty)
+            # the same call writing into arrays the caller's callback returns (vcy_extract_voxel_into: the class API's path)
+            iv = dev.ExtractVoxelInto(inside_empty)
+            assert np.array_equal(iv["faces"], ov["faces"]), (max_update, inside_empty)
+            assert np.array_equal(iv["vertices"].view(np.uint32), ov["vertices"].view(np.uint32)), (max_update, inside_empty)
+    fresh = vc.VoxelCarver(opt)
+    assert fresh.Init()
+    assert len(fresh.ExtractVoxelInto(False)["vertices"]) == 0  # (nothing kept: the callback is never called)
 
 
 def test_degenerate_grids_and_errors():

@@ -326,6 +326,47 @@ def test_voxel_cubes_without_a_gpu_equals_the_oracle():
         assert np.array_equal(np.unique(v[:, 2]), np.unique(np.array([lo_t[2] + pos[t][2], hi_t[2] + pos[t][2]], np.float32)))
 
 
+def test_voxel_cubes_into_the_callers_arrays():
+    """vcy_voxel_cubes_into: the callback is called once with the mesh's sizes (never for an empty mesh) and the arrays it
+    returns hold what vcy_voxel_cubes returns -- 16-byte aligned ones through the streaming-store fill, misaligned ones
+    through the scalar loop."""
+    import ctypes as C
+    from vacancy_amd import capi, carver
+    import bunny_data as B
+    opt = B.bunny_option(2.3)
+    rng = np.random.RandomState(5)
+    ids = np.sort(rng.choice(232 * 233 * 184 // 8, 90000, replace=False)).astype(np.int64)
+    want = carver.voxel_cubes(opt, ids)
+    got = carver.voxel_cubes_into(opt, ids)
+    assert got["calls"] == 1
+    assert np.array_equal(got["vertices"].view(np.uint32), want["vertices"].view(np.uint32))
+    assert np.array_equal(got["faces"], want["faces"])
+    empty = carver.voxel_cubes_into(opt, np.zeros(0, np.int64))
+    assert empty["calls"] == 0 and len(empty["vertices"]) == 0
+    # arrays 4 bytes off a 16-byte boundary, and a callback that refuses
+    lib = capi.load()
+    hold = {}
+
+    def misaligned(user, nv, nf, pv, pf):
+        hold["v"] = np.empty(3 * nv + 4, np.float32)
+        hold["f"] = np.empty(3 * nf + 4, np.int32)
+        ov = (4 - (hold["v"].ctypes.data % 16) // 4 + 1) % 4 or 1
+        of = (4 - (hold["f"].ctypes.data % 16) // 4 + 1) % 4 or 1
+        hold["ov"], hold["of"], hold["nv"], hold["nf"] = ov, of, nv, nf
+        assert (hold["v"].ctypes.data + 4 * ov) % 16 != 0
+        pv[0] = C.cast(hold["v"].ctypes.data + 4 * ov, C.POINTER(C.c_float))
+        pf[0] = C.cast(hold["f"].ctypes.data + 4 * of, C.POINTER(C.c_int32))
+        return 0
+
+    cb = capi.MeshArraysFn(misaligned)
+    assert lib.vcy_voxel_cubes_into(C.byref(opt), len(ids), ids.ctypes.data_as(C.c_void_p), cb, None) == 0, carver.last_error()
+    v = hold["v"][hold["ov"]:hold["ov"] + 3 * hold["nv"]].reshape(-1, 3)
+    f = hold["f"][hold["of"]:hold["of"] + 3 * hold["nf"]].reshape(-1, 3)
+    assert np.array_equal(v.view(np.uint32), want["vertices"].view(np.uint32)) and np.array_equal(f, want["faces"])
+    refuse = capi.MeshArraysFn(lambda user, nv, nf, pv, pf: 1)
+    assert lib.vcy_voxel_cubes_into(C.byref(opt), len(ids), ids.ctypes.data_as(C.c_void_p), refuse, None) != 0
+
+
 def test_voxel_cubes_speculative_chunks_are_checked_and_redone():
     """vcy_voxel_cubes runs the serial cube chain in chunks on host threads, each from a GUESSED incoming state, and checks
     afterwards that every guess equals what the predecessor really left.  (1) a resolution whose half is not a dyadic

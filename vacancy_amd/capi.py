@@ -80,6 +80,11 @@ class Mesh(C.Structure):
     ]
 
 
+# vcy_mesh_arrays_fn: int (*)(void* user, int64 n_vertices, int64 n_faces, float** vertices, int32** faces)
+MeshArraysFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.POINTER(C.c_float)),
+                           C.POINTER(C.POINTER(C.c_int32)))
+
+
 def make_view(w2c_f32, fx, fy, cx, cy, width, height, roi_min=None, roi_max=None, is_ortho=False):
     v = View()
     flat = [float(x) for x in list(w2c_f32.reshape(-1))]
@@ -135,6 +140,8 @@ def load():
         "vcy_extract_voxel_ids": (C.c_int, [vp, C.c_int, P(P(C.c_int64)), P(C.c_int64)]),
         "vcy_ids_free": (None, [P(C.c_int64)]),
         "vcy_voxel_cubes": (C.c_int, [P(CarverOption), C.c_int64, vp, P(Mesh)]),
+        "vcy_extract_voxel_into": (C.c_int, [vp, C.c_int, MeshArraysFn, vp]),
+        "vcy_voxel_cubes_into": (C.c_int, [P(CarverOption), C.c_int64, vp, MeshArraysFn, vp]),
         "vcy_mesh_free": (None, [P(Mesh)]),
         "vcy_last_extract_ms": (C.c_int, [vp, P(C.c_float)]),
         "vcy_last_extract_wall_ms": (C.c_int, [vp, P(C.c_float)]),

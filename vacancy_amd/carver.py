@@ -216,6 +216,24 @@ class VoxelCarver:
         self._lib.vcy_mesh_free(C.byref(m))
         return out
 
+    def ExtractVoxelInto(self, inside_empty=False):
+        """vcy_extract_voxel_into: the voxel mesh written by the library into numpy arrays this call allocates once the
+        sizes are known (what the C++ class API does with its Mesh's vectors)."""
+        got = {"vertices": np.zeros((0, 3), np.float32), "faces": np.zeros((0, 3), np.int32)}
+
+        def provide(user, nv, nf, pv, pf):
+            got["vertices"] = np.empty((nv, 3), np.float32)
+            got["faces"] = np.empty((nf, 3), np.int32)
+            pv[0] = got["vertices"].ctypes.data_as(C.POINTER(C.c_float))
+            pf[0] = got["faces"].ctypes.data_as(C.POINTER(C.c_int32))
+            return 0
+
+        cb = capi.MeshArraysFn(provide)
+        rc = self._lib.vcy_extract_voxel_into(self._ctx, int(inside_empty), cb, None)
+        if rc != 0:
+            raise RuntimeError(last_error())
+        return got
+
     def extract_voxel_ids(self, inside_empty=False):
         """vcy_extract_voxel_ids: GLOBAL ids of the voxels of this slab that ExtractVoxel keeps, in scan order."""
         p, n = C.POINTER(C.c_int64)(), C.c_int64(0)
@@ -397,6 +415,27 @@ def voxel_cubes(option, ids):
            "faces": _mesh_array(m.faces, m.n_faces, 3, np.int32)}
     lib.vcy_mesh_free(C.byref(m))
     return out
+
+
+def voxel_cubes_into(option, ids):
+    """vcy_voxel_cubes_into: as voxel_cubes, into numpy arrays allocated by the callback."""
+    lib = capi.load()
+    ids = np.ascontiguousarray(ids, np.int64)
+    got = {"vertices": np.zeros((0, 3), np.float32), "faces": np.zeros((0, 3), np.int32), "calls": 0}
+
+    def provide(user, nv, nf, pv, pf):
+        got["calls"] += 1
+        got["vertices"] = np.empty((nv, 3), np.float32)
+        got["faces"] = np.empty((nf, 3), np.int32)
+        pv[0] = got["vertices"].ctypes.data_as(C.POINTER(C.c_float))
+        pf[0] = got["faces"].ctypes.data_as(C.POINTER(C.c_int32))
+        return 0
+
+    cb = capi.MeshArraysFn(provide)
+    rc = lib.vcy_voxel_cubes_into(C.byref(option), len(ids), _p(ids), cb, None)
+    if rc != 0:
+        raise RuntimeError(last_error())
+    return got
 
 
 def halo_allgather(carvers):

@@ -230,8 +230,10 @@ static double xv_now() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// (`arrays` null: the mesh in library-owned arrays, *out; else into what the caller's callback returns, *out only counts)
 static int cubes_from_ids(const float* px, const float* py, const float* pz, int nx, int ny, float resolution,
-                          const int64_t* ids, size_t kept, vcy_mesh* out) {
+                          const int64_t* ids, size_t kept, vcy_mesh* out, vcy_mesh_arrays_fn arrays = nullptr,
+                          void* arrays_user = nullptr) {
   using namespace vcy;
   // unit cube of MakeCube(resolution): 6 quads x 4 corners, 12 triangles
   const float h = resolution / 2;
@@ -249,16 +251,27 @@ static int cubes_from_ids(const float* px, const float* py, const float* pz, int
   out->n_faces = (int64_t)kept * 12;
   if (kept == 0) return VCY_OK;  // an empty mesh has no arrays
   const double t_a = xv_now();
-  out->vertices = (float*)mesh_host_alloc(sizeof(float) * 3 * kept * 24);
-  out->faces = (int32_t*)mesh_host_alloc(sizeof(int32_t) * 3 * kept * 12);
-  const double t_b = xv_now();
-  if (!out->vertices || !out->faces) {
-    mesh_host_free(out->vertices);
-    mesh_host_free(out->faces);
-    std::memset(out, 0, sizeof(*out));
-    set_error("out of host memory for the voxel mesh");
-    return VCY_ERR_INTERNAL;
+  if (arrays) {
+    float* v_dst = nullptr;
+    int32_t* f_dst = nullptr;
+    if (arrays(arrays_user, out->n_vertices, out->n_faces, &v_dst, &f_dst) != 0 || !v_dst || !f_dst) {
+      std::memset(out, 0, sizeof(*out));
+      set_error("the caller's callback gave no arrays for the voxel mesh");
+      return VCY_ERR_INTERNAL;
+    }
+    out->vertices = v_dst, out->faces = f_dst;  // (the caller's: cleared again before returning)
+  } else {
+    out->vertices = (float*)mesh_host_alloc(sizeof(float) * 3 * kept * 24);
+    out->faces = (int32_t*)mesh_host_alloc(sizeof(int32_t) * 3 * kept * 12);
+    if (!out->vertices || !out->faces) {
+      mesh_host_free(out->vertices);
+      mesh_host_free(out->faces);
+      std::memset(out, 0, sizeof(*out));
+      set_error("out of host memory for the voxel mesh");
+      return VCY_ERR_INTERNAL;
+    }
   }
+  const double t_b = xv_now();
   // corner value per axis and sign: every corner with the same (axis, sign) went through the same
   // additions, so the reference's 72 running coordinates are these six.
   // Pass 1, serial -- the chain itself: the six values of every kept voxel after Translate(pos) (24 bytes per voxel).
@@ -421,6 +434,7 @@ static int cubes_from_ids(const float* px, const float* py, const float* pz, int
     std::fprintf(stderr, "vcy xv: %zu kept voxels: host buffers %.2f ms, chain + fill in %zu chunks on %zu threads %.2f ms, "
                          "check + %zu chunks done again %.2f ms\n",
                  kept, t_b - t_a, nchunks, nthreads, t_c - t_b, redone, xv_now() - t_c);
+  if (arrays) out->vertices = nullptr, out->faces = nullptr;  // (the caller's arrays: nothing for vcy_mesh_free here)
   return VCY_OK;
 }
 
@@ -443,7 +457,8 @@ extern "C" int vcy_extract_voxel_ids(vcy_ctx* c, int inside_empty, int64_t** ids
 
 extern "C" void vcy_ids_free(int64_t* ids) { vcy::mesh_host_free(ids); }
 
-extern "C" int vcy_voxel_cubes(const vcy_carver_option* o, int64_t n_ids, const int64_t* ids, vcy_mesh* out) {
+static int voxel_cubes_impl(const vcy_carver_option* o, int64_t n_ids, const int64_t* ids, vcy_mesh* out,
+                            vcy_mesh_arrays_fn arrays, void* user) {
   using namespace vcy;
   if (!o || !out || n_ids < 0 || (n_ids > 0 && !ids)) {
     set_error("invalid argument");
@@ -470,10 +485,25 @@ extern "C" int vcy_voxel_cubes(const vcy_carver_option* o, int64_t n_ids, const 
     rc = vcy_axis_positions(o->bb_min, o->bb_max, o->resolution, a, axis[a].data());
     if (rc != VCY_OK) return rc;
   }
-  return cubes_from_ids(axis[0].data(), axis[1].data(), axis[2].data(), dims[0], dims[1], o->resolution, ids, (size_t)n_ids, out);
+  return cubes_from_ids(axis[0].data(), axis[1].data(), axis[2].data(), dims[0], dims[1], o->resolution, ids, (size_t)n_ids, out,
+                        arrays, user);
 }
 
-extern "C" int vcy_extract_voxel(vcy_ctx* c, int inside_empty, vcy_mesh* out) {
+extern "C" int vcy_voxel_cubes(const vcy_carver_option* o, int64_t n_ids, const int64_t* ids, vcy_mesh* out) {
+  return voxel_cubes_impl(o, n_ids, ids, out, nullptr, nullptr);
+}
+
+extern "C" int vcy_voxel_cubes_into(const vcy_carver_option* o, int64_t n_ids, const int64_t* ids, vcy_mesh_arrays_fn arrays,
+                                    void* user) {
+  if (!arrays) {
+    vcy::set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  vcy_mesh counts;
+  return voxel_cubes_impl(o, n_ids, ids, &counts, arrays, user);
+}
+
+static int extract_voxel_impl(vcy_ctx* c, int inside_empty, vcy_mesh* out, vcy_mesh_arrays_fn arrays, void* user) {
   using namespace vcy;
   if (!c || !out) {
     set_error("invalid argument");
@@ -493,5 +523,18 @@ extern "C" int vcy_extract_voxel(vcy_ctx* c, int inside_empty, vcy_mesh* out) {
   if (xv_timing()) std::fprintf(stderr, "vcy xv: kept voxel ids (device predicate + compaction + D2H) %.2f ms\n", xv_now() - t_a);
   std::vector<float> py((size_t)c->ny);
   VCY_HIP_CHECK(hipMemcpy(py.data(), c->d_py, sizeof(float) * (size_t)c->ny, hipMemcpyDeviceToHost));
-  return cubes_from_ids(c->h_px, py.data(), c->h_pz, c->nx, c->ny, c->opt.resolution, ids.p, ids.n, out);
+  return cubes_from_ids(c->h_px, py.data(), c->h_pz, c->nx, c->ny, c->opt.resolution, ids.p, ids.n, out, arrays, user);
+}
+
+extern "C" int vcy_extract_voxel(vcy_ctx* c, int inside_empty, vcy_mesh* out) {
+  return extract_voxel_impl(c, inside_empty, out, nullptr, nullptr);
+}
+
+extern "C" int vcy_extract_voxel_into(vcy_ctx* c, int inside_empty, vcy_mesh_arrays_fn arrays, void* user) {
+  if (!arrays) {
+    vcy::set_error("invalid argument");
+    return VCY_ERR_INVALID_ARG;
+  }
+  vcy_mesh counts;
+  return extract_voxel_impl(c, inside_empty, &counts, arrays, user);
 }

@@ -16,6 +16,37 @@
 namespace vacancy {
 namespace detail {
 
+// Huge pages for a large fresh buffer where the kernel hands them out on request: 400 faults instead of 200 000.
+inline void RequestHugePages(void* p, size_t bytes) {
+#if defined(__linux__)
+  if (bytes < ((size_t)8 << 20)) return;
+  const uintptr_t a0 = (reinterpret_cast<uintptr_t>(p) + ((size_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1);
+  const uintptr_t a1 = (reinterpret_cast<uintptr_t>(p) + bytes) & ~(((uintptr_t)2 << 20) - 1);
+  if (a1 > a0) (void)madvise(reinterpret_cast<void*>(a0), a1 - a0, MADV_HUGEPAGE);
+#else
+  (void)p, (void)bytes;
+#endif
+}
+
+// vcy_mesh_arrays_fn for a Mesh: the library's host threads write the voxel mesh straight into the Mesh's vectors
+// (vcy_extract_voxel_into / vcy_voxel_cubes_into) -- resize() initialises nothing, see CopyTriples.
+template <typename VV, typename VF>
+struct MeshArrays {
+  std::vector<VV>* vertices;
+  std::vector<VF>* faces;
+  static int Provide(void* user, int64_t n_vertices, int64_t n_faces, float** v, int32_t** f) {
+    static_assert(sizeof(VV) == 3 * sizeof(float) && sizeof(VF) == 3 * sizeof(int32_t), "packed vector layout");
+    MeshArrays* a = static_cast<MeshArrays*>(user);
+    a->vertices->resize(static_cast<size_t>(n_vertices));
+    a->faces->resize(static_cast<size_t>(n_faces));
+    RequestHugePages(a->vertices->data(), sizeof(VV) * static_cast<size_t>(n_vertices));
+    RequestHugePages(a->faces->data(), sizeof(VF) * static_cast<size_t>(n_faces));
+    *v = reinterpret_cast<float*>(a->vertices->data());
+    *f = reinterpret_cast<int32_t*>(a->faces->data());
+    return 0;
+  }
+};
+
 // dst[0, n) = the n packed triples at src.  `dst->resize(n)` initialises nothing (Eigen's fixed-size vectors have no
 // default value, and neither has the stand-in of vacancy/linalg.h), so for a large mesh -- ExtractVoxel's is 24 vertices
 // and 12 triangles per kept voxel, 0.8 - 2 GB for the bunny at resolution 2.5 -- the pages of the fresh vector are
@@ -35,13 +66,7 @@ void CopyTriples(std::vector<V>* dst, const S* src, size_t n, size_t offset = 0)
     std::memcpy(d, s, bytes);
     return;
   }
-#if defined(__linux__)
-  {  // huge pages for the fresh buffer where the kernel hands them out on request: 400 faults instead of 200 000
-    const uintptr_t a0 = (reinterpret_cast<uintptr_t>(d) + ((size_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1);
-    const uintptr_t a1 = (reinterpret_cast<uintptr_t>(d) + bytes) & ~(((uintptr_t)2 << 20) - 1);
-    if (a1 > a0) (void)madvise(reinterpret_cast<void*>(a0), a1 - a0, MADV_HUGEPAGE);
-  }
-#endif
+  RequestHugePages(d, bytes);
   const size_t piece = ((bytes + nthreads - 1) / nthreads + 4095) & ~(size_t)4095;
   std::vector<std::thread> pool;
   for (size_t t = 0; t < nthreads; ++t) {

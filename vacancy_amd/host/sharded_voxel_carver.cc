@@ -268,16 +268,12 @@ void ShardedVoxelCarver::ExtractVoxel(Mesh* mesh, bool inside_empty) {
     std::vector<int64_t> all;
     for (size_t s = 0; s < ns; ++s) all.insert(all.end(), ids[s], ids[s] + counts[s]);
     const vcy_carver_option c = ToC(impl_->option);
-    vcy_mesh m;
-    if (vcy_voxel_cubes(&c, static_cast<int64_t>(all.size()), all.data(), &m) == VCY_OK) {
-      std::vector<Eigen::Vector3f>* V = mesh->mutable_vertices();
-      std::vector<Eigen::Vector3i>* F = mesh->mutable_vertex_indices();
-      detail::CopyTriples(V, m.vertices, static_cast<size_t>(m.n_vertices));
-      detail::CopyTriples(F, m.faces, static_cast<size_t>(m.n_faces));
-    } else {
+    typedef detail::MeshArrays<Eigen::Vector3f, Eigen::Vector3i> Arrays;
+    Arrays arrays{mesh->mutable_vertices(), mesh->mutable_vertex_indices()};
+    if (vcy_voxel_cubes_into(&c, static_cast<int64_t>(all.size()), all.data(), &Arrays::Provide, &arrays) != VCY_OK) {
       LOGE("%s\n", vcy_last_error());
+      mesh->Clear();
     }
-    vcy_mesh_free(&m);
   }
   for (int64_t* p : ids) vcy_ids_free(p);
 }

@@ -296,19 +296,16 @@ void VoxelCarver::ExtractVoxel(Mesh* mesh, bool inside_empty) {
   mesh->Clear();
   if (!impl_->ctx) return;
   const double t0 = NowMs();
-  vcy_mesh m;
-  if (vcy_extract_voxel(impl_->ctx, inside_empty ? 1 : 0, &m) != VCY_OK) {
+  // (the library's host threads fill the Mesh's own vectors: no library-owned copy of the mesh in between)
+  typedef detail::MeshArrays<Eigen::Vector3f, Eigen::Vector3i> Arrays;
+  Arrays arrays{mesh->mutable_vertices(), mesh->mutable_vertex_indices()};
+  if (vcy_extract_voxel_into(impl_->ctx, inside_empty ? 1 : 0, &Arrays::Provide, &arrays) != VCY_OK) {
     LOGE("%s\n", vcy_last_error());
-    vcy_mesh_free(&m);
+    mesh->Clear();
     LogAppliedCarves(impl_->ctx, &impl_->carve_timer);
     return;
   }
   LogAppliedCarves(impl_->ctx, &impl_->carve_timer);
-  std::vector<Eigen::Vector3f>* v = mesh->mutable_vertices();
-  std::vector<Eigen::Vector3i>* f = mesh->mutable_vertex_indices();
-  detail::CopyTriples(v, m.vertices, static_cast<size_t>(m.n_vertices));
-  detail::CopyTriples(f, m.faces, static_cast<size_t>(m.n_faces));
-  vcy_mesh_free(&m);
   LOGI("VoxelCarver::ExtractVoxel %02f\n", NowMs() - t0);
 }
 
